@@ -1,0 +1,289 @@
+"""Scenario catalogue shared by the golden-vector generator and the parity tests.
+
+Each scenario is an ``env_params`` dict in the reference's own vocabulary
+(/root/reference/src/pcgym/pcgym.py:32-253 consumes exactly these keys) plus a
+scripted action sequence.  ``gen_golden.py`` feeds the dict to the *reference*
+``make_env`` (run in the build container only); the tests feed the very same
+dict to this repo's ``make_env`` and compare against the committed fixtures.
+
+Configs are the reference's canonical ones:
+  cstr        README.md:16-55, pc-gym_paper/train_policies/cstr/cstr_train.py:12-47
+  four_tank   pc-gym_paper/train_policies/four_tank/4tank_train.py:54-84
+  ME          pc-gym_paper/train_policies/multistage_extraction/me_train.py:55-91
+  cryst       pc-gym_paper/train_policies/crystalisation/cryst_train.py:50-99
+  custom      tests/environment/test_make_env_custom_model.py:66-86 (the only KAT)
+
+This file is this repo's own code: it contains no reference source.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _thirds(n, a, b, c):
+    k = n // 3
+    return [a] * k + [b] * k + [c] * (n - 2 * k)
+
+
+def _halves(n, a, b):
+    k = n // 2
+    return [a] * k + [b] * (n - k)
+
+
+# ----------------------------------------------------------------------------
+# constraint callables in the reference's style g(x,u) <= 0
+# (docs/guides/constraints.md:35-51)
+# ----------------------------------------------------------------------------
+def cons_cstr_T(x, u):
+    return np.array([319 - x[1], x[1] - 331]).reshape(-1,)
+
+
+def cons_cstr_T_u(x, u):
+    # state and input rows mixed
+    return np.array([x[1] - 336.0, 295.2 - u[0], 0.5 * x[0] + 0.001 * x[1] - 0.8]).reshape(-1,)
+
+
+def cons_me(x, u):
+    return np.array([x[8] - 0.45, 0.2 - x[0]]).reshape(-1,)
+
+
+class LinearCustomModel:
+    """Shape of tests/environment/test_make_env_custom_model.py:7-25 (written
+    from the protocol description, pcgym.py:150-153: __call__(x,u), info(),
+    attribute int_method)."""
+
+    def __init__(self, p1=1.0, p2=2.0):
+        self.int_method = "casadi"
+        self.p1 = p1
+        self.p2 = p2
+
+    def __call__(self, x, u):
+        return np.array([self.p1 * x[0] + u[0], self.p2 * x[1]])
+
+    def info(self):
+        return {
+            "parameters": {"p1": self.p1, "p2": self.p2},
+            "states": ["x1", "x2"],
+            "inputs": ["u1"],
+            "disturbances": [],
+        }
+
+
+def _cstr_base(N=60, tsim=26.0):
+    return {
+        "N": N,
+        "tsim": tsim,
+        "SP": {"Ca": _thirds(N, 0.85, 0.9, 0.87)},
+        "o_space": {"low": np.array([0.7, 300, 0.8]), "high": np.array([1, 350, 0.9])},
+        "a_space": {"low": np.array([295]), "high": np.array([302])},
+        "x0": np.array([0.8, 330, 0.8]),
+        "r_scale": {"Ca": 1e3},
+        "model": "cstr",
+        "normalise_a": True,
+        "normalise_o": True,
+    }
+
+
+def _four_tank_base(N=60, tsim=1000.0):
+    return {
+        "N": N,
+        "tsim": tsim,
+        "SP": {"h3": _halves(N, 0.5, 0.1), "h4": _halves(N, 0.2, 0.3)},
+        "o_space": {"low": np.array([0.0] * 6), "high": np.array([0.6] * 6)},
+        "a_space": {"low": np.array([0.1, 0.1]), "high": np.array([10.0, 10.0])},
+        "x0": np.array([0.141, 0.112, 0.072, 0.42, 0.5, 0.2]),
+        "r_scale": {"h3": 1e3, "h4": 1e3},
+        "model": "four_tank",
+        "normalise_a": True,
+        "normalise_o": True,
+    }
+
+
+def _me_base(N=60, tsim=60.0):
+    return {
+        "N": N,
+        "tsim": tsim,
+        "SP": {"X5": _thirds(N, 0.3, 0.4, 0.3)},
+        "o_space": {"low": np.array([0.0] * 10 + [0.3]), "high": np.array([1.0] * 10 + [0.4])},
+        "a_space": {"low": np.array([5.0, 10.0]), "high": np.array([500.0, 1000.0])},
+        "x0": np.array([0.55, 0.3, 0.45, 0.25, 0.4, 0.20, 0.35, 0.15, 0.25, 0.1, 0.3]),
+        "r_scale": {"X5": 1e2},
+        "model": "multistage_extraction",
+        "normalise_a": True,
+        "normalise_o": True,
+    }
+
+
+def _cryst_base(N=30, tsim=30.0):
+    mu = [1478.00986666666, 22995.8230590611, 1800863.24079725, 248516167.940593]
+    cv0 = float(np.sqrt(mu[2] * mu[0] / (mu[1] ** 2) - 1))
+    ln0 = mu[1] / (mu[0] + 1e-6)
+    return {
+        "N": N,
+        "tsim": tsim,
+        "SP": {"CV": [1.0] * N, "Ln": [15.0] * N},
+        "o_space": {
+            "low": np.array([0, 0, 0, 0, 0, 0, 0, 0.9, 14.0]),
+            "high": np.array([1e20, 1e20, 1e20, 1e20, 0.5, 2, 20, 1.1, 16.0]),
+        },
+        "a_space": {"low": np.array([-1.0]), "high": np.array([1.0])},
+        "a_space_act": {"low": np.array([10.0]), "high": np.array([40.0])},
+        "x0": np.array(mu + [0.15861523304, cv0, ln0, 1.0, 15.0]),
+        "model": "crystallization",
+        "normalise_a": True,
+        "normalise_o": True,
+        "a_0": 39.0,
+        "a_delta": True,
+    }
+
+
+def _me_reactive_base(N=40, tsim=40.0):
+    x0 = []
+    for s in range(5):
+        x0 += [1.6 - 0.25 * s, 0.05 + 0.01 * s, 1.2 + 0.1 * s, 0.02 * (s + 1)]
+    return {
+        "N": N,
+        "tsim": tsim,
+        "SP": {"XA5": _halves(N, 0.6, 0.8)},
+        "o_space": {"low": np.array([0.0] * 20 + [0.0]), "high": np.array([3.0] * 20 + [2.0])},
+        "a_space": {"low": np.array([5.0, 10.0]), "high": np.array([50.0, 100.0])},
+        "x0": np.array(x0 + [0.6]),
+        "model": "multistage_extraction_reactive",
+        "normalise_a": True,
+        "normalise_o": True,
+    }
+
+
+def scenarios():
+    """name -> dict(env_params=..., steps=T, action_seed=..., notes=...)."""
+    S = {}
+
+    # 1. BASELINE.json configs[0]: README quick-start, 99-step rollout
+    S["cstr_quickstart"] = dict(
+        env_params={
+            "N": 100,
+            "tsim": 25,
+            "SP": {"Ca": _halves(100, 0.85, 0.9)},
+            "o_space": {"low": np.array([0.7, 300, 0.8]), "high": np.array([1, 350, 0.9])},
+            "a_space": {"low": np.array([295]), "high": np.array([302])},
+            "x0": np.array([0.8, 330, 0.8]),
+            "model": "cstr",
+        },
+        steps=99,
+        action_seed=0,
+    )
+    S["cstr_canonical"] = dict(env_params=_cstr_base(), steps=59, action_seed=1)
+
+    p = _cstr_base()
+    p.update(normalise_a=False, normalise_o=False)
+    S["cstr_raw"] = dict(env_params=p, steps=59, action_seed=2, raw_actions=True)
+
+    # constraints: quirk Q3 (normalised state fed to g) + Q4 penalty per SP key
+    p = _cstr_base()
+    p.update(constraints=cons_cstr_T, done_on_cons_vio=False, r_penalty=True)
+    S["cstr_cons_pen_norm"] = dict(env_params=p, steps=59, action_seed=3)
+
+    p = _cstr_base()
+    p.update(normalise_a=False, normalise_o=False, constraints=cons_cstr_T,
+             done_on_cons_vio=False, r_penalty=True)
+    S["cstr_cons_pen_raw"] = dict(env_params=p, steps=59, action_seed=4, raw_actions=True)
+
+    p = _cstr_base()
+    p.update(normalise_a=False, normalise_o=False, constraints=cons_cstr_T_u,
+             done_on_cons_vio=True, r_penalty=False)
+    S["cstr_cons_done_raw"] = dict(env_params=p, steps=59, action_seed=5, raw_actions=True)
+
+    # disturbances (docs/guides/disturbances.md:5-17)
+    p = _cstr_base()
+    N = p["N"]
+    p.update(
+        disturbances={"Ti": np.repeat([350.0, 345.0, 350.0], [N // 4, N // 2, N - N // 4 - N // 2])},
+        disturbance_bounds={"low": np.array([320.0]), "high": np.array([360.0])},
+    )
+    S["cstr_dist_Ti"] = dict(env_params=p, steps=58, action_seed=6)
+
+    p = _cstr_base()
+    p.update(
+        normalise_o=False,
+        disturbances={
+            "Caf": np.linspace(0.95, 1.05, N),
+            "Ti": 350.0 + 3.0 * np.sin(np.arange(N) / 5.0),
+        },
+        disturbance_bounds={"low": np.array([320.0, 0.9]), "high": np.array([360.0, 1.1])},
+    )
+    S["cstr_dist_both"] = dict(env_params=p, steps=58, action_seed=7)
+
+    S["four_tank_canonical"] = dict(env_params=_four_tank_base(), steps=59, action_seed=8)
+    S["me_canonical"] = dict(env_params=_me_base(), steps=59, action_seed=9,
+                             action_scale=0.25, action_shift=-0.7)
+
+    p = _me_base()
+    N = p["N"]
+    p.update(
+        disturbances={"X0": np.repeat([0.6, 0.7, 0.6], [N // 3, N // 3, N - 2 * (N // 3)])},
+        disturbance_bounds={"low": np.array([0.5]), "high": np.array([0.8])},
+        constraints=cons_me, done_on_cons_vio=False, r_penalty=False,
+        normalise_o=False, normalise_a=False,  # normalise_a + disturbances + constraints
+        # raises in the reference itself (pcgym.py:597-600 broadcasts Nu against na)
+    )
+    S["me_dist_cons"] = dict(env_params=p, steps=58, action_seed=10,
+                             action_scale=0.25, action_shift=-0.7, raw_actions=True)
+
+    S["cryst_adelta"] = dict(env_params=_cryst_base(), steps=29, action_seed=11,
+                             action_scale=0.3, action_shift=-0.2)
+    S["me_reactive"] = dict(env_params=_me_reactive_base(), steps=39, action_seed=12)
+
+    # terminal ("batch") reward path, pcgym.py:502-532: no SP, reward_states
+    p = _cstr_base()
+    del p["SP"]
+    del p["r_scale"]
+    p.update(
+        o_space={"low": np.array([0.7, 300]), "high": np.array([1, 350])},
+        x0=np.array([0.8, 330.0]),
+        reward_states=["Ca", "T"],
+        maximise_reward=False,
+        r_scale={"T": 0.01},
+        N=20,
+        tsim=20 * 26.0 / 60.0,
+    )
+    S["cstr_batch_reward"] = dict(env_params=p, steps=19, action_seed=13)
+
+    # partial observation (pcgym.py:344-347, 495-498)
+    p = _cstr_base()
+    p.update(partial_observation=["Ca"])
+    S["cstr_partial_obs"] = dict(env_params=p, steps=20, action_seed=14)
+
+    # the reference's own known-answer test (custom linear model)
+    S["custom_linear_kat"] = dict(
+        env_params={
+            "custom_model": LinearCustomModel(1.5, 2.5),
+            "a_space": {"low": np.array([-1]), "high": np.array([1])},
+            "o_space": {"low": np.array([-1, -1]), "high": np.array([1, 1])},
+            "SP": {"x2": [2] * 100},
+            "N": 100,
+            "tsim": 10,
+            "x0": np.array([1.0, 1.0]),
+        },
+        steps=5,
+        action_seed=None,
+        fixed_action=0.5,
+    )
+    return S
+
+
+def actions_for(name, sc):
+    """Scripted policy: i.i.d. U(-1,1) (or U(low,high) when normalise_a is off)."""
+    p = sc["env_params"]
+    na = len(p["a_space"]["low"])
+    T = sc["steps"]
+    if sc.get("fixed_action") is not None:
+        return np.full((T, na), sc["fixed_action"], dtype=np.float64)
+    rng = np.random.default_rng(sc["action_seed"])
+    a = rng.uniform(-1.0, 1.0, size=(T, na))
+    a = a * sc.get("action_scale", 1.0) + sc.get("action_shift", 0.0)
+    a = np.clip(a, -1.0, 1.0)
+    if sc.get("raw_actions"):
+        lo = np.asarray(p["a_space"]["low"], dtype=np.float64)
+        hi = np.asarray(p["a_space"]["high"], dtype=np.float64)
+        a = (a + 1.0) * (hi - lo) / 2.0 + lo
+    return a
