@@ -1,0 +1,265 @@
+/*
+ * pcgym_hip.h -- C ABI of libpcgym_hip.so, the MI355X (gfx950) batched
+ * process-control environment engine.
+ *
+ * This is the drop-in boundary for pc-gym's per-timestep hot path.  In the
+ * reference (pc-gym v0.1.8, all Python) that path is
+ *
+ *     make_env.step            src/pcgym/pcgym.py:350-500
+ *       -> integration_engine.casadi_step / jax_step
+ *                              src/pcgym/integrator.py:65-107, 163-182
+ *       -> model.__call__      src/pcgym/model_classes.py:45-62, 370-412,
+ *                                                        790-845, 891-913, 1272-1319
+ *     make_env.reset           src/pcgym/pcgym.py:263-349
+ *
+ * one env per Python object, one CVODES object rebuilt per step.  Here the same
+ * arithmetic runs for B environments per launch, one wavefront lane per
+ * environment, over caller-owned SoA fp64 buffers  field[component][B].
+ *
+ * Conventions
+ *   - plain C types only; no torch / C++ types cross this boundary.
+ *   - every entry point returns an int status: 0 = ok, <0 = PCG_E_* (bad
+ *     argument), >0 = a hipError_t.  Nothing throws, nothing calls exit().
+ *   - all device buffers are caller-owned (e.g. torch tensors); the library
+ *     allocates only the opaque plan (a few KB of device constants).
+ *   - launches are asynchronous on the hipStream_t passed as `stream`
+ *     (NULL = the default stream).  One plan may be driven by one host thread at
+ *     a time; distinct plans / streams / devices are independent.
+ *   - a plan belongs to the device that was current at pcg_plan_create().
+ */
+#ifndef PCGYM_HIP_H
+#define PCGYM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCG_ABI_VERSION 1
+
+#ifndef PCG_API
+#define PCG_API __attribute__((visibility("default")))
+#endif
+
+/* capacity limits (compile-time; per-lane state lives in VGPRs) */
+#define PCG_MAX_NX 20     /* physical states          */
+#define PCG_MAX_NA 4      /* action dims              */
+#define PCG_MAX_NDM 4     /* model disturbance inputs */
+#define PCG_MAX_NSP 4     /* set-point keys           */
+#define PCG_MAX_NCON 8    /* constraint rows          */
+#define PCG_MAX_PARAMS 128
+#define PCG_MAX_NOBS (PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM)
+#define PCG_MAX_NU (PCG_MAX_NA + PCG_MAX_NDM)
+#define PCG_MAX_N 4096    /* episode length (schedule rows staged in LDS) */
+
+/* status codes */
+#define PCG_OK 0
+#define PCG_E_NULL -1        /* required pointer is NULL                 */
+#define PCG_E_MODEL -2       /* unknown model / integrator id            */
+#define PCG_E_DIM -3         /* a dimension is out of range / mismatched */
+#define PCG_E_VALUE -4       /* invalid scalar (dt<=0, substeps<1, ...)  */
+#define PCG_E_PLAN -5        /* plan handle invalid / wrong device       */
+#define PCG_E_UNSUPPORTED -6 /* combination not built                    */
+
+/* model ids: the reference registry keys (pcgym.py:128-148) that are on the hot path */
+enum pcg_model {
+  PCG_MODEL_CSTR = 0,          /* model_classes.py:23-62     nx=2  nu=1 (+Ti,Caf)      */
+  PCG_MODEL_FOUR_TANK = 1,     /* model_classes.py:864-931   nx=4  nu=2                */
+  PCG_MODEL_ME = 2,            /* model_classes.py:346-430   nx=10 nu=2 (+X0,Y6)       */
+  PCG_MODEL_ME_REACTIVE = 3,   /* model_classes.py:763-861   nx=20 nu=2                */
+  PCG_MODEL_CRYST = 4,         /* model_classes.py:1232-1345 nx=7  nu=1                */
+  PCG_MODEL_AFFINE = 5,        /* custom_model whose RHS is affine: dx = A x + B u + c
+                                  (pcgym.py:150-153; the reference's only KAT,
+                                  tests/environment/test_make_env_custom_model.py:66-86) */
+  PCG_MODEL_COUNT = 6
+};
+
+/* integrators replacing integrator.py:90-107 (CVODES) / :65-88 (diffrax Tsit5) */
+enum pcg_integrator {
+  PCG_INT_RK4 = 0,     /* classical RK4, `substeps` equal sub-steps per env step (zero-order hold on u) */
+  PCG_INT_DOPRI5 = 1,  /* adaptive Dormand-Prince 5(4), per-lane step size, rtol/atol
+                          (mirrors integrator.py:61 PIDController(rtol=1e-8, atol=1e-8)) */
+  PCG_INT_COUNT = 2
+};
+
+/* cfg.flags */
+#define PCG_F_NORMALISE_A 0x0001u   /* pcgym.py:59,372-375                                     */
+#define PCG_F_NORMALISE_O 0x0002u   /* pcgym.py:60,483-489                                     */
+#define PCG_F_A_DELTA 0x0004u       /* pcgym.py:57,376-383                                     */
+#define PCG_F_R_PENALTY 0x0008u     /* pcgym.py:121,556-557 / 529-530                          */
+#define PCG_F_DONE_ON_CONS 0x0010u  /* pcgym.py:120,613-614                                    */
+#define PCG_F_NOISE 0x0020u         /* pcgym.py:453-466 multiplicative Gaussian obs noise      */
+#define PCG_F_REWARD_BATCH 0x0040u  /* terminal reward, pcgym.py:502-532 (else SP reward)      */
+#define PCG_F_MAXIMISE 0x0080u      /* batch reward sign, pcgym.py:524-527                     */
+#define PCG_F_REF_COMPAT 0x0100u    /* replicate reference quirks Q1 (double action
+                                       de-normalisation when normalise_a && a_delta,
+                                       pcgym.py:372-379) and Q3 (constraint rows see a
+                                       re-"de-normalised" state/input, pcgym.py:597-608)       */
+#define PCG_F_GAUSS_DIST 0x0200u    /* extension: d = d_sched + d_sigma*z, z~N(0,1) Philox,
+                                       clipped to [d_clip_lo,d_clip_hi] (BASELINE configs[4])  */
+#define PCG_F_X0_NORMAL 0x0400u     /* reset-time x0 uncertainty is normal (else uniform),
+                                       pcgym.py:255-261                                        */
+
+/*
+ * Environment configuration: the numeric content of the reference's
+ * env_params dict (pcgym.py:32-253).  All arrays are small HOST arrays, copied
+ * at pcg_plan_create(); pointers may be NULL when the matching count is 0.
+ *
+ * Layout of one env's "state"/observation vector, as in the reference
+ * (pcgym.py:160-165,291-298,409-410,432-438):
+ *      [ x(0..nx) | SP slot (nsp_obs) | configured disturbances (nd) ]  Nobs = nx+nsp_obs+nd
+ * and of the model input vector (pcgym.py:371,386-404):
+ *      uk = [ action (na) | model disturbance inputs (ndm) ]            Nu = na+ndm
+ */
+typedef struct pcg_env_cfg {
+  int32_t model_id;       /* enum pcg_model */
+  int32_t integrator_id;  /* enum pcg_integrator */
+  int32_t nx;             /* physical states (reference: Nx_oracle)                     */
+  int32_t na;             /* action dims (len(a_space.low))                             */
+  int32_t ndm;            /* len(model.info()["disturbances"]) if disturbances active, else 0 */
+  int32_t nd;             /* configured disturbance keys (reference: Nd), <= ndm         */
+  int32_t nsp;            /* len(SP)                                                    */
+  int32_t nsp_obs;        /* SP slots present in the state/obs vector: nsp when x0 carries them
+                             (len(x0) == nx+nsp, the documented form), 0 when x0 has only the nx
+                             physical states -- the reference then silently drops the SP slot
+                             (pcgym.py:438 assigns into an empty slice), as in its own KAT      */
+  int32_t ncon;           /* constraint rows (reference: n_con)                         */
+  int32_t nrew;           /* batch reward: number of reward states                      */
+  int32_t N;              /* episode length (reference: N); done when t == N-1          */
+  int32_t substeps;       /* RK4 sub-steps per env step (>=1)                           */
+  int32_t max_steps;      /* DOPRI5: step budget per env step (accepted+rejected)       */
+  uint32_t flags;         /* PCG_F_*                                                    */
+  int32_t n_params;
+  double dt;              /* tsim / N  (pcgym.py:110)                                   */
+  double rtol, atol;      /* DOPRI5 tolerances                                          */
+
+  const double* params;   /* [n_params] model parameters, order = pcg_model_param_names() */
+  const double* x0;       /* [nx+nsp_obs] reference x0 incl. SP slots (pcgym.py:108,284) */
+  const double* x0_unc;   /* [nx] or NULL: reset-time x0 uncertainty fraction (pcgym.py:285-288) */
+  const double* a_low;    /* [na] a_space                                               */
+  const double* a_high;   /* [na]                                                       */
+  const double* a_act_low;   /* [na] a_space_act (a_delta clip), pcgym.py:383           */
+  const double* a_act_high;  /* [na]                                                    */
+  const double* a_0;      /* [na] a_delta initial action (pcgym.py:58,320)              */
+  const double* o_low;    /* [Nobs] observation_space_base incl. disturbance bounds     */
+  const double* o_high;   /* [Nobs]                                                     */
+  const uint8_t* obs_mask;/* [nx] or NULL: 1 = observed (partial_observation)           */
+  const int32_t* sp_index;/* [nsp] state index of each SP key (pcgym.py:553)            */
+  const double* sp;       /* [nsp][N] set-point schedules                               */
+  const double* r_scale;  /* [nsp] (SP reward) or [nrew] (batch reward)                 */
+  const int32_t* rew_index;  /* [nrew] batch reward state indices                       */
+  const int32_t* d_slot;  /* [nd] for each configured key, its index in the model's
+                             disturbance list (ascending; pcgym.py:392-398)             */
+  const double* d_sched;  /* [nd][N] disturbance schedules (pcgym.py:173,394)           */
+  const double* d_default;/* [ndm] model default for unconfigured inputs (pcgym.py:400-404) */
+  const double* d_sigma;  /* [nd] PCG_F_GAUSS_DIST                                      */
+  const double* d_clip_lo;/* [nd]                                                       */
+  const double* d_clip_hi;/* [nd]                                                       */
+  const double* con_A;    /* [ncon][Nobs+Nu] affine constraint rows g = A.[state;uk] - b <= 0,
+                             the declarative form of the reference's callable g(x,u)
+                             (pcgym.py:560-577, docs/guides/constraints.md:35-51)       */
+  const double* con_b;    /* [ncon]                                                     */
+  const double* noise_pct;/* [nx] per-state noise fraction (pcgym.py:454-466)           */
+} pcg_env_cfg;
+
+/*
+ * Per-call device buffers (caller-owned, SoA, fp64 unless noted).
+ * "in/out" buffers are updated in place.
+ */
+typedef struct pcg_buffers {
+  int64_t B;          /* environments in this launch                                            */
+  double* x;          /* [nx][B]    in/out  physical state                                      */
+  const double* a;    /* [na][B]    in      policy action (normalised if PCG_F_NORMALISE_A)     */
+  const double* d;    /* [nd][B]    in|NULL per-env explicit disturbance values for this step;
+                                            NULL = use the plan's shared schedule               */
+  int32_t* t;         /* [B]        in/out|NULL per-env step counter; NULL = lock-stepped batch,
+                                            the scalar `t` argument is used                     */
+  double* a_save;     /* [na][B]    in/out|NULL a_delta accumulator (required with PCG_F_A_DELTA) */
+  double* obs;        /* [Nobs][B]  out     observation                                         */
+  double* rew;        /* [B]        out     reward                                              */
+  uint8_t* done;      /* [B]        out     episode finished                                    */
+  uint8_t* viol;      /* [B]        out|NULL any constraint row > 0 after the step              */
+  double* g;          /* [ncon][B]  out|NULL constraint rows after the step (cons_info[:,t,:])  */
+  double* g_pre;      /* [ncon][B]  out|NULL rows of the pre-step check the reference runs when
+                                            t==0 (pcgym.py:416-420); untouched for other t      */
+  int32_t* nsteps;    /* [2][B]     out|NULL DOPRI5 accepted / rejected step counts             */
+} pcg_buffers;
+
+typedef struct pcg_plan pcg_plan; /* opaque */
+
+/* library / ABI version (PCG_ABI_VERSION). */
+PCG_API int pcg_version(void);
+
+/* human-readable text for a status returned by any entry point (static storage). */
+PCG_API const char* pcg_strerror(int status);
+
+/* model metadata = model.info() of the reference (model_classes.py:8-20, 414-430, ...):
+ * fills nx, nu (inputs), ndm (disturbance inputs), n_params.  */
+PCG_API int pcg_model_info(int model_id, int32_t* nx, int32_t* nu, int32_t* ndm, int32_t* n_params);
+
+/* default parameter vector of a model, in the order the kernels expect
+ * (= declaration order of the reference dataclass fields).  out has n_params slots. */
+PCG_API int pcg_model_default_params(int model_id, double* out, int32_t n_out);
+
+/* Build a plan: validates cfg, folds the affine maps (action de-normalisation,
+ * observation normalisation, compat transforms) and uploads constants and
+ * schedules to the current device.  Replaces integration_engine.__init__
+ * (integrator.py:19-63) + make_env._setup_* numeric state (pcgym.py:56-253). */
+PCG_API int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg);
+PCG_API int pcg_plan_destroy(pcg_plan* plan);
+
+/* Algorithmic HBM bytes one env-step moves for this plan and buffer set
+ * (SURVEY.md section 8d formula); used by bench.py for the roofline line. */
+PCG_API int64_t pcg_plan_bytes_per_env_step(const pcg_plan* plan, const pcg_buffers* io);
+
+/* One fused environment step for B envs: replaces make_env.step (pcgym.py:350-500):
+ * action map -> disturbance injection -> ODE integration over [0,dt] -> SP slot ->
+ * constraint rows -> done -> observation noise -> reward -> observation normalisation.
+ * `t` is the pre-step counter for lock-stepped batches (io->t == NULL).
+ * `seed` keys the counter-based RNG (Philox4x32-10 on (seed, env index, t)). */
+PCG_API int pcg_step(pcg_plan* plan, const pcg_buffers* io, int32_t t, uint64_t seed, void* stream);
+
+/* Reset (pcgym.py:263-349): x <- x0 (with optional x0 uncertainty), t <- 0,
+ * a_save <- a_0, obs <- normalised [x0 | SP slots of x0 | d[:,0]].
+ * mask [B] u8 or NULL: only envs with mask!=0 are reset (masked auto-reset).
+ * env_offset: global index of env 0 of this shard (keys the RNG; multi-GPU). */
+PCG_API int pcg_reset(pcg_plan* plan, const pcg_buffers* io, const uint8_t* mask, uint64_t seed,
+              void* stream);
+
+/* Global env index of local env 0 (batch sharded over GPUs); default 0. */
+PCG_API int pcg_plan_set_env_offset(pcg_plan* plan, int64_t env_offset);
+
+/* Tuning / sharding options. */
+#define PCG_OPT_ENV_OFFSET 1  /* same as pcg_plan_set_env_offset                              */
+#define PCG_OPT_LDS_STAGES 2  /* DOPRI5: keep stage vectors k1..k6 in LDS [stage][comp][lane]
+                                 (64-thread workgroups) instead of VGPRs; default 0           */
+PCG_API int pcg_plan_set_option(pcg_plan* plan, int option, int64_t value);
+
+/* Host-only validation of a cfg: the status pcg_plan_create() would return before it
+ * touches the device (usable on machines without a GPU). */
+PCG_API int pcg_cfg_validate(const pcg_env_cfg* cfg);
+
+/* Test hook: dx = f(x,u) of the plan's model for B envs.
+ * x [nx][B], u [Nu][B] (physical units), dx [nx][B]. */
+PCG_API int pcg_rhs(pcg_plan* plan, int64_t B, const double* x, const double* u, double* dx, void* stream);
+
+/* Test hook: integrate only.  x [nx][B] in/out, u [Nu][B] physical, held for [0,dt]
+ * (zero-order hold, integrator.py:163-182).  nsteps [2][B] or NULL. */
+PCG_API int pcg_integrate(pcg_plan* plan, int64_t B, double* x, const double* u, int32_t* nsteps,
+                  void* stream);
+
+/* Open-loop fused rollout ("next" row f-1: counterpart of policy_eval.rollout,
+ * policy_evaluation.py:71-130): T env steps with the state kept in registers.
+ * a_seq [T][na][B]; obs_seq [T][Nobs][B]|NULL; rew_seq [T][B]|NULL; io->obs/rew/done
+ * receive the last step.  Lock-stepped only (io->t must be NULL). */
+PCG_API int pcg_rollout(pcg_plan* plan, const pcg_buffers* io, int32_t t0, int32_t T, const double* a_seq,
+                double* obs_seq, double* rew_seq, uint64_t seed, void* stream);
+
+/* Raw Philox4x32-10 block for KAT tests: ctr[4], key[2] -> out[4]. (host) */
+PCG_API void pcg_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCGYM_HIP_H */

@@ -1,0 +1,639 @@
+/*
+ * pcg_oracle.c -- CPU restatement of pc-gym's per-timestep hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it,
+ * and only as the checker / the timed CPU baseline.  The product
+ * (pc-gym_amd/, libpcgym_hip.so) never links, imports or falls back to it.
+ *
+ * Pinning: the reference is pure Python whose integrator arithmetic lives in
+ * un-vendored third-party wheels (casadi -> SUNDIALS CVODES, requirements.txt:7;
+ * diffrax Tsit5, requirements.txt:8-10), none installed here.  The oracle is
+ * therefore pinned by
+ *   (1) RHS vectors produced by importing the reference's own model_classes.py
+ *       (tests/golden/rhs_*.npz, generator tests/golden/gen_golden.py),
+ *   (2) the MPC-oracle trajectories the reference ships in pc-gym_paper
+ *       (tests/golden/paper_*.npz; authored by its own CVODES simulator), replayed
+ *       as (x,u,dt)->x' known answers,
+ *   (3) the reference's only in-tree KAT (custom linear model,
+ *       tests/environment/test_make_env_custom_model.py:66-86),
+ *   (4) full reset()/step() tuples recorded from the reference make_env with the
+ *       CVODES call replaced by LSODA(1e-12) on the reference's own RHS
+ *       (tests/golden/step_*.npz),
+ *   (5) Random123's published Philox4x32-10 known answers.
+ * See tests/test_oracle_golden.py.
+ *
+ * Each function cites the reference lines it follows.  Arithmetic is written in
+ * the reference's own expression order so that RHS values agree to ~1 ulp.
+ * The integrators (fixed-step RK4 with sub-steps; adaptive Dormand-Prince 5(4))
+ * are NOT the reference's (CVODES BDF / Tsit5): any convergent one-step method
+ * reproduces the same ODE solution to the reference's accuracy class
+ * (CasADi default reltol 1e-6); see DESIGN.md "Numerical contract".
+ *
+ * Build: make -C oracle   (gcc -O2 -fopenmp -shared -fPIC) -> oracle/libpcg_oracle.so
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/pcgym_hip.h"
+
+#define ORC_EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* Model right-hand sides                                                     */
+/* ------------------------------------------------------------------------- */
+
+/* model_classes.py:45-62.  p = q,V,rho,C,deltaHr,EA_over_R,k0,UA,Ti,Caf (:24-33).
+ * u.size==1 -> Tc only; else Tc,Ti,Caf = u[0..2] (:48-51). */
+static void rhs_cstr(const double* p, const double* x, const double* u, int nu, double* dx) {
+  double q = p[0], V = p[1], rho = p[2], C = p[3], deltaHr = p[4], EA_over_R = p[5], k0 = p[6],
+         UA = p[7], Ti = p[8], Caf = p[9];
+  double ca = x[0], T = x[1];
+  double Tc = u[0];
+  if (nu != 1) {
+    Ti = u[1];
+    Caf = u[2];
+  }
+  double rA = k0 * exp(-EA_over_R / T) * ca;
+  dx[0] = q / V * (Caf - ca) - rA;
+  dx[1] = q / V * (Ti - T) + ((-deltaHr) * rA) * (1 / (rho * C)) + UA * (Tc - T) * (1 / (rho * C * V));
+}
+
+/* model_classes.py:891-913.  p = g,gamma_1,gamma_2,k1,k2,a1..a4,A1..A4 (:877-889). */
+static void rhs_four_tank(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu;
+  double g = p[0], gamma_1 = p[1], gamma_2 = p[2], k1 = p[3], k2 = p[4];
+  double a1 = p[5], a2 = p[6], a3 = p[7], a4 = p[8], A1 = p[9], A2 = p[10], A3 = p[11], A4 = p[12];
+  double h1 = x[0], h2 = x[1], h3 = x[2], h4 = x[3], v1 = u[0], v2 = u[1];
+  dx[0] = (-a1 / A1) * sqrt(2 * g * h1) + (a3 / A1) * sqrt(2 * g * h3) + ((gamma_1 * k1) / (A1)) * v1;
+  dx[1] = (-a2 / A2) * sqrt(2 * g * h2) + (a4 / A2) * sqrt(2 * g * h4) + ((gamma_2 * k2) / (A2)) * v2;
+  dx[2] = (-a3 / A3) * sqrt(2 * g * h3) + (((1 - gamma_2) * k2) / (A3)) * v2;
+  dx[3] = (-a4 / A4) * sqrt(2 * g * h4) + (((1 - gamma_1) * k1) / (A4)) * v1;
+}
+
+/* model_classes.py:370-412.  p = Vl,Vg,m,Kla,eq_exponent,X0,Y6 (:361-367).
+ * u.size==2 -> L,G; else L,G,X0,Y6 (:382-385).  x = X1,Y1,...,X5,Y5 interleaved. */
+static void rhs_me(const double* p, const double* x, const double* u, int nu, double* dx) {
+  double Vl = p[0], Vg = p[1], m = p[2], Kla = p[3], e = p[4], X0 = p[5], Y6 = p[6];
+  double L = u[0], G = u[1];
+  if (nu != 2) {
+    X0 = u[2];
+    Y6 = u[3];
+  }
+  double Q[5];
+  for (int s = 0; s < 5; ++s) {
+    double Xeq = pow(x[2 * s + 1], e) / m;
+    Q[s] = Kla * (x[2 * s] - Xeq) * Vl;
+  }
+  for (int s = 0; s < 5; ++s) {
+    double Xprev = (s == 0) ? X0 : x[2 * (s - 1)];
+    double Ynext = (s == 4) ? Y6 : x[2 * (s + 1) + 1];
+    dx[2 * s] = (1 / Vl) * (L * (Xprev - x[2 * s]) - Q[s]);
+    dx[2 * s + 1] = (1 / Vg) * (G * (Ynext - x[2 * s + 1]) + Q[s]);
+  }
+}
+
+/* model_classes.py:790-845.  p = Vl,Vg,m,Kla,k,eq_exponent,XA0,YA6,YB6,YC6 (:777-786).
+ * x = (XA,YA,YB,YC) x 5 stages. */
+static void rhs_me_reactive(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu;
+  double Vl = p[0], Vg = p[1], m = p[2], Kla = p[3], k = p[4], e = p[5];
+  double XA0 = p[6], YA6 = p[7], YB6 = p[8], YC6 = p[9];
+  double L = u[0], G = u[1];
+  for (int s = 0; s < 5; ++s) {
+    const double* c = x + 4 * s;
+    double XA = c[0], YA = c[1], YB = c[2], YC = c[3];
+    double XAeq = pow(YA, e) / m;
+    double Q = Kla * (XA - XAeq) * Vl;
+    double r = k * YA * YB;
+    double XAprev = (s == 0) ? XA0 : x[4 * (s - 1)];
+    double YAn = (s == 4) ? YA6 : x[4 * (s + 1) + 1];
+    double YBn = (s == 4) ? YB6 : x[4 * (s + 1) + 2];
+    double YCn = (s == 4) ? YC6 : x[4 * (s + 1) + 3];
+    dx[4 * s + 0] = (1 / Vl) * (L * (XAprev - XA) - Q);
+    dx[4 * s + 1] = (1 / Vg) * (G * (YAn - YA) + Q - r * Vg);
+    dx[4 * s + 2] = (1 / Vg) * (G * (YBn - YB) - r * Vg);
+    dx[4 * s + 3] = (1 / Vg) * (G * (YCn - YC) + r * Vg);
+  }
+}
+
+/* model_classes.py:1295-1319.  p = ka,kb,kc,kd,kg,k1,k2,a,b,alfa,ro (:1260-1270).
+ * x = mu0..mu3, conc, CV, Ln ; u = T [degC].  u[1:] ignored (quirk Q13). */
+static void rhs_cryst(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu;
+  double ka = p[0], kb = p[1], kc = p[2], kd = p[3], kg = p[4], k1 = p[5], k2 = p[6];
+  double a = p[7], b = p[8], alfa = p[9], ro = p[10];
+  double mu0 = x[0], mu1 = x[1], mu2 = x[2], mu3 = x[3], conc = x[4];
+  double T = u[0];
+  double Tk = T + 273.15;
+  double Ceq = -686.2686 + 3.579165 * Tk - 0.00292874 * (Tk * Tk);
+  double S = conc * 1e3 - Ceq;
+  double B0 = ka * exp(kb / Tk) * pow(S * S, kc / 2) * pow(mu3 * mu3, kd / 2);
+  double Ginf = kg * exp(k1 / Tk) * pow(S * S, k2 / 2);
+  double dmi0dt = B0;
+  double dmi1dt = Ginf * (a * mu0 + b * mu1 * 1e-4) * 1e4;
+  double dmi2dt = 2 * Ginf * (a * mu1 * 1e-4 + b * mu2 * 1e-8) * 1e8;
+  double dmi3dt = 3 * Ginf * (a * mu2 * 1e-8 + b * mu3 * 1e-12) * 1e12;
+  double dcdt = -0.5 * ro * alfa * Ginf * (a * mu2 * 1e-8 + b * mu3 * 1e-12);
+  double CV = sqrt(mu2 * mu0 / (mu1 * mu1) - 1);
+  double mu1_2 = mu1 * mu1;
+  double dCVdt = 1 / (2 * CV + 1e-10) *
+                 ((dmi2dt * mu0 + mu2 * dmi0dt) * mu1_2 - mu2 * mu0 * 2 * mu1 * dmi1dt) /
+                 (mu1_2 * mu1_2 + 1e-10);
+  double dLndt = (dmi1dt * mu0 - mu1 * dmi0dt) / (mu0 * mu0 + 1e-10);
+  dx[0] = dmi0dt;
+  dx[1] = dmi1dt;
+  dx[2] = dmi2dt;
+  dx[3] = dmi3dt;
+  dx[4] = dcdt;
+  dx[5] = dCVdt;
+  dx[6] = dLndt;
+}
+
+/* custom_model with an affine RHS (pcgym.py:150-153): dx = A x + B u + c.
+ * p = A[nx][nx] | B[nx][nu] | c[nx]. */
+static void rhs_affine(const double* p, int nx, const double* x, const double* u, int nu, double* dx) {
+  const double* A = p;
+  const double* Bm = p + nx * nx;
+  const double* c = Bm + nx * nu;
+  for (int i = 0; i < nx; ++i) {
+    double s = c[i];
+    for (int j = 0; j < nx; ++j) s += A[i * nx + j] * x[j];
+    for (int j = 0; j < nu; ++j) s += Bm[i * nu + j] * u[j];
+    dx[i] = s;
+  }
+}
+
+typedef struct {
+  int model_id, nx, nu;
+  const double* p;
+} orc_model;
+
+static void rhs(const orc_model* m, const double* x, const double* u, double* dx) {
+  switch (m->model_id) {
+    case PCG_MODEL_CSTR: rhs_cstr(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_FOUR_TANK: rhs_four_tank(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_ME: rhs_me(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_ME_REACTIVE: rhs_me_reactive(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_CRYST: rhs_cryst(m->p, x, u, m->nu, dx); break;
+    default: rhs_affine(m->p, m->nx, x, u, m->nu, dx); break;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Integrators over one env step [0,dt], u held constant (integrator.py:163-182:
+ * dae = {x, p=u, ode}, t0=0, tf=dt  => zero-order hold)                        */
+/* ------------------------------------------------------------------------- */
+#define MAXNX PCG_MAX_NX
+
+static void rk4(const orc_model* m, double* x, const double* u, double dt, int nsub) {
+  int nx = m->nx;
+  double h = dt / nsub;
+  double k1[MAXNX], k2[MAXNX], k3[MAXNX], k4[MAXNX], y[MAXNX];
+  for (int s = 0; s < nsub; ++s) {
+    rhs(m, x, u, k1);
+    for (int i = 0; i < nx; ++i) y[i] = x[i] + 0.5 * h * k1[i];
+    rhs(m, y, u, k2);
+    for (int i = 0; i < nx; ++i) y[i] = x[i] + 0.5 * h * k2[i];
+    rhs(m, y, u, k3);
+    for (int i = 0; i < nx; ++i) y[i] = x[i] + h * k3[i];
+    rhs(m, y, u, k4);
+    for (int i = 0; i < nx; ++i) x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+  }
+}
+
+/* Dormand & Prince (1980) 5(4) pair, FSAL.  Controller = the spec in DESIGN.md
+ * "adaptive stepping": RMS error norm over scale = atol + rtol*max(|y|,|ynew|),
+ * accept iff E < 1, factor = clip(0.9*E^-1/5, 0.2, 10) (<=1 right after a
+ * rejection), Hairer's initial-step heuristic.  Mirrors the *semantics* of
+ * integrator.py:56-61 (adaptive explicit 5(4) pair, rtol=atol=1e-8, dt0=None). */
+static double rms_scaled(const double* v, const double* y0, const double* y1, int n, double rtol, double atol) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double a0 = fabs(y0[i]), a1 = fabs(y1[i]);
+    double sc = atol + rtol * (a0 > a1 ? a0 : a1);
+    double r = v[i] / sc;
+    s += r * r;
+  }
+  return sqrt(s / n);
+}
+
+static int dopri5(const orc_model* m, double* x, const double* u, double dt, double rtol, double atol,
+                  int max_steps, int32_t* nacc, int32_t* nrej) {
+  static const double c2 = 1.0 / 5, c3 = 3.0 / 10, c4 = 4.0 / 5, c5 = 8.0 / 9;
+  static const double a21 = 1.0 / 5;
+  static const double a31 = 3.0 / 40, a32 = 9.0 / 40;
+  static const double a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9;
+  static const double a51 = 19372.0 / 6561, a52 = -25360.0 / 2187, a53 = 64448.0 / 6561, a54 = -212.0 / 729;
+  static const double a61 = 9017.0 / 3168, a62 = -355.0 / 33, a63 = 46732.0 / 5247, a64 = 49.0 / 176,
+                      a65 = -5103.0 / 18656;
+  static const double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
+  /* e = b - bhat */
+  static const double e1 = 71.0 / 57600, e3 = -71.0 / 16695, e4 = 71.0 / 1920, e5 = -17253.0 / 339200,
+                      e6 = 22.0 / 525, e7 = -1.0 / 40;
+  (void)c2; (void)c3; (void)c4; (void)c5;
+  int nx = m->nx;
+  double k1[MAXNX], k2[MAXNX], k3[MAXNX], k4[MAXNX], k5[MAXNX], k6[MAXNX], k7[MAXNX];
+  double y[MAXNX], ynew[MAXNX], err[MAXNX];
+  int acc = 0, rej = 0;
+  rhs(m, x, u, k1);
+  /* initial step (Hairer, Norsett & Wanner II.4) */
+  double h;
+  {
+    double d0 = rms_scaled(x, x, x, nx, rtol, atol);
+    double d1 = rms_scaled(k1, x, x, nx, rtol, atol);
+    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    if (h0 > dt) h0 = dt;
+    for (int i = 0; i < nx; ++i) y[i] = x[i] + h0 * k1[i];
+    rhs(m, y, u, k2);
+    for (int i = 0; i < nx; ++i) err[i] = k2[i] - k1[i];
+    double d2 = rms_scaled(err, x, x, nx, rtol, atol) / h0;
+    double dm = d1 > d2 ? d1 : d2;
+    double h1 = (dm <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / dm, 0.2);
+    h = fmin(100.0 * h0, h1);
+    if (h > dt) h = dt;
+  }
+  double t = 0.0;
+  int rejected_last = 0;
+  int status = 0;
+  for (;;) {
+    int last = 0;
+    if (acc + rej >= max_steps) { status = 1; break; }
+    if (t + h >= dt * (1.0 - 1e-14)) { h = dt - t; last = 1; }
+    for (int i = 0; i < nx; ++i) y[i] = x[i] + h * (a21 * k1[i]);
+    rhs(m, y, u, k2);
+    for (int i = 0; i < nx; ++i) y[i] = x[i] + h * (a31 * k1[i] + a32 * k2[i]);
+    rhs(m, y, u, k3);
+    for (int i = 0; i < nx; ++i) y[i] = x[i] + h * (a41 * k1[i] + a42 * k2[i] + a43 * k3[i]);
+    rhs(m, y, u, k4);
+    for (int i = 0; i < nx; ++i) y[i] = x[i] + h * (a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i]);
+    rhs(m, y, u, k5);
+    for (int i = 0; i < nx; ++i)
+      y[i] = x[i] + h * (a61 * k1[i] + a62 * k2[i] + a63 * k3[i] + a64 * k4[i] + a65 * k5[i]);
+    rhs(m, y, u, k6);
+    for (int i = 0; i < nx; ++i)
+      ynew[i] = x[i] + h * (b1 * k1[i] + b3 * k3[i] + b4 * k4[i] + b5 * k5[i] + b6 * k6[i]);
+    rhs(m, ynew, u, k7);
+    for (int i = 0; i < nx; ++i)
+      err[i] = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * k7[i]);
+    double E = rms_scaled(err, x, ynew, nx, rtol, atol);
+    if (E < 1.0) {
+      double f = (E == 0.0) ? 10.0 : fmin(10.0, fmax(0.2, 0.9 * pow(E, -0.2)));
+      if (rejected_last && f > 1.0) f = 1.0;
+      t += h;
+      h *= f;
+      for (int i = 0; i < nx; ++i) { x[i] = ynew[i]; k1[i] = k7[i]; }
+      rejected_last = 0;
+      ++acc;
+      if (last) break; /* reached dt */
+    } else {
+      /* also the NaN path: E is NaN -> comparison false -> shrink hardest */
+      double f = (E == E) ? fmax(0.2, 0.9 * pow(E, -0.2)) : 0.2;
+      if (f > 1.0) f = 1.0;
+      h *= f;
+      rejected_last = 1;
+      ++rej;
+      if (!(h > 1e-13 * dt)) { status = 2; break; } /* step size underflow (NaN / blow-up) */
+    }
+  }
+  if (nacc) *nacc = acc;
+  if (nrej) *nrej = rej;
+  return status;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Counter-based RNG: Philox4x32-10 (Salmon et al., SC'11; Random123 v1.09)   */
+/* ------------------------------------------------------------------------- */
+ORC_EXPORT void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* RNG contract shared with the kernels (DESIGN.md "RNG"):
+ *   key = (seed_lo, seed_hi); ctr = (env_lo, env_hi, t, purpose + pair_index)
+ *   purpose: 0x100 obs noise, 0x200 Gaussian disturbance, 0x300 reset uncertainty
+ *   one block -> two uniforms (53-bit) -> one Box-Muller pair (z0 for even index, z1 odd) */
+#define ORC_RNG_NOISE 0x100u
+#define ORC_RNG_DIST 0x200u
+#define ORC_RNG_RESET 0x300u
+
+static void rng_uniform2(uint64_t seed, uint64_t env, uint32_t t, uint32_t stream, double* u0, double* u1) {
+  uint32_t ctr[4] = {(uint32_t)env, (uint32_t)(env >> 32), t, stream};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t o[4];
+  orc_philox4x32_10(ctr, key, o);
+  *u0 = (double)(((uint64_t)(o[0] >> 5) << 26) | (uint64_t)(o[1] >> 6)) * (1.0 / 9007199254740992.0);
+  *u1 = (double)(((uint64_t)(o[2] >> 5) << 26) | (uint64_t)(o[3] >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+static double rng_normal(uint64_t seed, uint64_t env, uint32_t t, uint32_t purpose, int idx) {
+  double u0, u1;
+  rng_uniform2(seed, env, t, purpose + (uint32_t)(idx >> 1), &u0, &u1);
+  double r = sqrt(-2.0 * log(1.0 - u0));
+  double th = 6.283185307179586476925286766559 * u1;
+  return (idx & 1) ? r * sin(th) : r * cos(th);
+}
+
+static double rng_uniform(uint64_t seed, uint64_t env, uint32_t t, uint32_t purpose, int idx) {
+  double u0, u1;
+  rng_uniform2(seed, env, t, purpose + (uint32_t)(idx >> 1), &u0, &u1);
+  return (idx & 1) ? u1 : u0;
+}
+
+ORC_EXPORT double orc_rng_normal(uint64_t seed, uint64_t env, uint32_t t, uint32_t purpose, int idx) {
+  return rng_normal(seed, env, t, purpose, idx);
+}
+ORC_EXPORT double orc_rng_uniform(uint64_t seed, uint64_t env, uint32_t t, uint32_t purpose, int idx) {
+  return rng_uniform(seed, env, t, purpose, idx);
+}
+
+/* ------------------------------------------------------------------------- */
+/* make_env.step for ONE environment, pcgym.py:350-500, statement by statement */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  double* state;   /* [Nobs]  reference self.state = [x | SP | d]  in/out */
+  double* a_save;  /* [na]    in/out (a_delta) */
+  int32_t t;       /* in/out */
+} orc_env;
+
+static int cfg_nobs(const pcg_env_cfg* c) { return c->nx + c->nsp_obs + c->nd; }
+static int cfg_nu(const pcg_env_cfg* c) { return c->na + c->ndm; }
+
+/* constraint_check + con_checker, pcgym.py:580-615, 560-577.
+ * The user callable g(x,u) is represented by its affine rows (con_A, con_b). */
+static int constraint_check(const pcg_env_cfg* c, const double* state, const double* uk, double* g_out) {
+  int nobs = cfg_nobs(c), nu = cfg_nu(c);
+  double s[PCG_MAX_NOBS], in[PCG_MAX_NU];
+  for (int i = 0; i < nobs; ++i) s[i] = state[i];
+  for (int i = 0; i < nu; ++i) in[i] = uk[i];
+  if (c->flags & PCG_F_REF_COMPAT) {
+    /* Q3: the reference "de-normalises" the physical input/state again (pcgym.py:597-608).
+     * numpy broadcasting of a_space (na) against uk (Nu) is only defined for Nu==na or na==1. */
+    if (c->flags & PCG_F_NORMALISE_A)
+      for (int i = 0; i < nu; ++i) {
+        int j = (c->na == 1) ? 0 : i;
+        in[i] = (in[i] + 1) * (c->a_high[j] - c->a_low[j]) / 2 + c->a_low[j];
+      }
+    if (c->flags & PCG_F_NORMALISE_O)
+      for (int i = 0; i < nobs; ++i) s[i] = (s[i] + 1) * (c->o_high[i] - c->o_low[i]) / 2 + c->o_low[i];
+  }
+  int violated = 0;
+  for (int r = 0; r < c->ncon; ++r) {
+    const double* row = c->con_A + (size_t)r * (nobs + nu);
+    double g = 0.0;
+    for (int i = 0; i < nobs; ++i) g += row[i] * s[i];
+    for (int i = 0; i < nu; ++i) g += row[nobs + i] * in[i];
+    g -= c->con_b[r];
+    if (g_out) g_out[r] = g;
+    if (g > 0) violated = 1;
+  }
+  return violated;
+}
+
+typedef struct {
+  double* obs;    /* [Nobs] */
+  double rew;
+  uint8_t done, viol;
+  double* g;      /* [ncon] or NULL */
+  double* g_pre;  /* [ncon] or NULL */
+  int32_t nacc, nrej;
+  double uk[PCG_MAX_NU];
+} orc_out;
+
+static void env_step(const pcg_env_cfg* c, orc_env* e, const double* action_in, const double* d_env,
+                     uint64_t seed, uint64_t env_id, orc_out* o) {
+  int nx = c->nx, na = c->na, nsp = c->nsp, nd = c->nd, ndm = c->ndm;
+  int nobs = cfg_nobs(c), nu = cfg_nu(c);
+  double action[PCG_MAX_NA];
+  double* uk = o->uk;
+  int t = e->t;
+  int tn = (t + 1 < c->N) ? t + 1 : c->N - 1; /* schedule index clamp (reference would IndexError) */
+  int tc = (t < c->N) ? t : c->N - 1;
+  for (int i = 0; i < nu; ++i) uk[i] = 0.0; /* :371 */
+  for (int i = 0; i < na; ++i) action[i] = action_in[i];
+  if (c->flags & PCG_F_NORMALISE_A) /* :372-375 */
+    for (int i = 0; i < na; ++i) action[i] = (action[i] + 1) * (c->a_high[i] - c->a_low[i]) / 2 + c->a_low[i];
+  if ((c->flags & PCG_F_NORMALISE_A) && (c->flags & PCG_F_A_DELTA)) { /* :376-383 */
+    if (c->flags & PCG_F_REF_COMPAT) /* Q1: de-normalised a second time */
+      for (int i = 0; i < na; ++i) action[i] = (action[i] + 1) * (c->a_high[i] - c->a_low[i]) / 2 + c->a_low[i];
+    for (int i = 0; i < na; ++i) {
+      action[i] = e->a_save[i] + action[i]; /* Q2: the unclipped sum drives the plant */
+      double s = action[i];
+      if (s < c->a_act_low[i]) s = c->a_act_low[i];
+      if (s > c->a_act_high[i]) s = c->a_act_high[i];
+      e->a_save[i] = s;
+    }
+  }
+  /* disturbances :386-412 */
+  for (int i = 0; i < na; ++i) uk[i] = action[i];
+  if (ndm > 0) {
+    for (int j = 0; j < ndm; ++j) uk[na + j] = c->d_default[j]; /* :400-404 */
+    for (int k = 0; k < nd; ++k) {
+      double v;
+      if (d_env) v = d_env[k];
+      else v = c->d_sched[(size_t)k * c->N + tn]; /* :394  index t+1 (Q6) */
+      if (c->flags & PCG_F_GAUSS_DIST) {
+        v += c->d_sigma[k] * rng_normal(seed, env_id, (uint32_t)t, ORC_RNG_DIST, k);
+        if (v < c->d_clip_lo[k]) v = c->d_clip_lo[k];
+        if (v > c->d_clip_hi[k]) v = c->d_clip_hi[k];
+      }
+      uk[na + c->d_slot[k]] = v;
+      e->state[nx + c->nsp_obs + k] = v; /* :409-410 */
+    }
+  }
+  o->viol = 0;
+  uint8_t done = 0;
+  if (t == 0 && c->ncon > 0) { /* :414-420 pre-step check */
+    double gp[PCG_MAX_NCON];
+    int v = constraint_check(c, e->state, uk, gp);
+    if (o->g_pre) memcpy(o->g_pre, gp, sizeof(double) * c->ncon);
+    if (v && (c->flags & PCG_F_DONE_ON_CONS)) done = 1;
+  }
+  /* integrate :423-429 */
+  orc_model m = {c->model_id, nx, nu, c->params};
+  o->nacc = o->nrej = 0;
+  if (c->integrator_id == PCG_INT_RK4) rk4(&m, e->state, uk, c->dt, c->substeps);
+  else dopri5(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
+  /* SP slot :432-438 uses SP[k][t] with the OLD t (Q5) */
+  for (int k = 0; k < c->nsp_obs; ++k) e->state[nx + k] = c->sp[(size_t)k * c->N + tc];
+  e->t = t + 1; /* :441 */
+  int violated = 0;
+  if (c->ncon > 0) { /* :443-446 */
+    violated = constraint_check(c, e->state, uk, o->g);
+    if (violated && (c->flags & PCG_F_DONE_ON_CONS)) done = 1;
+  }
+  o->viol = (uint8_t)violated;
+  if (e->t == c->N - 1) done = 1; /* :448-449 */
+  o->done = done;
+  /* obs + noise :452-466 */
+  for (int i = 0; i < nobs; ++i) o->obs[i] = e->state[i];
+  if (c->flags & PCG_F_NOISE)
+    for (int i = 0; i < nx; ++i)
+      o->obs[i] += rng_normal(seed, env_id, (uint32_t)t, ORC_RNG_NOISE, i) * e->state[i] * c->noise_pct[i];
+  /* reward :470-482 */
+  double r = 0.0;
+  if (c->flags & PCG_F_REWARD_BATCH) { /* :502-532 */
+    if (e->t == c->N - 1) {
+      for (int k = 0; k < c->nrew; ++k) {
+        if (c->flags & PCG_F_MAXIMISE) r += e->state[c->rew_index[k]] * c->r_scale[k];
+        else r -= e->state[c->rew_index[k]] * c->r_scale[k];
+      }
+      if ((c->flags & PCG_F_R_PENALTY) && violated) r -= 1000;
+    }
+  } else { /* :535-558 */
+    int ti = (e->t < c->N) ? e->t : c->N - 1;
+    for (int k = 0; k < nsp; ++k) {
+      double d = e->state[c->sp_index[k]] - c->sp[(size_t)k * c->N + ti];
+      r += (-(d * d)) * c->r_scale[k];
+      if ((c->flags & PCG_F_R_PENALTY) && violated) r -= 1000; /* Q4: once per SP key */
+    }
+  }
+  o->rew = r;
+  /* normalise :483-489 */
+  if (c->flags & PCG_F_NORMALISE_O)
+    for (int i = 0; i < nobs; ++i) o->obs[i] = 2 * (o->obs[i] - c->o_low[i]) / (c->o_high[i] - c->o_low[i]) - 1;
+  /* partial observation :495-498 */
+  if (c->obs_mask)
+    for (int i = 0; i < nx; ++i)
+      if (!c->obs_mask[i]) o->obs[i] = 0;
+}
+
+/* make_env.reset for one env, pcgym.py:263-349 */
+static void env_reset(const pcg_env_cfg* c, orc_env* e, uint64_t seed, uint64_t env_id, double* obs) {
+  int nx = c->nx, nsp = c->nsp_obs, nd = c->nd, nobs = cfg_nobs(c);
+  e->t = 0; /* :279 */
+  for (int i = 0; i < nx + nsp; ++i) e->state[i] = c->x0[i]; /* :284 */
+  if (c->x0_unc) /* :285-288, apply_uncertainties :255-261 */
+    for (int i = 0; i < nx; ++i) {
+      double pct = c->x0_unc[i];
+      if (pct == 0.0) continue;
+      if (c->flags & PCG_F_X0_NORMAL)
+        e->state[i] = c->x0[i] + pct * c->x0[i] * rng_normal(seed, env_id, 0u, ORC_RNG_RESET, i);
+      else
+        e->state[i] = c->x0[i] * (1 + pct * (2.0 * rng_uniform(seed, env_id, 0u, ORC_RNG_RESET, i) - 1.0));
+    }
+  for (int k = 0; k < nd; ++k) e->state[nx + nsp + k] = c->d_sched[(size_t)k * c->N + 0]; /* :291-298 (Q6: index 0) */
+  if (c->flags & PCG_F_A_DELTA) /* :319-320 */
+    for (int i = 0; i < c->na; ++i) e->a_save[i] = c->a_0[i];
+  for (int i = 0; i < nobs; ++i) obs[i] = e->state[i];
+  if (c->flags & PCG_F_NORMALISE_O) /* :331-337 */
+    for (int i = 0; i < nobs; ++i) obs[i] = 2 * (obs[i] - c->o_low[i]) / (c->o_high[i] - c->o_low[i]) - 1;
+  if (c->obs_mask) /* :344-347 */
+    for (int i = 0; i < nx; ++i)
+      if (!c->obs_mask[i]) obs[i] = 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Batched entry points over the SAME SoA buffers the HIP library takes        */
+/* (host memory).  The SP / disturbance slots of the reference state vector    */
+/* are carried in io->obs-shaped scratch `state_slots` [nsp+nd][B].            */
+/* ------------------------------------------------------------------------- */
+ORC_EXPORT int orc_rhs(int model_id, const double* params, int nx, int nu, int64_t B, const double* x,
+                       const double* u, double* dx) {
+  orc_model m = {model_id, nx, nu, params};
+  for (int64_t b = 0; b < B; ++b) {
+    double xi[MAXNX], ui[PCG_MAX_NU], di[MAXNX];
+    for (int i = 0; i < nx; ++i) xi[i] = x[(size_t)i * B + b];
+    for (int i = 0; i < nu; ++i) ui[i] = u[(size_t)i * B + b];
+    rhs(&m, xi, ui, di);
+    for (int i = 0; i < nx; ++i) dx[(size_t)i * B + b] = di[i];
+  }
+  return 0;
+}
+
+ORC_EXPORT int orc_integrate(const pcg_env_cfg* c, int64_t B, double* x, const double* u, int32_t* nsteps) {
+  int nx = c->nx, nu = cfg_nu(c);
+  orc_model m = {c->model_id, nx, nu, c->params};
+  for (int64_t b = 0; b < B; ++b) {
+    double xi[MAXNX], ui[PCG_MAX_NU];
+    int32_t na_ = 0, nr_ = 0;
+    for (int i = 0; i < nx; ++i) xi[i] = x[(size_t)i * B + b];
+    for (int i = 0; i < nu; ++i) ui[i] = u[(size_t)i * B + b];
+    if (c->integrator_id == PCG_INT_RK4) rk4(&m, xi, ui, c->dt, c->substeps);
+    else dopri5(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, &na_, &nr_);
+    for (int i = 0; i < nx; ++i) x[(size_t)i * B + b] = xi[i];
+    if (nsteps) { nsteps[b] = na_; nsteps[B + b] = nr_; }
+  }
+  return 0;
+}
+
+/* slots: [nsp+nd][B] host scratch holding the SP / disturbance slots of the reference's
+ * state vector between calls (written by orc_reset / orc_step). */
+ORC_EXPORT int orc_step(const pcg_env_cfg* c, const pcg_buffers* io, double* slots, int32_t t_scalar,
+                        uint64_t seed, int64_t env_offset, int n_threads) {
+  int nx = c->nx, na = c->na, nsp = c->nsp_obs, nd = c->nd, nobs = cfg_nobs(c), ncon = c->ncon;
+  int64_t B = io->B;
+  (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+  for (int64_t b = 0; b < B; ++b) {
+    double state[PCG_MAX_NOBS], asave[PCG_MAX_NA], act[PCG_MAX_NA], denv[PCG_MAX_NDM];
+    double obs[PCG_MAX_NOBS], g[PCG_MAX_NCON], gp[PCG_MAX_NCON];
+    for (int i = 0; i < nx; ++i) state[i] = io->x[(size_t)i * B + b];
+    for (int i = 0; i < nsp + nd; ++i) state[nx + i] = slots ? slots[(size_t)i * B + b] : 0.0;
+    for (int i = 0; i < na; ++i) act[i] = io->a[(size_t)i * B + b];
+    if (io->a_save)
+      for (int i = 0; i < na; ++i) asave[i] = io->a_save[(size_t)i * B + b];
+    if (io->d)
+      for (int i = 0; i < nd; ++i) denv[i] = io->d[(size_t)i * B + b];
+    orc_env e = {state, asave, io->t ? io->t[b] : t_scalar};
+    orc_out o;
+    o.obs = obs;
+    o.g = g;
+    o.g_pre = gp;
+    int t_old = e.t;
+    env_step(c, &e, act, io->d ? denv : NULL, seed, (uint64_t)(env_offset + b), &o);
+    for (int i = 0; i < nx; ++i) io->x[(size_t)i * B + b] = state[i];
+    if (slots)
+      for (int i = 0; i < nsp + nd; ++i) slots[(size_t)i * B + b] = state[nx + i];
+    if (io->a_save)
+      for (int i = 0; i < na; ++i) io->a_save[(size_t)i * B + b] = asave[i];
+    if (io->t) io->t[b] = e.t;
+    for (int i = 0; i < nobs; ++i) io->obs[(size_t)i * B + b] = obs[i];
+    io->rew[b] = o.rew;
+    io->done[b] = o.done;
+    if (io->viol) io->viol[b] = o.viol;
+    if (io->g)
+      for (int i = 0; i < ncon; ++i) io->g[(size_t)i * B + b] = g[i];
+    if (io->g_pre && t_old == 0)
+      for (int i = 0; i < ncon; ++i) io->g_pre[(size_t)i * B + b] = gp[i];
+    if (io->nsteps) { io->nsteps[b] = o.nacc; io->nsteps[B + b] = o.nrej; }
+  }
+  return 0;
+}
+
+ORC_EXPORT int orc_reset(const pcg_env_cfg* c, const pcg_buffers* io, double* slots, const uint8_t* mask,
+                         uint64_t seed, int64_t env_offset) {
+  int nx = c->nx, na = c->na, nsp = c->nsp_obs, nd = c->nd, nobs = cfg_nobs(c);
+  int64_t B = io->B;
+  for (int64_t b = 0; b < B; ++b) {
+    if (mask && !mask[b]) continue;
+    double state[PCG_MAX_NOBS], asave[PCG_MAX_NA], obs[PCG_MAX_NOBS];
+    orc_env e = {state, asave, 0};
+    env_reset(c, &e, seed, (uint64_t)(env_offset + b), obs);
+    for (int i = 0; i < nx; ++i) io->x[(size_t)i * B + b] = state[i];
+    if (slots)
+      for (int i = 0; i < nsp + nd; ++i) slots[(size_t)i * B + b] = state[nx + i];
+    if (io->a_save && (c->flags & PCG_F_A_DELTA))
+      for (int i = 0; i < na; ++i) io->a_save[(size_t)i * B + b] = asave[i];
+    if (io->t) io->t[b] = 0;
+    for (int i = 0; i < nobs; ++i) io->obs[(size_t)i * B + b] = obs[i];
+  }
+  return 0;
+}
+
+ORC_EXPORT int orc_version(void) { return PCG_ABI_VERSION; }

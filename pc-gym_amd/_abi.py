@@ -1,0 +1,175 @@
+"""ctypes mirror of include/pcgym_hip.h (structs + constants).
+
+tests/test_abi.py parses the header and checks every #define / enum value and
+struct field order against this file, so the two cannot drift silently.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+PCG_ABI_VERSION = 1
+PCG_MAX_NX = 20
+PCG_MAX_NA = 4
+PCG_MAX_NDM = 4
+PCG_MAX_NSP = 4
+PCG_MAX_NCON = 8
+PCG_MAX_PARAMS = 128
+PCG_MAX_NOBS = PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM
+PCG_MAX_NU = PCG_MAX_NA + PCG_MAX_NDM
+PCG_MAX_N = 4096
+
+PCG_OK = 0
+PCG_E_NULL = -1
+PCG_E_MODEL = -2
+PCG_E_DIM = -3
+PCG_E_VALUE = -4
+PCG_E_PLAN = -5
+PCG_E_UNSUPPORTED = -6
+
+PCG_OPT_ENV_OFFSET = 1
+PCG_OPT_LDS_STAGES = 2
+
+PCG_INT_RK4 = 0
+PCG_INT_DOPRI5 = 1
+
+PCG_F_NORMALISE_A = 0x0001
+PCG_F_NORMALISE_O = 0x0002
+PCG_F_A_DELTA = 0x0004
+PCG_F_R_PENALTY = 0x0008
+PCG_F_DONE_ON_CONS = 0x0010
+PCG_F_NOISE = 0x0020
+PCG_F_REWARD_BATCH = 0x0040
+PCG_F_MAXIMISE = 0x0080
+PCG_F_REF_COMPAT = 0x0100
+PCG_F_GAUSS_DIST = 0x0200
+PCG_F_X0_NORMAL = 0x0400
+
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+_pu8 = C.POINTER(C.c_uint8)
+
+
+class pcg_env_cfg(C.Structure):
+    _fields_ = [
+        ("model_id", C.c_int32),
+        ("integrator_id", C.c_int32),
+        ("nx", C.c_int32),
+        ("na", C.c_int32),
+        ("ndm", C.c_int32),
+        ("nd", C.c_int32),
+        ("nsp", C.c_int32),
+        ("nsp_obs", C.c_int32),
+        ("ncon", C.c_int32),
+        ("nrew", C.c_int32),
+        ("N", C.c_int32),
+        ("substeps", C.c_int32),
+        ("max_steps", C.c_int32),
+        ("flags", C.c_uint32),
+        ("n_params", C.c_int32),
+        ("dt", C.c_double),
+        ("rtol", C.c_double),
+        ("atol", C.c_double),
+        ("params", _pd),
+        ("x0", _pd),
+        ("x0_unc", _pd),
+        ("a_low", _pd),
+        ("a_high", _pd),
+        ("a_act_low", _pd),
+        ("a_act_high", _pd),
+        ("a_0", _pd),
+        ("o_low", _pd),
+        ("o_high", _pd),
+        ("obs_mask", _pu8),
+        ("sp_index", _pi),
+        ("sp", _pd),
+        ("r_scale", _pd),
+        ("rew_index", _pi),
+        ("d_slot", _pi),
+        ("d_sched", _pd),
+        ("d_default", _pd),
+        ("d_sigma", _pd),
+        ("d_clip_lo", _pd),
+        ("d_clip_hi", _pd),
+        ("con_A", _pd),
+        ("con_b", _pd),
+        ("noise_pct", _pd),
+    ]
+
+
+class pcg_buffers(C.Structure):
+    _fields_ = [
+        ("B", C.c_int64),
+        ("x", C.c_void_p),
+        ("a", C.c_void_p),
+        ("d", C.c_void_p),
+        ("t", C.c_void_p),
+        ("a_save", C.c_void_p),
+        ("obs", C.c_void_p),
+        ("rew", C.c_void_p),
+        ("done", C.c_void_p),
+        ("viol", C.c_void_p),
+        ("g", C.c_void_p),
+        ("g_pre", C.c_void_p),
+        ("nsteps", C.c_void_p),
+    ]
+
+
+# every extern "C" symbol the header declares (tests check the .so exports all)
+EXPORTS = [
+    "pcg_version",
+    "pcg_strerror",
+    "pcg_model_info",
+    "pcg_model_default_params",
+    "pcg_plan_create",
+    "pcg_plan_destroy",
+    "pcg_plan_bytes_per_env_step",
+    "pcg_step",
+    "pcg_reset",
+    "pcg_plan_set_env_offset",
+    "pcg_plan_set_option",
+    "pcg_cfg_validate",
+    "pcg_rhs",
+    "pcg_integrate",
+    "pcg_rollout",
+    "pcg_philox4x32_10",
+]
+
+
+def declare(lib):
+    """Attach argtypes/restype to a loaded libpcgym_hip.so."""
+    vp = C.c_void_p
+    lib.pcg_version.restype = C.c_int
+    lib.pcg_version.argtypes = []
+    lib.pcg_strerror.restype = C.c_char_p
+    lib.pcg_strerror.argtypes = [C.c_int]
+    lib.pcg_model_info.restype = C.c_int
+    lib.pcg_model_info.argtypes = [C.c_int, _pi, _pi, _pi, _pi]
+    lib.pcg_model_default_params.restype = C.c_int
+    lib.pcg_model_default_params.argtypes = [C.c_int, _pd, C.c_int32]
+    lib.pcg_plan_create.restype = C.c_int
+    lib.pcg_plan_create.argtypes = [C.POINTER(vp), C.POINTER(pcg_env_cfg)]
+    lib.pcg_plan_destroy.restype = C.c_int
+    lib.pcg_plan_destroy.argtypes = [vp]
+    lib.pcg_plan_bytes_per_env_step.restype = C.c_int64
+    lib.pcg_plan_bytes_per_env_step.argtypes = [vp, C.POINTER(pcg_buffers)]
+    lib.pcg_step.restype = C.c_int
+    lib.pcg_step.argtypes = [vp, C.POINTER(pcg_buffers), C.c_int32, C.c_uint64, vp]
+    lib.pcg_reset.restype = C.c_int
+    lib.pcg_reset.argtypes = [vp, C.POINTER(pcg_buffers), vp, C.c_uint64, vp]
+    lib.pcg_plan_set_env_offset.restype = C.c_int
+    lib.pcg_plan_set_env_offset.argtypes = [vp, C.c_int64]
+    lib.pcg_plan_set_option.restype = C.c_int
+    lib.pcg_plan_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    lib.pcg_cfg_validate.restype = C.c_int
+    lib.pcg_cfg_validate.argtypes = [C.POINTER(pcg_env_cfg)]
+    lib.pcg_rhs.restype = C.c_int
+    lib.pcg_rhs.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
+    lib.pcg_integrate.restype = C.c_int
+    lib.pcg_integrate.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
+    lib.pcg_rollout.restype = C.c_int
+    lib.pcg_rollout.argtypes = [vp, C.POINTER(pcg_buffers), C.c_int32, C.c_int32, vp, vp, vp,
+                                C.c_uint64, vp]
+    lib.pcg_philox4x32_10.restype = None
+    lib.pcg_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_uint32)]
+    return lib

@@ -1,0 +1,461 @@
+"""env_params dict -> numeric environment specification.
+
+Mirrors the parsing done by the reference ``make_env.__init__`` and its
+``_setup_*`` helpers (pcgym.py:32-253): same keys, same defaults, same
+``ValueError`` sites.  The result (``EnvSpec``) is the host-side image of
+``pcg_env_cfg`` (include/pcgym_hip.h); ``EnvSpec.to_cfg()`` marshals it for the
+C ABI.  Nothing numeric about the hot path happens here.
+
+New optional keys (do not exist in the reference):
+  integrator   'rk4' | 'dopri5'   (default per model, see DEFAULT_INTEGRATOR)
+  substeps     RK4 sub-steps per env step
+  rtol, atol   DOPRI5 tolerances (default 1e-8, integrator.py:61)
+  max_steps    DOPRI5 step budget per env step
+  reference_compat  replicate reference quirks Q1/Q3 (default True)
+  gaussian_disturbances {name: sigma}  in-kernel N(0,1)*sigma added to the schedule,
+                    clipped to disturbance_bounds (BASELINE.json configs[4])
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as abi
+from . import models as M
+
+# integration_method -> integrator.  'casadi' (CVODES, reltol 1e-6) and the
+# default 'hip' map to the per-model default below; 'jax' (diffrax Tsit5,
+# rtol=atol=1e-8, integrator.py:56-61) maps to the adaptive 5(4) pair.
+DEFAULT_INTEGRATOR = {
+    M.CSTR: "rk4",
+    M.FOUR_TANK: "rk4",
+    M.ME: "dopri5",           # stiff at high L,G (|lambda| dt up to ~240): adaptive
+    M.ME_REACTIVE: "dopri5",
+    M.CRYST: "rk4",
+    M.AFFINE: "rk4",
+}
+# Default RK4 sub-step length per model (model time units): substeps = ceil(dt / h).  Chosen so that
+# the canonical configs (cstr dt=26/60 -> 4, four_tank dt=1000/60 -> 4, cryst dt=1 -> 32, ME dt=1 ->
+# 128) reach <=1e-6 relative, the accuracy class of the reference's CVODES defaults (SURVEY.md
+# section 8a table).  Fixed-step RK4 is only conditionally stable: outside the canonical operating
+# range (cstr thermal runaway, ME at high flows) use integrator='dopri5'.
+DEFAULT_RK4_H = {M.CSTR: 26.0 / 60.0 / 4, M.FOUR_TANK: 1000.0 / 60.0 / 4, M.ME: 1.0 / 128,
+                 M.ME_REACTIVE: 1.0 / 32, M.CRYST: 1.0 / 32, M.AFFINE: None}
+
+
+def default_substeps(model_id, dt):
+    h = DEFAULT_RK4_H[model_id]
+    if h is None:
+        return 8
+    return max(1, int(np.ceil(dt / h - 1e-9)))
+
+_f64 = np.float64
+
+
+def _arr(v, dtype=_f64):
+    return np.ascontiguousarray(np.asarray(v, dtype=dtype).reshape(-1))
+
+
+def probe_affine(fn, dims, sample_points, what):
+    """Recover (A, c) with fn(z_0, z_1, ...) == A @ concat(z) + c for a Python callable
+    that is affine in its arguments; raise ValueError when it is not.
+
+    The reference accepts arbitrary callables for ``constraints`` (pcgym.py:119-125)
+    and ``custom_model`` (pcgym.py:150-153); a Python callable cannot run inside a
+    kernel, so the engine takes the declarative (affine) subset and says so loudly
+    otherwise.  Probing at 0 and the unit vectors is exact for affine maps.
+    """
+    n = int(sum(dims))
+
+    def call(z):
+        parts, o = [], 0
+        for d in dims:
+            parts.append(np.array(z[o:o + d], dtype=_f64))
+            o += d
+        with np.errstate(all="ignore"):
+            out = np.asarray(fn(*parts), dtype=_f64).reshape(-1)
+        return out
+
+    c = call(np.zeros(n))
+    m = c.shape[0]
+    A = np.zeros((m, n))
+    for i in range(n):
+        e = np.zeros(n)
+        e[i] = 1.0
+        A[:, i] = call(e) - c
+    if not (np.all(np.isfinite(A)) and np.all(np.isfinite(c))):
+        raise ValueError(f"{what}: callable is not affine (non-finite value at the probe points); "
+                         "only affine callables can be compiled into the HIP step kernel")
+    for z in sample_points:
+        z = np.asarray(z, dtype=_f64).reshape(-1)
+        want = call(z)
+        got = A @ z + c
+        tol = 1e-9 * (np.abs(A) @ np.abs(z) + np.abs(c) + 1e-300)
+        if not np.all(np.abs(want - got) <= tol):
+            raise ValueError(f"{what}: callable is not affine in its arguments; only affine "
+                             "callables can be compiled into the HIP step kernel "
+                             "(pass the declarative form {'A':..., 'b':...} or an affine function)")
+    return A, c
+
+
+class EnvSpec:
+    """Numeric image of env_params (see module docstring)."""
+
+    def __init__(self, env_params: dict):
+        if not isinstance(env_params, dict):
+            raise ValueError("env_params must be a dictionary")  # pcgym.py:40-41
+        p = self.env_params = copy.deepcopy(env_params)
+
+        # --- pcgym.py:56-61 ---------------------------------------------------
+        self.a_delta = bool(p.get("a_delta", False))
+        self.normalise_a = bool(p.get("normalise_a", True))
+        self.normalise_o = bool(p.get("normalise_o", True))
+        self.reference_compat = bool(p.get("reference_compat", True))
+
+        # --- spaces, pcgym.py:68-92 -------------------------------------------
+        self.a_low = _arr(p["a_space"]["low"])
+        self.a_high = _arr(p["a_space"]["high"])
+        self.na = self.a_low.shape[0]
+        o_low = _arr(p["o_space"]["low"])
+        o_high = _arr(p["o_space"]["high"])
+
+        # --- reward kind, pcgym.py:94-103 --------------------------------------
+        self.SP = p.get("SP")
+        self.custom_reward = p.get("custom_reward")
+        self.reward_batch = self.SP is None
+        if self.reward_batch and self.custom_reward is None:
+            self.reward_states = list(p["reward_states"])
+            self.maximise_reward = bool(p["maximise_reward"])
+        else:
+            self.reward_states = list(p.get("reward_states", []))
+            self.maximise_reward = bool(p.get("maximise_reward", True))
+
+        # --- simulation, pcgym.py:105-111 --------------------------------------
+        self.N = int(p["N"])
+        self.tsim = p["tsim"]
+        self.x0 = _arr(p["x0"])
+        self.integration_method = p.get("integration_method", "hip")
+        if self.integration_method not in ("hip", "casadi", "jax"):
+            raise ValueError("integration_method must be 'hip' (or the reference's 'casadi'/'jax', "
+                             "which map onto the HIP integrators)")
+        self.dt = float(self.tsim) / self.N
+        if not (1 < self.N <= abi.PCG_MAX_N):
+            raise ValueError(f"N must be in (1, {abi.PCG_MAX_N}]")
+
+        # --- model, pcgym.py:127-158 -------------------------------------------
+        self.affine_AB = None
+        if p.get("custom_model") is not None:
+            self.model = self._adopt_custom_model(p["custom_model"], p)
+        else:
+            self.model = M.get_model(p.get("model"))
+        info = self.model.info()
+        self.nx = len(info["states"])
+        self.nu_inputs = len(info["inputs"])
+        if self.nu_inputs != self.na:
+            raise ValueError(f"a_space has {self.na} entries but the model has {self.nu_inputs} inputs")
+
+        # --- SP ------------------------------------------------------------------
+        self.sp_keys = list(self.SP.keys()) if self.SP is not None else []
+        self.nsp = len(self.sp_keys)
+        self.sp_index = np.array([info["states"].index(k) for k in self.sp_keys], dtype=np.int32)
+        self.sp = np.zeros((self.nsp, self.N))
+        for j, k in enumerate(self.sp_keys):
+            v = _arr(self.SP[k])
+            if v.shape[0] < self.N - 1:
+                raise ValueError(f"SP['{k}'] has {v.shape[0]} entries, need at least N-1={self.N - 1}")
+            n = min(v.shape[0], self.N)
+            self.sp[j, :n] = v[:n]
+            self.sp[j, n:] = v[n - 1]
+        r_scale = p.get("r_scale", {}) or {}
+        if self.reward_batch:
+            names = [s for s in self.reward_states if str(s) in info["states"]]  # pcgym.py:519
+            self.rew_index = np.array([info["states"].index(s) for s in names], dtype=np.int32)
+            self.r_scale = np.array([float(r_scale.get(s, 1)) for s in names], dtype=_f64)
+        else:
+            self.rew_index = np.zeros(0, dtype=np.int32)
+            self.r_scale = np.array([float(r_scale.get(k, 1)) for k in self.sp_keys], dtype=_f64)
+        self.nrew = self.rew_index.shape[0]
+
+        # x0 normally carries the SP slots ([x | SP], README.md:47).  With only the nx physical
+        # states the reference silently drops the SP slot from state/obs (pcgym.py:438 assigns into
+        # an empty slice) -- its own KAT (tests/environment/test_make_env_custom_model.py:66-86) does so.
+        if self.x0.shape[0] == self.nx + self.nsp:
+            self.nsp_obs = self.nsp
+        elif self.x0.shape[0] == self.nx:
+            self.nsp_obs = 0
+        else:
+            raise ValueError(f"x0 must have nx+len(SP) = {self.nx + self.nsp} entries "
+                             f"(states then SP slots) or nx = {self.nx}, got {self.x0.shape[0]}")
+
+        # --- disturbances, pcgym.py:167-199 --------------------------------------
+        self.disturbances = p.get("disturbances")
+        self.nd = self.ndm = 0
+        self.d_slot = np.zeros(0, dtype=np.int32)
+        self.d_sched = np.zeros((0, self.N))
+        self.d_default = np.zeros(0)
+        self.d_keys = []
+        if self.disturbances is not None:
+            mdist = list(info["disturbances"])
+            for k in self.disturbances:
+                if k not in mdist:
+                    raise ValueError(f"disturbance '{k}' is not an input of model '{self.model.name}' "
+                                     f"(available: {mdist})")
+            self.ndm = len(mdist)
+            # state slots follow the MODEL's disturbance order (pcgym.py:292-295, 392-398)
+            self.d_keys = [k for k in mdist if k in self.disturbances]
+            self.nd = len(self.d_keys)
+            if self.nsp_obs != self.nsp:
+                raise ValueError("disturbances need x0 to carry the SP slots (len(x0) == nx+len(SP))")
+            self.d_slot = np.array([mdist.index(k) for k in self.d_keys], dtype=np.int32)
+            self.d_sched = np.zeros((self.nd, self.N))
+            for j, k in enumerate(self.d_keys):
+                v = _arr(self.disturbances[k])
+                if v.shape[0] < self.N:
+                    raise ValueError(f"disturbances['{k}'] has {v.shape[0]} entries, need N={self.N}")
+                self.d_sched[j] = v[:self.N]
+            self.d_default = np.array([float(info["parameters"][str(k)]) for k in mdist])
+            o_low = np.concatenate([o_low, _arr(p["disturbance_bounds"]["low"])])
+            o_high = np.concatenate([o_high, _arr(p["disturbance_bounds"]["high"])])
+        self.o_low, self.o_high = o_low, o_high
+        self.nobs = self.nx + self.nsp_obs + self.nd
+        self.nu = self.na + self.ndm
+        if self.o_low.shape[0] != self.nobs or self.o_high.shape[0] != self.nobs:
+            raise ValueError(f"o_space (+disturbance_bounds) must have {self.nobs} entries "
+                             f"[states | SP | disturbances], got {self.o_low.shape[0]}")
+
+        gd = p.get("gaussian_disturbances")
+        self.gauss = gd is not None
+        self.d_sigma = np.zeros(self.nd)
+        if self.gauss:
+            for k in gd:
+                if k not in self.d_keys:
+                    raise ValueError(f"gaussian_disturbances['{k}'] needs a matching disturbances entry")
+            self.d_sigma = np.array([float(gd.get(k, 0.0)) for k in self.d_keys])
+        self.d_clip_lo = self.o_low[self.nx + self.nsp_obs:].copy()
+        self.d_clip_hi = self.o_high[self.nx + self.nsp_obs:].copy()
+
+        # --- a_delta, pcgym.py:57-58, 376-383 -------------------------------------
+        if self.a_delta:
+            self.a_0 = np.broadcast_to(_arr(p["a_0"]), (self.na,)).astype(_f64).copy()
+            self.a_act_low = _arr(p["a_space_act"]["low"])
+            self.a_act_high = _arr(p["a_space_act"]["high"])
+        else:
+            self.a_0 = np.zeros(self.na)
+            self.a_act_low = np.full(self.na, -np.inf)
+            self.a_act_high = np.full(self.na, np.inf)
+
+        # --- constraints, pcgym.py:113-125 ----------------------------------------
+        self.constraint_active = False
+        self.r_penalty = False
+        self.done_on_constraint = False
+        self.ncon = 0
+        self.con_A = np.zeros((0, self.nobs + self.nu))
+        self.con_b = np.zeros(0)
+        cons = p.get("constraints")
+        if cons is not None:
+            self.done_on_constraint = bool(p["done_on_cons_vio"])
+            self.r_penalty = bool(p["r_penalty"])
+            self.constraint_active = True
+            if isinstance(cons, dict):
+                A = np.atleast_2d(np.asarray(cons["A"], dtype=_f64))
+                b = _arr(cons["b"])
+            elif callable(cons):
+                rng = np.random.default_rng(7)
+                pts = []
+                for _ in range(3):
+                    xs = self.x0_full() * (1 + 0.1 * rng.uniform(-1, 1, self.nobs)) + 0.01 * rng.uniform(-1, 1, self.nobs)
+                    us = rng.uniform(-1, 1, self.nu)
+                    pts.append(np.concatenate([xs, us]))
+                A, c = probe_affine(cons, [self.nobs, self.nu], pts, "constraints")
+                b = -c
+            else:
+                raise ValueError("constraints must be a callable g(x,u) or {'A':..., 'b':...}")
+            if A.shape[1] != self.nobs + self.nu:
+                raise ValueError(f"constraint rows must have Nobs+Nu = {self.nobs + self.nu} columns")
+            self.con_A, self.con_b = np.ascontiguousarray(A), np.ascontiguousarray(b)
+            self.ncon = A.shape[0]
+            if self.ncon > abi.PCG_MAX_NCON:
+                raise ValueError(f"at most {abi.PCG_MAX_NCON} constraint rows are supported")
+            if (self.reference_compat and self.normalise_a and self.nu != self.na and self.na != 1):
+                # the reference itself raises here (numpy broadcast of a_space against uk, pcgym.py:597-600)
+                raise ValueError("operands could not be broadcast together: the reference cannot "
+                                 "combine normalise_a, disturbances and constraints for na>1 "
+                                 "(pcgym.py:597-600); set reference_compat=False or normalise_a=False")
+
+        # --- noise, pcgym.py:63-66, 453-466 ----------------------------------------
+        self.noise = bool(p.get("noise", False))
+        self.noise_pct = np.zeros(self.nx)
+        npct = p.get("noise_percentage")
+        if self.noise:
+            if isinstance(npct, dict):
+                for i, s in enumerate(info["states"]):
+                    if s in npct:
+                        self.noise_pct[i] = float(npct[s])
+            elif npct is not None:
+                self.noise_pct[:] = float(npct)
+
+        # --- partial observation, pcgym.py:208-211 -----------------------------------
+        self.partial_observation = p.get("partial_observation")
+        self.obs_mask = None
+        if self.partial_observation:
+            self.obs_mask = np.array([1 if s in self.partial_observation else 0 for s in info["states"]],
+                                     dtype=np.uint8)
+
+        # --- uncertainty, pcgym.py:212-253 (x0 only in this build) ---------------------
+        self.x0_unc = None
+        self.x0_normal = False
+        up = p.get("uncertainty_percentages")
+        if p.get("empirical_distribution") is not None:
+            raise ValueError("empirical_distribution is not built yet (per-env parameter arrays, "
+                             "SURVEY.md section 8 row f-3)")
+        if up is not None:
+            extra = [k for k in up if k != "x0"]
+            if extra:
+                raise ValueError(f"parameter uncertainty {extra} is not built yet (per-env parameter "
+                                 "arrays, SURVEY.md section 8 row f-3); only 'x0' is supported")
+            dist = p.get("distribution", "uniform")
+            if dist not in ("uniform", "normal"):
+                raise ValueError("distribution must be 'uniform' or 'normal'")
+            self.x0_normal = dist == "normal"
+            xu = _arr(up["x0"])
+            self.x0_unc = np.zeros(self.nx)
+            n = min(self.nx, xu.shape[0])
+            self.x0_unc[:n] = xu[:n]
+
+        # --- integrator selection (new keys) -------------------------------------------
+        d_int = DEFAULT_INTEGRATOR[self.model.model_id]
+        if self.integration_method == "jax":
+            d_int = "dopri5"
+        self.integrator = p.get("integrator", d_int)
+        if self.integrator not in ("rk4", "dopri5"):
+            raise ValueError("integrator must be 'rk4' or 'dopri5'")
+        self.substeps = int(p.get("substeps", default_substeps(self.model.model_id, self.dt)))
+        self.rtol = float(p.get("rtol", 1e-8))
+        self.atol = float(p.get("atol", 1e-8))
+        self.max_steps = int(p.get("max_steps", 100000))
+        if self.substeps < 1:
+            raise ValueError("substeps must be >= 1")
+
+        for name, lim in (("nx", abi.PCG_MAX_NX), ("na", abi.PCG_MAX_NA), ("ndm", abi.PCG_MAX_NDM),
+                          ("nsp", abi.PCG_MAX_NSP)):
+            if getattr(self, name) > lim:
+                raise ValueError(f"{name}={getattr(self, name)} exceeds the build limit {lim}")
+
+    # ------------------------------------------------------------------------------
+    def x0_full(self):
+        """reference reset state [x0 | SP slots | d[:,0]] (pcgym.py:284-298)."""
+        return np.concatenate([self.x0, self.d_sched[:, 0] if self.nd else np.zeros(0)])
+
+    def _adopt_custom_model(self, m, p):
+        """custom_model (pcgym.py:150-153).  Registry-shaped objects reuse the
+        matching kernel with the object's parameter values; any other object must
+        have an affine RHS, which is compiled into PCG_MODEL_AFFINE."""
+        info = m.info()
+        cls = type(m).__name__
+        reg = {"cstr": "cstr", "four_tank": "four_tank", "multistage_extraction": "multistage_extraction",
+               "multistage_extraction_reactive": "multistage_extraction_reactive",
+               "crystallization": "crystallization"}
+        if cls in reg and list(info["states"]) == M.get_model(reg[cls]).states:
+            mi = M.get_model(reg[cls])
+            for k in mi.parameters:
+                if k in info["parameters"]:
+                    mi.parameters[k] = float(info["parameters"][k])
+            return mi
+        nx = len(info["states"])
+        nu = len(info["inputs"])
+        dist = [d for d in info.get("disturbances", []) if d != "None"]
+        if p.get("disturbances") is not None:
+            nu += len(dist)
+        if nx > 8 or nu > abi.PCG_MAX_NU:
+            raise ValueError("affine custom_model supports nx<=8")
+        rng = np.random.default_rng(11)
+        x0 = _arr(p["x0"])[:nx]
+        pts = [np.concatenate([x0 * (1 + 0.1 * rng.uniform(-1, 1, nx)) + 0.01 * rng.uniform(-1, 1, nx),
+                               rng.uniform(-1, 1, nu)]) for _ in range(3)]
+        A, c = probe_affine(lambda x, u: m(x, u), [nx, nu], pts, "custom_model")
+        mi = M.ModelInfo(cls, M.AFFINE, info["states"], info["inputs"], dist,
+                         list(info.get("parameters", {}).items()))
+        self.affine_AB = (A[:, :nx].copy(), A[:, nx:].copy(), c.copy())
+        return mi
+
+    def param_vector(self):
+        if self.model.model_id == M.AFFINE:
+            A, Bm, c = self.affine_AB
+            return np.concatenate([A.reshape(-1), Bm.reshape(-1), c.reshape(-1)])
+        return np.array(self.model.param_vector(), dtype=_f64)
+
+    def flags(self):
+        f = 0
+        f |= abi.PCG_F_NORMALISE_A if self.normalise_a else 0
+        f |= abi.PCG_F_NORMALISE_O if self.normalise_o else 0
+        f |= abi.PCG_F_A_DELTA if (self.a_delta and self.normalise_a) else 0  # pcgym.py:376
+        f |= abi.PCG_F_R_PENALTY if self.r_penalty else 0
+        f |= abi.PCG_F_DONE_ON_CONS if self.done_on_constraint else 0
+        f |= abi.PCG_F_NOISE if self.noise else 0
+        f |= abi.PCG_F_REWARD_BATCH if self.reward_batch else 0
+        f |= abi.PCG_F_MAXIMISE if self.maximise_reward else 0
+        f |= abi.PCG_F_REF_COMPAT if self.reference_compat else 0
+        f |= abi.PCG_F_GAUSS_DIST if self.gauss else 0
+        f |= abi.PCG_F_X0_NORMAL if self.x0_normal else 0
+        return f
+
+    def to_cfg(self):
+        """-> (pcg_env_cfg, keepalive list).  The arrays must outlive the call that reads the cfg."""
+        keep = []
+
+        def pd(a):
+            if a is None or a.size == 0:
+                return None
+            a = np.ascontiguousarray(a, dtype=_f64)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_double))
+
+        def pi(a):
+            if a is None or a.size == 0:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.int32)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+        def pu8(a):
+            if a is None or a.size == 0:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.uint8)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+        params = self.param_vector()
+        cfg = abi.pcg_env_cfg()
+        cfg.model_id = self.model.model_id
+        cfg.integrator_id = abi.PCG_INT_RK4 if self.integrator == "rk4" else abi.PCG_INT_DOPRI5
+        cfg.nx, cfg.na, cfg.ndm, cfg.nd = self.nx, self.na, self.ndm, self.nd
+        cfg.nsp, cfg.ncon, cfg.nrew, cfg.N = self.nsp, self.ncon, self.nrew, self.N
+        cfg.nsp_obs = self.nsp_obs
+        cfg.substeps, cfg.max_steps = self.substeps, self.max_steps
+        cfg.flags = self.flags()
+        cfg.n_params = params.shape[0]
+        cfg.dt, cfg.rtol, cfg.atol = self.dt, self.rtol, self.atol
+        cfg.params = pd(params)
+        cfg.x0 = pd(self.x0)
+        cfg.x0_unc = pd(self.x0_unc)
+        cfg.a_low, cfg.a_high = pd(self.a_low), pd(self.a_high)
+        cfg.a_act_low, cfg.a_act_high = pd(self.a_act_low), pd(self.a_act_high)
+        cfg.a_0 = pd(self.a_0)
+        cfg.o_low, cfg.o_high = pd(self.o_low), pd(self.o_high)
+        cfg.obs_mask = pu8(self.obs_mask)
+        cfg.sp_index = pi(self.sp_index)
+        cfg.sp = pd(self.sp)
+        cfg.r_scale = pd(self.r_scale)
+        cfg.rew_index = pi(self.rew_index)
+        cfg.d_slot = pi(self.d_slot)
+        cfg.d_sched = pd(self.d_sched)
+        cfg.d_default = pd(self.d_default)
+        cfg.d_sigma = pd(self.d_sigma)
+        cfg.d_clip_lo = pd(self.d_clip_lo)
+        cfg.d_clip_hi = pd(self.d_clip_hi)
+        cfg.con_A = pd(self.con_A)
+        cfg.con_b = pd(self.con_b)
+        cfg.noise_pct = pd(self.noise_pct)
+        return cfg, keep

@@ -1,0 +1,198 @@
+// pcg_integrators.hpp -- per-lane one-step ODE integrators over one env step [0,dt]
+// with the input held constant (zero-order hold; reference integrator.py:163-182
+// builds integrator("cvodes", {x, p=u, ode}, 0, dt)).
+//
+//   rk4      classical RK4, n equal sub-steps.  State + 3 work vectors in VGPRs.
+//   dopri5   Dormand-Prince 5(4) FSAL, per-lane adaptive step; semantic twin of the
+//            reference's jax path (integrator.py:56-61: adaptive explicit 5(4) pair,
+//            rtol=atol=1e-8, dt0=None).  Stage vectors k1..k7 live either in VGPRs
+//            (RegStages) or in LDS laid out [stage][component][lane] (LdsStages) --
+//            the variant BASELINE.json's north_star asks for the wide models.
+//
+// The controller is specified in DESIGN.md ("Adaptive stepping") and implemented
+// independently in oracle/pcg_oracle.c.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pcg_models.hpp"
+
+namespace pcg {
+
+template <int NX, class F>
+PCG_DEV void rk4(const F& f, double (&x)[NX], double h, int nsub) {
+  double k[NX], acc[NX], y[NX];
+  const double h2 = 0.5 * h, h6 = h / 6.0;
+  for (int s = 0; s < nsub; ++s) {
+    f(x, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      acc[i] = k[i];
+      y[i] = x[i] + h2 * k[i];
+    }
+    f(y, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      acc[i] += 2.0 * k[i];
+      y[i] = x[i] + h2 * k[i];
+    }
+    f(y, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      acc[i] += 2.0 * k[i];
+      y[i] = x[i] + h * k[i];
+    }
+    f(y, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] += h6 * (acc[i] + k[i]);
+  }
+}
+
+// ---- stage storage policies -------------------------------------------------
+template <int NX>
+struct RegStages {
+  double k[6][NX];
+  PCG_DEV double get(int s, int i) const { return k[s][i]; }
+  PCG_DEV void set(int s, int i, double v) { k[s][i] = v; }
+};
+
+// LDS layout [stage][component][thread]: lane-contiguous 8-byte words, so each
+// ds_read_b64 / ds_write_b64 of a wave touches 512 contiguous bytes (conflict-free).
+template <int NX, int THREADS>
+struct LdsStages {
+  double* base;  // &lds[threadIdx.x]
+  PCG_DEV double get(int s, int i) const { return base[(s * NX + i) * THREADS]; }
+  PCG_DEV void set(int s, int i, double v) { base[(s * NX + i) * THREADS] = v; }
+  static constexpr size_t bytes() { return sizeof(double) * 6 * NX * THREADS; }
+};
+
+template <int NX>
+PCG_DEV double rms_scaled(const double (&v)[NX], const double (&y0)[NX], const double (&y1)[NX], int n,
+                          double rtol, double atol) {
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const double sc = atol + rtol * fmax(fabs(y0[i]), fabs(y1[i]));
+    const double r = v[i] / sc;
+    s += (i < n) ? r * r : 0.0;
+  }
+  return sqrt(s / n);
+}
+
+// returns 0 ok, 1 step budget exhausted, 2 step-size underflow
+template <int NX, class F, class ST>
+PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double rtol, double atol,
+                   int max_steps, int& nacc, int& nrej) {
+  constexpr double a21 = 1.0 / 5;
+  constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
+  constexpr double a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9;
+  constexpr double a51 = 19372.0 / 6561, a52 = -25360.0 / 2187, a53 = 64448.0 / 6561, a54 = -212.0 / 729;
+  constexpr double a61 = 9017.0 / 3168, a62 = -355.0 / 33, a63 = 46732.0 / 5247, a64 = 49.0 / 176,
+                   a65 = -5103.0 / 18656;
+  constexpr double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
+  constexpr double e1 = 71.0 / 57600, e3 = -71.0 / 16695, e4 = 71.0 / 1920, e5 = -17253.0 / 339200,
+                   e6 = 22.0 / 525, e7 = -1.0 / 40;
+  double y[NX], kk[NX], w[NX];
+  int acc = 0, rej = 0, status = 0;
+
+  f(x, kk);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) K.set(0, i, kk[i]);
+  // initial step size (Hairer, Norsett & Wanner, II.4)
+  double h;
+  {
+    const double d0 = rms_scaled<NX>(x, x, x, n, rtol, atol);
+    const double d1 = rms_scaled<NX>(kk, x, x, n, rtol, atol);
+    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    h0 = fmin(h0, dt);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = x[i] + h0 * kk[i];
+    f(y, w);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) w[i] -= kk[i];
+    const double d2 = rms_scaled<NX>(w, x, x, n, rtol, atol) / h0;
+    const double dm = fmax(d1, d2);
+    const double h1 = (dm <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / dm, 0.2);
+    h = fmin(fmin(100.0 * h0, h1), dt);
+  }
+  double t = 0.0;
+  bool rejected_last = false;
+  for (;;) {
+    bool last = false;
+    if (acc + rej >= max_steps) {
+      status = 1;
+      break;
+    }
+    if (t + h >= dt * (1.0 - 1e-14)) {
+      h = dt - t;
+      last = true;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (a21 * K.get(0, i));
+    f(y, kk);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      K.set(1, i, kk[i]);
+      y[i] = x[i] + h * (a31 * K.get(0, i) + a32 * kk[i]);
+    }
+    f(y, kk);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      K.set(2, i, kk[i]);
+      y[i] = x[i] + h * (a41 * K.get(0, i) + a42 * K.get(1, i) + a43 * kk[i]);
+    }
+    f(y, kk);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      K.set(3, i, kk[i]);
+      y[i] = x[i] + h * (a51 * K.get(0, i) + a52 * K.get(1, i) + a53 * K.get(2, i) + a54 * kk[i]);
+    }
+    f(y, kk);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      K.set(4, i, kk[i]);
+      y[i] = x[i] + h * (a61 * K.get(0, i) + a62 * K.get(1, i) + a63 * K.get(2, i) + a64 * K.get(3, i) +
+                         a65 * kk[i]);
+    }
+    f(y, kk);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      K.set(5, i, kk[i]);
+      y[i] = x[i] + h * (b1 * K.get(0, i) + b3 * K.get(2, i) + b4 * K.get(3, i) + b5 * K.get(4, i) + b6 * kk[i]);
+    }
+    f(y, kk);  // k7 at the 5th-order solution (FSAL)
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      w[i] = h * (e1 * K.get(0, i) + e3 * K.get(2, i) + e4 * K.get(3, i) + e5 * K.get(4, i) +
+                  e6 * K.get(5, i) + e7 * kk[i]);
+    const double E = rms_scaled<NX>(w, x, y, n, rtol, atol);
+    if (E < 1.0) {
+      double fac = (E == 0.0) ? 10.0 : fmin(10.0, fmax(0.2, 0.9 * pow(E, -0.2)));
+      if (rejected_last && fac > 1.0) fac = 1.0;
+      t += h;
+      h *= fac;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        x[i] = y[i];
+        K.set(0, i, kk[i]);
+      }
+      rejected_last = false;
+      ++acc;
+      if (last) break;
+    } else {
+      double fac = (E == E) ? fmax(0.2, 0.9 * pow(E, -0.2)) : 0.2;  // NaN -> hardest shrink
+      if (fac > 1.0) fac = 1.0;
+      h *= fac;
+      rejected_last = true;
+      ++rej;
+      if (!(h > 1e-13 * dt)) {  // step-size underflow (NaN state / blow-up): give up on this lane
+        status = 2;
+        break;
+      }
+    }
+  }
+  nacc = acc;
+  nrej = rej;
+  return status;
+}
+
+}  // namespace pcg

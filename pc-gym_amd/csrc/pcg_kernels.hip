@@ -1,0 +1,983 @@
+// pcg_kernels.hip -- fused environment-step kernels for gfx950 (MI355X) and the
+// C ABI of include/pcgym_hip.h.
+//
+// Execution model
+//   * one wavefront lane = one environment; 256-thread workgroups; grid = ceil(B/256)
+//     (B = 2^20 -> 4096 workgroups = 16 per CU, 2 per CU per XCD round).
+//   * all per-env arrays are SoA  field[component][B]  in HBM: lane i of a wave reads
+//     address base + 8*i  -> every load/store instruction of a wave touches 512
+//     contiguous bytes.  Each byte of state/action/obs crosses HBM exactly once per step.
+//   * env state, the RK work vectors and the held inputs live in VGPRs; everything that
+//     is identical for all envs of a plan (model constants, folded affine maps, bounds,
+//     constraint rows) is one DevConst block in device memory read with wave-uniform
+//     addresses, i.e. through the scalar cache into SGPRs -- no VGPR or LDS cost.
+//   * time-indexed tables (set-point / disturbance schedules) are read with the scalar
+//     unit when the batch is lock-stepped, and are staged in LDS when every env carries
+//     its own step counter (per-lane table lookups after masked auto-reset).
+//   * DOPRI5 stage vectors: VGPRs, or LDS [stage][component][lane] (PCG_OPT_LDS_STAGES).
+//   * no MFMA: there is no dense contraction on this path.
+//
+// Reference path restated: make_env.step / reset (src/pcgym/pcgym.py:263-500),
+// integration_engine (src/pcgym/integrator.py:65-107,163-182), model RHS
+// (src/pcgym/model_classes.py) -- see pcg_models.hpp for per-model line ranges.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/pcgym_hip.h"
+#include "pcg_integrators.hpp"
+#include "pcg_models.hpp"
+
+namespace pcg {
+
+constexpr int BLOCK = 256;      // threads per workgroup (4 waves, one per SIMD)
+constexpr int BLOCK_LDS = 64;   // LDS-staged DOPRI5: 6*NX*8 B of stage storage per lane
+constexpr int tb(bool lds_stages) { return lds_stages ? BLOCK_LDS : BLOCK; }
+constexpr int KNU = PCG_MAX_NA + PCG_MAX_NDM;                      // kernel-side u width
+constexpr int CON_W = PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + KNU; // padded constraint row
+
+// Everything wave-uniform about a plan.  Read only through uniform addresses.
+struct DevConst {
+  double kp[136];  // model KP (pcg_models.hpp)
+  // action map: act = (a + a_pre) * a_scale + a_off   (folds pcgym.py:372-379)
+  double a_pre[PCG_MAX_NA], a_scale[PCG_MAX_NA], a_off[PCG_MAX_NA];
+  double a_act_lo[PCG_MAX_NA], a_act_hi[PCG_MAX_NA], a_0[PCG_MAX_NA];
+  // observation map: obs = (o - o_lo) * o_sc + o_off  (pcgym.py:483-498; mask -> sc=off=0)
+  double o_lo[PCG_MAX_NOBS], o_sc[PCG_MAX_NOBS], o_off[PCG_MAX_NOBS];
+  double r_scale[PCG_MAX_NX];
+  double noise_pct[PCG_MAX_NX];
+  double x0[PCG_MAX_NX + PCG_MAX_NSP];
+  double x0_unc[PCG_MAX_NX];
+  double d_default[PCG_MAX_NDM];
+  double d_sigma[PCG_MAX_NDM], d_lo[PCG_MAX_NDM], d_hi[PCG_MAX_NDM];
+  // constraint rows over [x(PCG_MAX_NX) | sp(PCG_MAX_NSP) | d(PCG_MAX_NDM) | u(KNU)], compat folded in
+  double con_A[PCG_MAX_NCON][CON_W];
+  double con_b[PCG_MAX_NCON];
+  double dt, h, rtol, atol;
+  int32_t sp_index[PCG_MAX_NSP], rew_index[PCG_MAX_NX], d_slot[PCG_MAX_NDM];
+  int32_t nx, na, ndm, nd, nsp, nsp_obs, ncon, nrew, N, substeps, max_steps, nobs, has_x0_unc;
+  uint32_t flags;
+};
+
+struct StepArgs {
+  const DevConst* C;
+  const double* sched;  // [nsp + nd][N]
+  double* x;
+  const double* a;
+  const double* d;
+  int32_t* t;
+  double* a_save;
+  double* obs;
+  double* rew;
+  uint8_t* done;
+  uint8_t* viol;
+  double* g;
+  double* g_pre;
+  int32_t* nsteps;
+  const uint8_t* mask;  // reset only
+  int64_t B;
+  int64_t env_offset;
+  uint64_t seed;
+  int32_t t_scalar;
+  int32_t sched_in_lds;  // per-env-t kernels: schedules staged in LDS
+  // rollout
+  const double* a_seq;
+  double* obs_seq;
+  double* rew_seq;
+  int32_t T;
+};
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11).  RNG contract:
+//   key = (seed_lo, seed_hi); ctr = (env_lo, env_hi, t, purpose + pair index)
+//   one block -> two 53-bit uniforms -> one Box-Muller pair.
+// ---------------------------------------------------------------------------
+constexpr uint32_t RNG_NOISE = 0x100u, RNG_DIST = 0x200u, RNG_RESET = 0x300u;
+
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+PCG_DEV void rng_uniform2(uint64_t seed, uint64_t env, uint32_t t, uint32_t stream, double& u0, double& u1) {
+  uint32_t o[4];
+  philox4x32_10((uint32_t)env, (uint32_t)(env >> 32), t, stream, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  u0 = (double)(((uint64_t)(o[0] >> 5) << 26) | (uint64_t)(o[1] >> 6)) * (1.0 / 9007199254740992.0);
+  u1 = (double)(((uint64_t)(o[2] >> 5) << 26) | (uint64_t)(o[3] >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+PCG_DEV void rng_normal2(uint64_t seed, uint64_t env, uint32_t t, uint32_t stream, double& z0, double& z1) {
+  double u0, u1;
+  rng_uniform2(seed, env, t, stream, u0, u1);
+  const double r = sqrt(-2.0 * log(1.0 - u0));
+  double s, c;
+  sincospi(2.0 * u1, &s, &c);  // angle = 2*pi*u1, u1 in [0,1): no large-argument reduction
+  z0 = r * c;
+  z1 = r * s;
+}
+
+// value at runtime index `idx` of a register array, without dynamic register indexing
+template <int N>
+PCG_DEV double pick(const double (&v)[N], int idx) {
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r = (i == idx) ? v[i] : r;
+  return r;
+}
+
+template <class M>
+struct RhsFn {
+  const typename M::KP& kp;
+  const typename M::Hold& hold;
+  PCG_DEV void operator()(const double (&x)[M::NX], double (&dx)[M::NX]) const { M::rhs(kp, hold, x, dx); }
+};
+
+// constraint rows g = A.[x|sp|d|u] - b  (affine form of the reference's callable, pcgym.py:560-577);
+// writes rows to gout (if non-null) and returns "any row > 0".
+template <class M>
+PCG_DEV bool constraint_rows(const DevConst& c, const double (&x)[M::NX], const double (&spv)[PCG_MAX_NSP],
+                             const double (&dv)[PCG_MAX_NDM], const double (&u)[M::NA + M::NDM], double* gout,
+                             int64_t B, int64_t e) {
+  bool violated = false;
+  for (int r = 0; r < c.ncon; ++r) {
+    const double* row = c.con_A[r];
+    double g = -c.con_b[r];
+#pragma unroll
+    for (int i = 0; i < M::NX; ++i) g += row[i] * x[i];
+#pragma unroll
+    for (int k = 0; k < PCG_MAX_NSP; ++k) g += row[PCG_MAX_NX + k] * spv[k];
+#pragma unroll
+    for (int k = 0; k < PCG_MAX_NDM; ++k) g += row[PCG_MAX_NX + PCG_MAX_NSP + k] * dv[k];
+#pragma unroll
+    for (int j = 0; j < M::NA; ++j) g += row[PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + j] * u[j];
+#pragma unroll
+    for (int j = 0; j < M::NDM; ++j)
+      g += row[PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + PCG_MAX_NA + j] * u[M::NA + j];
+    if (gout) gout[(size_t)r * B + e] = g;
+    violated |= (g > 0.0);
+  }
+  return violated;
+}
+
+// schedule lookup: lock-stepped -> uniform scalar load; per-env t -> LDS table (or global)
+template <bool PER_ENV_T>
+PCG_DEV double sched_at(const double* sched_g, const double* sched_l, bool in_lds, int row, int N, int idx) {
+  if (PER_ENV_T && in_lds) return sched_l[row * N + idx];
+  return sched_g[(size_t)row * N + idx];
+}
+
+// ---------------------------------------------------------------------------
+// One env step for the lane's environment.  Statement order follows
+// make_env.step (pcgym.py:350-500).  `x` is the lane's physical state (in/out).
+// Returns through out-params; does all global stores except x itself.
+// ---------------------------------------------------------------------------
+template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS>
+PCG_DEV void env_step(const StepArgs& A, const DevConst& c, const double* sched_l, double* stage_l, int64_t e,
+                      int t, const double (&a_in)[M::NA], double (&x)[M::NX], double* obs_out, double* rew_out) {
+  constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
+  const int64_t B = A.B;
+  const uint32_t flags = c.flags;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  const int na = M::DYNAMIC ? c.na : NA;
+  const int N = c.N, nsp = c.nsp, nso = c.nsp_obs, nd = c.nd;
+  const int tn = min(t + 1, N - 1);  // schedule index clamp (the reference would IndexError)
+  const int tc = min(t, N - 1);
+  const uint64_t env_id = (uint64_t)(A.env_offset + e);
+  const typename M::KP& kp = *reinterpret_cast<const typename M::KP*>(c.kp);
+
+  // ---- action map (pcgym.py:371-383) ----
+  double u[NA + NDM];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    double av = 0.0;
+    if (i < na) {
+      av = (a_in[i] + c.a_pre[i]) * c.a_scale[i] + c.a_off[i];
+      if (flags & PCG_F_A_DELTA) {
+        av = A.a_save[(size_t)i * B + e] + av;  // Q2: the unclipped sum drives the plant
+        A.a_save[(size_t)i * B + e] = fmin(fmax(av, c.a_act_lo[i]), c.a_act_hi[i]);
+      }
+    }
+    u[i] = av;
+  }
+  // ---- disturbance injection (pcgym.py:386-412) ----
+  double dv[PCG_MAX_NDM] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < NDM; ++j) u[NA + j] = c.d_default[j];
+  if (NDM > 0 && nd > 0) {
+#pragma unroll
+    for (int k = 0; k < (NDM > 0 ? NDM : 1); ++k) {
+      if (k < nd) {
+        double v = A.d ? A.d[(size_t)k * B + e] : sched_at<PER_ENV_T>(A.sched, sched_l, A.sched_in_lds, nsp + k, N, tn);
+        if (EXTRAS && (flags & PCG_F_GAUSS_DIST)) {
+          double z0, z1;
+          rng_normal2(A.seed, env_id, (uint32_t)t, RNG_DIST + (uint32_t)(k >> 1), z0, z1);
+          v += c.d_sigma[k] * ((k & 1) ? z1 : z0);
+          v = fmin(fmax(v, c.d_lo[k]), c.d_hi[k]);
+        }
+        dv[k] = v;
+        const int slot = c.d_slot[k];
+#pragma unroll
+        for (int j = 0; j < NDM; ++j) u[NA + j] = (j == slot) ? v : u[NA + j];
+      }
+    }
+  }
+  // ---- pre-step constraint check at t == 0 (pcgym.py:414-420) ----
+  bool done = false;
+  if (EXTRAS && c.ncon > 0 && t == 0) {
+    double sp0[PCG_MAX_NSP];
+#pragma unroll
+    for (int k = 0; k < PCG_MAX_NSP; ++k) sp0[k] = (k < nso) ? c.x0[(M::DYNAMIC ? nx : NX) + k] : 0.0;
+    const bool v = constraint_rows<M>(c, x, sp0, dv, u, A.g_pre, B, e);
+    done = v && (flags & PCG_F_DONE_ON_CONS);
+  }
+  // ---- integrate over [0, dt], u held (pcgym.py:423-429, integrator.py:90-107,163-182) ----
+  const typename M::Hold hold = M::hold(kp, u);
+  const RhsFn<M> f{kp, hold};
+  if (INTEG == PCG_INT_RK4) {
+    rk4<NX>(f, x, c.h, c.substeps);
+  } else {
+    int nacc = 0, nrej = 0;
+    if (LDS_STAGES) {
+      LdsStages<NX, BLOCK_LDS> K{stage_l + threadIdx.x};
+      dopri5<NX>(f, K, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    } else {
+      RegStages<NX> K;
+      dopri5<NX>(f, K, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    }
+    if (A.nsteps) {
+      A.nsteps[e] = nacc;
+      A.nsteps[B + e] = nrej;
+    }
+  }
+  // ---- SP slot uses SP[t_old] (pcgym.py:432-438, quirk Q5); t += 1 ----
+  double spv[PCG_MAX_NSP] = {0.0, 0.0, 0.0, 0.0};
+  double spn[PCG_MAX_NSP] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < PCG_MAX_NSP; ++k)
+    if (k < nsp) {
+      spv[k] = sched_at<PER_ENV_T>(A.sched, sched_l, A.sched_in_lds, k, N, tc);
+      spn[k] = sched_at<PER_ENV_T>(A.sched, sched_l, A.sched_in_lds, k, N, tn);
+    }
+  const int t_new = t + 1;
+  // ---- post-step constraints (pcgym.py:443-446) ----
+  bool violated = false;
+  if (EXTRAS && c.ncon > 0) {
+    violated = constraint_rows<M>(c, x, spv, dv, u, A.g, B, e);
+    done |= violated && (flags & PCG_F_DONE_ON_CONS);
+  }
+  done |= (t_new == N - 1);  // pcgym.py:448-449
+  A.done[e] = done ? 1 : 0;
+  if (A.viol) A.viol[e] = violated ? 1 : 0;
+  // ---- reward on the noise-free state (pcgym.py:470-482) ----
+  double r = 0.0;
+  if (flags & PCG_F_REWARD_BATCH) {  // pcgym.py:502-532
+    if (t_new == N - 1) {
+      for (int k = 0; k < c.nrew; ++k) {
+        const double v = pick<NX>(x, c.rew_index[k]) * c.r_scale[k];
+        r = (flags & PCG_F_MAXIMISE) ? r + v : r - v;
+      }
+      if ((flags & PCG_F_R_PENALTY) && violated) r -= 1000.0;
+    }
+  } else {  // pcgym.py:535-558
+#pragma unroll
+    for (int k = 0; k < PCG_MAX_NSP; ++k)
+      if (k < nsp) {
+        const double dd = pick<NX>(x, c.sp_index[k]) - spn[k];
+        r += (-(dd * dd)) * c.r_scale[k];
+        if ((flags & PCG_F_R_PENALTY) && violated) r -= 1000.0;  // Q4: once per SP key
+      }
+  }
+  *rew_out = r;
+  // ---- observation: noise (pcgym.py:452-466), normalise (:483-489), mask (:495-498) ----
+  double zn[NX];
+  if (EXTRAS && (flags & PCG_F_NOISE)) {
+#pragma unroll
+    for (int i = 0; i < NX; i += 2) {
+      double z0, z1;
+      rng_normal2(A.seed, env_id, (uint32_t)t, RNG_NOISE + (uint32_t)(i >> 1), z0, z1);
+      zn[i] = z0;
+      if (i + 1 < NX) zn[i + 1] = z1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    if (i < nx) {
+      double o = x[i];
+      if (EXTRAS && (flags & PCG_F_NOISE)) o += zn[i] * x[i] * c.noise_pct[i];
+      obs_out[(size_t)i * B] = (o - c.o_lo[i]) * c.o_sc[i] + c.o_off[i];
+    }
+#pragma unroll
+  for (int k = 0; k < PCG_MAX_NSP; ++k)
+    if (k < nso) obs_out[(size_t)(nx + k) * B] = (spv[k] - c.o_lo[nx + k]) * c.o_sc[nx + k] + c.o_off[nx + k];
+#pragma unroll
+  for (int k = 0; k < PCG_MAX_NDM; ++k)
+    if (k < nd)
+      obs_out[(size_t)(nx + nso + k) * B] =
+          (dv[k] - c.o_lo[nx + nso + k]) * c.o_sc[nx + nso + k] + c.o_off[nx + nso + k];
+}
+
+// cooperative copy of the schedules into LDS (per-env-t kernels)
+PCG_DEV void stage_schedules(const StepArgs& A, const DevConst& c, double* sched_l) {
+  if (A.sched_in_lds) {
+    const int n = (c.nsp + c.nd) * c.N;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sched_l[i] = A.sched[i];
+    __syncthreads();
+  }
+}
+
+template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS>
+__global__ __launch_bounds__(tb(LDS_STAGES)) void step_kernel(const StepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const DevConst& c = *A.C;
+  constexpr int NX = M::NX, NA = M::NA;
+  double* stage_l = lds;
+  double* sched_l = lds + (LDS_STAGES ? 6 * NX * BLOCK_LDS : 0);
+  if (PER_ENV_T) stage_schedules(A, c, sched_l);
+  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES) + threadIdx.x;
+  if (e >= A.B) return;
+  const int64_t B = A.B;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  const int na = M::DYNAMIC ? c.na : NA;
+  const int t = PER_ENV_T ? A.t[e] : A.t_scalar;
+  double x[NX], a[NA];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) x[i] = (i < nx) ? A.x[(size_t)i * B + e] : 0.0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) a[i] = (i < na) ? A.a[(size_t)i * B + e] : 0.0;
+  double r;
+  env_step<M, INTEG, PER_ENV_T, LDS_STAGES, EXTRAS>(A, c, sched_l, stage_l, e, t, a, x, A.obs + e, &r);
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    if (i < nx) A.x[(size_t)i * B + e] = x[i];
+  A.rew[e] = r;
+  if (PER_ENV_T) A.t[e] = t + 1;
+}
+
+// Open-loop fused rollout: T env steps with x in registers ("next" row f-1).
+template <class M, int INTEG, bool LDS_STAGES>
+__global__ __launch_bounds__(tb(LDS_STAGES)) void rollout_kernel(const StepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const DevConst& c = *A.C;
+  constexpr int NX = M::NX, NA = M::NA;
+  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES) + threadIdx.x;
+  if (e >= A.B) return;
+  const int64_t B = A.B;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  const int na = M::DYNAMIC ? c.na : NA;
+  const int nobs = c.nobs;
+  double x[NX], a[NA];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) x[i] = (i < nx) ? A.x[(size_t)i * B + e] : 0.0;
+  for (int s = 0; s < A.T; ++s) {
+    const double* as = A.a_seq + (size_t)s * na * B;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a[i] = (i < na) ? as[(size_t)i * B + e] : 0.0;
+    const bool last = (s == A.T - 1);
+    double* obs_dst = A.obs_seq ? A.obs_seq + (size_t)s * nobs * B + e : A.obs + e;
+    double r;
+    env_step<M, INTEG, false, LDS_STAGES, true>(A, c, lds, lds, e, A.t_scalar + s, a, x, obs_dst, &r);
+    if (A.rew_seq) A.rew_seq[(size_t)s * B + e] = r;
+    if (last) {
+      A.rew[e] = r;
+      if (A.obs_seq) {  // also mirror the final observation into io->obs
+        for (int i = 0; i < nobs; ++i) A.obs[(size_t)i * B + e] = obs_dst[(size_t)i * B];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    if (i < nx) A.x[(size_t)i * B + e] = x[i];
+}
+
+// reset (pcgym.py:263-349)
+__global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs A) {
+  const DevConst& c = *A.C;
+  const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (e >= A.B) return;
+  if (A.mask && !A.mask[e]) return;
+  const int64_t B = A.B;
+  const int nx = c.nx, nsp = c.nsp_obs, nd = c.nd;
+  const uint64_t env_id = (uint64_t)(A.env_offset + e);
+  for (int i = 0; i < nx; ++i) {
+    double v = c.x0[i];
+    if (c.has_x0_unc && c.x0_unc[i] != 0.0) {  // apply_uncertainties, pcgym.py:255-261
+      const double pct = c.x0_unc[i];
+      if (c.flags & PCG_F_X0_NORMAL) {
+        double z0, z1;
+        rng_normal2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(i >> 1), z0, z1);
+        v = c.x0[i] + pct * c.x0[i] * ((i & 1) ? z1 : z0);
+      } else {
+        double u0, u1;
+        rng_uniform2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(i >> 1), u0, u1);
+        v = c.x0[i] * (1 + pct * (2.0 * ((i & 1) ? u1 : u0) - 1.0));
+      }
+    }
+    A.x[(size_t)i * B + e] = v;
+    A.obs[(size_t)i * B + e] = (v - c.o_lo[i]) * c.o_sc[i] + c.o_off[i];
+  }
+  for (int k = 0; k < nsp; ++k)
+    A.obs[(size_t)(nx + k) * B + e] = (c.x0[nx + k] - c.o_lo[nx + k]) * c.o_sc[nx + k] + c.o_off[nx + k];
+  for (int k = 0; k < nd; ++k) {  // disturbances[k][0] (pcgym.py:291-298, quirk Q6)
+    const int j = nx + nsp + k;
+    A.obs[(size_t)j * B + e] = (A.sched[(size_t)(c.nsp + k) * c.N] - c.o_lo[j]) * c.o_sc[j] + c.o_off[j];
+  }
+  if ((c.flags & PCG_F_A_DELTA) && A.a_save)
+    for (int i = 0; i < c.na; ++i) A.a_save[(size_t)i * B + e] = c.a_0[i];
+  if (A.t) A.t[e] = 0;
+}
+
+// test hooks ------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(BLOCK) void rhs_kernel(const DevConst* C, int64_t B, int nu_rows, const double* xg,
+                                                    const double* ug, double* dxg) {
+  const DevConst& c = *C;
+  constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
+  const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (e >= B) return;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  const int na = M::DYNAMIC ? c.na : NA;
+  double x[NX], dx[NX], u[NA + NDM];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) x[i] = (i < nx) ? xg[(size_t)i * B + e] : 0.0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) u[i] = (i < na) ? ug[(size_t)i * B + e] : 0.0;
+#pragma unroll
+  for (int j = 0; j < NDM; ++j) u[NA + j] = (na + j < nu_rows) ? ug[(size_t)(na + j) * B + e] : c.d_default[j];
+  const typename M::KP& kp = *reinterpret_cast<const typename M::KP*>(c.kp);
+  const typename M::Hold hold = M::hold(kp, u);
+  M::rhs(kp, hold, x, dx);
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    if (i < nx) dxg[(size_t)i * B + e] = dx[i];
+}
+
+template <class M, int INTEG, bool LDS_STAGES>
+__global__ __launch_bounds__(tb(LDS_STAGES)) void integrate_kernel(const DevConst* C, int64_t B, int nu_rows,
+                                                                   double* xg, const double* ug, int32_t* nsteps) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const DevConst& c = *C;
+  constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
+  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES) + threadIdx.x;
+  if (e >= B) return;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  const int na = M::DYNAMIC ? c.na : NA;
+  double x[NX], u[NA + NDM];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) x[i] = (i < nx) ? xg[(size_t)i * B + e] : 0.0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) u[i] = (i < na) ? ug[(size_t)i * B + e] : 0.0;
+#pragma unroll
+  for (int j = 0; j < NDM; ++j) u[NA + j] = (na + j < nu_rows) ? ug[(size_t)(na + j) * B + e] : c.d_default[j];
+  const typename M::KP& kp = *reinterpret_cast<const typename M::KP*>(c.kp);
+  const typename M::Hold hold = M::hold(kp, u);
+  const RhsFn<M> f{kp, hold};
+  if (INTEG == PCG_INT_RK4) {
+    rk4<NX>(f, x, c.h, c.substeps);
+  } else {
+    int nacc = 0, nrej = 0;
+    if (LDS_STAGES) {
+      LdsStages<NX, BLOCK_LDS> K{lds + threadIdx.x};
+      dopri5<NX>(f, K, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    } else {
+      RegStages<NX> K;
+      dopri5<NX>(f, K, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    }
+    if (nsteps) {
+      nsteps[e] = nacc;
+      nsteps[B + e] = nrej;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    if (i < nx) xg[(size_t)i * B + e] = x[i];
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+using StepFn = void (*)(const StepArgs);
+using RhsKFn = void (*)(const DevConst*, int64_t, int, const double*, const double*, double*);
+using IntKFn = void (*)(const DevConst*, int64_t, int, double*, const double*, int32_t*);
+
+struct Kernels {
+  StepFn step[PCG_INT_COUNT][2][2][2];  // [integrator][per_env_t][lds_stages][extras]
+  StepFn rollout[PCG_INT_COUNT][2];  // [integrator][lds_stages]
+  RhsKFn rhs;
+  IntKFn integ[PCG_INT_COUNT][2];
+  int nx, na, ndm, nraw;
+  bool dynamic;
+  void (*prep)(const double*, int, int, double*, double*);
+  size_t kp_bytes;
+};
+
+template <int ID>
+Kernels make_kernels() {
+  using M = Model<ID>;
+  Kernels k;
+  k.step[PCG_INT_RK4][0][0][0] = step_kernel<M, PCG_INT_RK4, false, false, false>;
+  k.step[PCG_INT_RK4][0][0][1] = step_kernel<M, PCG_INT_RK4, false, false, true>;
+  k.step[PCG_INT_RK4][1][0][0] = step_kernel<M, PCG_INT_RK4, true, false, false>;
+  k.step[PCG_INT_RK4][1][0][1] = step_kernel<M, PCG_INT_RK4, true, false, true>;
+  for (int pe = 0; pe < 2; ++pe)
+    for (int ex = 0; ex < 2; ++ex) k.step[PCG_INT_RK4][pe][1][ex] = k.step[PCG_INT_RK4][pe][0][ex];  // no stage store
+  k.step[PCG_INT_DOPRI5][0][0][0] = step_kernel<M, PCG_INT_DOPRI5, false, false, false>;
+  k.step[PCG_INT_DOPRI5][0][0][1] = step_kernel<M, PCG_INT_DOPRI5, false, false, true>;
+  k.step[PCG_INT_DOPRI5][1][0][0] = step_kernel<M, PCG_INT_DOPRI5, true, false, false>;
+  k.step[PCG_INT_DOPRI5][1][0][1] = step_kernel<M, PCG_INT_DOPRI5, true, false, true>;
+  k.step[PCG_INT_DOPRI5][0][1][0] = step_kernel<M, PCG_INT_DOPRI5, false, true, false>;
+  k.step[PCG_INT_DOPRI5][0][1][1] = step_kernel<M, PCG_INT_DOPRI5, false, true, true>;
+  k.step[PCG_INT_DOPRI5][1][1][0] = step_kernel<M, PCG_INT_DOPRI5, true, true, false>;
+  k.step[PCG_INT_DOPRI5][1][1][1] = step_kernel<M, PCG_INT_DOPRI5, true, true, true>;
+  k.rollout[PCG_INT_RK4][0] = rollout_kernel<M, PCG_INT_RK4, false>;
+  k.rollout[PCG_INT_RK4][1] = k.rollout[PCG_INT_RK4][0];
+  k.rollout[PCG_INT_DOPRI5][0] = rollout_kernel<M, PCG_INT_DOPRI5, false>;
+  k.rollout[PCG_INT_DOPRI5][1] = rollout_kernel<M, PCG_INT_DOPRI5, true>;
+  k.rhs = rhs_kernel<M>;
+  k.integ[PCG_INT_RK4][0] = integrate_kernel<M, PCG_INT_RK4, false>;
+  k.integ[PCG_INT_RK4][1] = k.integ[PCG_INT_RK4][0];
+  k.integ[PCG_INT_DOPRI5][0] = integrate_kernel<M, PCG_INT_DOPRI5, false>;
+  k.integ[PCG_INT_DOPRI5][1] = integrate_kernel<M, PCG_INT_DOPRI5, true>;
+  k.nx = M::NX;
+  k.na = M::NA;
+  k.ndm = M::NDM;
+  k.nraw = M::NRAW;
+  k.dynamic = M::DYNAMIC;
+  k.prep = M::prep;
+  k.kp_bytes = sizeof(typename M::KP);
+  return k;
+}
+
+static const Kernels& kernels(int id) {
+  static const Kernels K[PCG_MODEL_COUNT] = {
+      make_kernels<PCG_MODEL_CSTR>(),        make_kernels<PCG_MODEL_FOUR_TANK>(),
+      make_kernels<PCG_MODEL_ME>(),          make_kernels<PCG_MODEL_ME_REACTIVE>(),
+      make_kernels<PCG_MODEL_CRYST>(),       make_kernels<PCG_MODEL_AFFINE>()};
+  return K[id];
+}
+
+// reference default parameters (model_classes.py:24-33, 877-889, 361-367, 777-786, 1260-1270)
+static const double DEF_CSTR[] = {100, 100, 1000, 0.239, -5e4, 8750, 7.2e10, 5e4, 350, 1};
+static const double DEF_FOUR_TANK[] = {9.81, 0.2, 0.2, 0.00085, 0.00095, 0.0035, 0.0030, 0.0020, 0.0025, 1, 1, 1, 1};
+static const double DEF_ME[] = {5, 5, 1, 5, 2, 0.6, 0.05};
+static const double DEF_ME_REACTIVE[] = {5.0, 5.0, 1.0, 0.01, 0.1, 2.0, 2.00, 0.00, 2.00, 0.00};
+static const double DEF_CRYST[] = {0.923714966, -6754.878558, 0.92229965554, 1.341205945, 48.07514464, -4921.261419,
+                                   1.871281405, 0.50523693,   7.271241375,   7.510905767, 2.658};
+static const double* const DEFAULTS[] = {DEF_CSTR, DEF_FOUR_TANK, DEF_ME, DEF_ME_REACTIVE, DEF_CRYST, nullptr};
+
+}  // namespace pcg
+
+using namespace pcg;
+
+struct pcg_plan {
+  uint32_t magic;
+  int device;
+  int model_id, integrator_id;
+  int lds_stages;
+  int64_t env_offset;
+  DevConst hc;       // host copy
+  DevConst* dC;      // device copy
+  double* dsched;    // [nsp+nd][N]
+  size_t sched_bytes;
+  int cfg_nu;        // na + ndm as the caller counts them
+};
+static constexpr uint32_t PLAN_MAGIC = 0x50434731u;  // 'PCG1'
+
+#define HIP_TRY(expr)                          \
+  do {                                         \
+    hipError_t _e = (expr);                    \
+    if (_e != hipSuccess) return (int)_e;      \
+  } while (0)
+
+extern "C" {
+
+int pcg_version(void) { return PCG_ABI_VERSION; }
+
+const char* pcg_strerror(int status) {
+  switch (status) {
+    case PCG_OK: return "ok";
+    case PCG_E_NULL: return "required pointer is NULL";
+    case PCG_E_MODEL: return "unknown model or integrator id";
+    case PCG_E_DIM: return "dimension out of range or inconsistent";
+    case PCG_E_VALUE: return "invalid scalar value";
+    case PCG_E_PLAN: return "invalid plan handle or wrong device";
+    case PCG_E_UNSUPPORTED: return "combination not supported by this build";
+    default: break;
+  }
+  if (status > 0) return hipGetErrorString((hipError_t)status);
+  return "unknown status";
+}
+
+int pcg_model_info(int model_id, int32_t* nx, int32_t* nu, int32_t* ndm, int32_t* n_params) {
+  if (model_id < 0 || model_id >= PCG_MODEL_COUNT) return PCG_E_MODEL;
+  const Kernels& k = kernels(model_id);
+  if (nx) *nx = k.nx;
+  if (nu) *nu = k.na;
+  if (ndm) *ndm = k.ndm;
+  if (n_params) *n_params = k.nraw;
+  return PCG_OK;
+}
+
+int pcg_model_default_params(int model_id, double* out, int32_t n_out) {
+  if (model_id < 0 || model_id >= PCG_MODEL_COUNT) return PCG_E_MODEL;
+  if (!out) return PCG_E_NULL;
+  const Kernels& k = kernels(model_id);
+  if (k.nraw < 0 || !DEFAULTS[model_id]) return PCG_E_UNSUPPORTED;
+  if (n_out < k.nraw) return PCG_E_DIM;
+  for (int i = 0; i < k.nraw; ++i) out[i] = DEFAULTS[model_id][i];
+  return PCG_OK;
+}
+
+void pcg_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t o[4];
+  philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], o);
+  for (int i = 0; i < 4; ++i) out[i] = o[i];
+}
+
+// Validates cfg and fills the host DevConst.  No HIP calls: unit-testable without a GPU.
+static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
+  if (!c || !d) return PCG_E_NULL;
+  if (c->model_id < 0 || c->model_id >= PCG_MODEL_COUNT) return PCG_E_MODEL;
+  if (c->integrator_id < 0 || c->integrator_id >= PCG_INT_COUNT) return PCG_E_MODEL;
+  const Kernels& k = kernels(c->model_id);
+  const int nx = c->nx, na = c->na, ndm = c->ndm, nd = c->nd, nsp = c->nsp, ncon = c->ncon, nrew = c->nrew;
+  if (k.dynamic) {
+    if (nx < 1 || nx > k.nx || na < 1 || na > k.na || ndm != 0) return PCG_E_DIM;
+    if (c->n_params != nx * nx + nx * na + nx) return PCG_E_DIM;
+  } else {
+    if (nx != k.nx || na != k.na) return PCG_E_DIM;
+    if (ndm != 0 && ndm != k.ndm) return PCG_E_DIM;
+    if (c->n_params != k.nraw) return PCG_E_DIM;
+  }
+  if (nd < 0 || nd > ndm || nsp < 0 || nsp > PCG_MAX_NSP || ncon < 0 || ncon > PCG_MAX_NCON) return PCG_E_DIM;
+  const int nso = c->nsp_obs;
+  if (nso != 0 && nso != nsp) return PCG_E_DIM;
+  if (nd > 0 && nso != nsp) return PCG_E_UNSUPPORTED;
+  if (nrew < 0 || nrew > PCG_MAX_NX) return PCG_E_DIM;
+  if (c->N < 2 || c->N > PCG_MAX_N) return PCG_E_DIM;
+  if (!(c->dt > 0.0) || !std::isfinite(c->dt)) return PCG_E_VALUE;
+  if (c->integrator_id == PCG_INT_RK4 && c->substeps < 1) return PCG_E_VALUE;
+  if (c->integrator_id == PCG_INT_DOPRI5 && (!(c->rtol > 0) || !(c->atol >= 0) || c->max_steps < 1))
+    return PCG_E_VALUE;
+  const int nobs = nx + nso + nd, cnu = na + ndm;
+  if (!c->params || !c->x0 || !c->a_low || !c->a_high || !c->o_low || !c->o_high) return PCG_E_NULL;
+  if (nsp && (!c->sp_index || !c->sp)) return PCG_E_NULL;
+  if ((nsp || nrew) && !c->r_scale) return PCG_E_NULL;
+  if (nrew && !c->rew_index) return PCG_E_NULL;
+  if (nd && (!c->d_slot || !c->d_sched)) return PCG_E_NULL;
+  if (ndm && !c->d_default) return PCG_E_NULL;
+  if (ncon && (!c->con_A || !c->con_b)) return PCG_E_NULL;
+  if ((c->flags & PCG_F_A_DELTA) && (!c->a_act_low || !c->a_act_high || !c->a_0)) return PCG_E_NULL;
+  if ((c->flags & PCG_F_NOISE) && !c->noise_pct) return PCG_E_NULL;
+  if ((c->flags & PCG_F_GAUSS_DIST) && nd && (!c->d_sigma || !c->d_clip_lo || !c->d_clip_hi)) return PCG_E_NULL;
+
+  std::memset(d, 0, sizeof(*d));
+  double ddef[PCG_MAX_NDM] = {0, 0, 0, 0};
+  k.prep(c->params, nx, na, d->kp, ddef);
+  for (int j = 0; j < k.ndm; ++j) d->d_default[j] = ndm ? c->d_default[j] : ddef[j];
+  const bool norm_a = c->flags & PCG_F_NORMALISE_A, norm_o = c->flags & PCG_F_NORMALISE_O;
+  const bool compat = c->flags & PCG_F_REF_COMPAT;
+  for (int i = 0; i < na; ++i) {
+    const double lo = c->a_low[i], hs = (c->a_high[i] - c->a_low[i]) / 2;
+    if (!norm_a) {
+      d->a_pre[i] = 0; d->a_scale[i] = 1; d->a_off[i] = 0;
+    } else if ((c->flags & PCG_F_A_DELTA) && compat) {
+      // Q1 (pcgym.py:372-379): f(f(a)), f(a) = (a+1)*hs + lo
+      d->a_pre[i] = 1; d->a_scale[i] = hs * hs; d->a_off[i] = (lo + 1) * hs + lo;
+    } else {
+      d->a_pre[i] = 1; d->a_scale[i] = hs; d->a_off[i] = lo;
+    }
+    if (c->flags & PCG_F_A_DELTA) {
+      d->a_act_lo[i] = c->a_act_low[i]; d->a_act_hi[i] = c->a_act_high[i]; d->a_0[i] = c->a_0[i];
+    }
+  }
+  for (int i = 0; i < nobs; ++i) {
+    const bool masked = (i < nx) && c->obs_mask && !c->obs_mask[i];
+    if (masked) {
+      d->o_lo[i] = 0; d->o_sc[i] = 0; d->o_off[i] = 0;
+    } else if (norm_o) {
+      if (!(c->o_high[i] > c->o_low[i])) return PCG_E_VALUE;
+      d->o_lo[i] = c->o_low[i]; d->o_sc[i] = 2.0 / (c->o_high[i] - c->o_low[i]); d->o_off[i] = -1.0;
+    } else {
+      d->o_lo[i] = 0; d->o_sc[i] = 1; d->o_off[i] = 0;
+    }
+  }
+  for (int i = 0; i < nsp; ++i) {
+    if (c->sp_index[i] < 0 || c->sp_index[i] >= nx) return PCG_E_DIM;
+    d->sp_index[i] = c->sp_index[i];
+  }
+  for (int i = 0; i < nrew; ++i) {
+    if (c->rew_index[i] < 0 || c->rew_index[i] >= nx) return PCG_E_DIM;
+    d->rew_index[i] = c->rew_index[i];
+  }
+  const int nrs = (c->flags & PCG_F_REWARD_BATCH) ? nrew : nsp;
+  for (int i = 0; i < nrs; ++i) d->r_scale[i] = c->r_scale[i];
+  if (c->flags & PCG_F_NOISE)
+    for (int i = 0; i < nx; ++i) d->noise_pct[i] = c->noise_pct[i];
+  for (int i = 0; i < nx + nso; ++i) d->x0[i] = c->x0[i];
+  d->has_x0_unc = c->x0_unc ? 1 : 0;
+  if (c->x0_unc)
+    for (int i = 0; i < nx; ++i) d->x0_unc[i] = c->x0_unc[i];
+  for (int i = 0; i < nd; ++i) {
+    if (c->d_slot[i] < 0 || c->d_slot[i] >= ndm) return PCG_E_DIM;
+    d->d_slot[i] = c->d_slot[i];
+    if (c->flags & PCG_F_GAUSS_DIST) {
+      d->d_sigma[i] = c->d_sigma[i]; d->d_lo[i] = c->d_clip_lo[i]; d->d_hi[i] = c->d_clip_hi[i];
+    }
+  }
+  // constraint rows: cfg layout [state(nobs) | uk(cnu)] -> padded kernel layout; compat Q3 folded:
+  //   state' = (s+1)*hs + lo = s*hs + (hs+lo)   (pcgym.py:601-608), input' likewise with a_space (:597-600)
+  for (int r = 0; r < ncon; ++r) {
+    const double* row = c->con_A + (size_t)r * (nobs + cnu);
+    double b = c->con_b[r];
+    for (int i = 0; i < nobs; ++i) {
+      double coef = row[i];
+      if (compat && norm_o) {
+        const double hs = (c->o_high[i] - c->o_low[i]) / 2;
+        b -= coef * (hs + c->o_low[i]);
+        coef *= hs;
+      }
+      const int col = (i < nx) ? i : (i < nx + nso) ? PCG_MAX_NX + (i - nx) : PCG_MAX_NX + PCG_MAX_NSP + (i - nx - nso);
+      d->con_A[r][col] = coef;
+    }
+    for (int j = 0; j < cnu; ++j) {
+      double coef = row[nobs + j];
+      if (compat && norm_a) {
+        if (cnu != na && na != 1) return PCG_E_UNSUPPORTED;  // the reference itself raises (broadcast error)
+        const int q = (na == 1) ? 0 : j;
+        const double hs = (c->a_high[q] - c->a_low[q]) / 2;
+        b -= coef * (hs + c->a_low[q]);
+        coef *= hs;
+      }
+      const int col = PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + ((j < na) ? j : PCG_MAX_NA + (j - na));
+      d->con_A[r][col] = coef;
+    }
+    d->con_b[r] = b;
+  }
+  d->dt = c->dt;
+  d->h = c->dt / (c->substeps > 0 ? c->substeps : 1);
+  d->rtol = c->rtol;
+  d->atol = c->atol;
+  d->nx = nx; d->na = na; d->ndm = ndm; d->nd = nd; d->nsp = nsp; d->nsp_obs = nso; d->ncon = ncon; d->nrew = nrew;
+  d->N = c->N; d->substeps = c->substeps; d->max_steps = c->max_steps; d->nobs = nobs;
+  d->flags = c->flags;
+  if (cfg_nu_out) *cfg_nu_out = cnu;
+  return PCG_OK;
+}
+
+int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
+  if (!out || !cfg) return PCG_E_NULL;
+  *out = nullptr;
+  pcg_plan* p = new (std::nothrow) pcg_plan();
+  if (!p) return (int)hipErrorOutOfMemory;
+  int rc = build_devconst(cfg, &p->hc, &p->cfg_nu);
+  if (rc != PCG_OK) {
+    delete p;
+    return rc;
+  }
+  p->magic = PLAN_MAGIC;
+  p->model_id = cfg->model_id;
+  p->integrator_id = cfg->integrator_id;
+  p->lds_stages = 0;
+  p->env_offset = 0;
+  p->dC = nullptr;
+  p->dsched = nullptr;
+  hipError_t e = hipGetDevice(&p->device);
+  if (e != hipSuccess) { delete p; return (int)e; }
+  const int rows = cfg->nsp + cfg->nd;
+  p->sched_bytes = sizeof(double) * (size_t)(rows > 0 ? rows : 1) * cfg->N;
+  e = hipMalloc((void**)&p->dC, sizeof(DevConst));
+  if (e == hipSuccess) e = hipMalloc((void**)&p->dsched, p->sched_bytes);
+  if (e == hipSuccess) e = hipMemcpy(p->dC, &p->hc, sizeof(DevConst), hipMemcpyHostToDevice);
+  if (e == hipSuccess && cfg->nsp)
+    e = hipMemcpy(p->dsched, cfg->sp, sizeof(double) * (size_t)cfg->nsp * cfg->N, hipMemcpyHostToDevice);
+  if (e == hipSuccess && cfg->nd)
+    e = hipMemcpy(p->dsched + (size_t)cfg->nsp * cfg->N, cfg->d_sched, sizeof(double) * (size_t)cfg->nd * cfg->N,
+                  hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (p->dC) (void)hipFree(p->dC);
+    if (p->dsched) (void)hipFree(p->dsched);
+    delete p;
+    return (int)e;
+  }
+  *out = p;
+  return PCG_OK;
+}
+
+static bool plan_ok(const pcg_plan* p) { return p && p->magic == PLAN_MAGIC; }
+
+int pcg_plan_destroy(pcg_plan* p) {
+  if (!plan_ok(p)) return PCG_E_PLAN;
+  p->magic = 0;
+  hipError_t e1 = hipFree(p->dC), e2 = hipFree(p->dsched);
+  delete p;
+  if (e1 != hipSuccess) return (int)e1;
+  if (e2 != hipSuccess) return (int)e2;
+  return PCG_OK;
+}
+
+int pcg_plan_set_env_offset(pcg_plan* p, int64_t env_offset) {
+  if (!plan_ok(p)) return PCG_E_PLAN;
+  p->env_offset = env_offset;
+  return PCG_OK;
+}
+
+int pcg_plan_set_option(pcg_plan* p, int option, int64_t value) {
+  if (!plan_ok(p)) return PCG_E_PLAN;
+  switch (option) {
+    case PCG_OPT_ENV_OFFSET: p->env_offset = value; return PCG_OK;
+    case PCG_OPT_LDS_STAGES: p->lds_stages = value ? 1 : 0; return PCG_OK;
+    default: return PCG_E_VALUE;
+  }
+}
+
+int64_t pcg_plan_bytes_per_env_step(const pcg_plan* p, const pcg_buffers* io) {
+  if (!plan_ok(p) || !io) return PCG_E_PLAN;
+  const DevConst& c = p->hc;
+  // read x, read a, write x', write obs, write reward, done (+viol)
+  int64_t A = 8 * (int64_t)(c.nx + c.na + c.nx + c.nobs + 1) + 1;
+  if (io->viol) A += 1;
+  if (io->d) A += 8 * c.nd;
+  if (io->g) A += 8 * c.ncon;
+  if (io->t) A += 8;
+  if ((c.flags & PCG_F_A_DELTA) && io->a_save) A += 16 * c.na;
+  if (io->nsteps) A += 8;
+  return A;
+}
+
+static int fill_args(const pcg_plan* p, const pcg_buffers* io, StepArgs* a) {
+  if (!plan_ok(p)) return PCG_E_PLAN;
+  if (!io) return PCG_E_NULL;
+  if (io->B < 0) return PCG_E_DIM;
+  std::memset(a, 0, sizeof(*a));
+  a->C = p->dC; a->sched = p->dsched;
+  a->x = io->x; a->a = io->a; a->d = io->d; a->t = io->t; a->a_save = io->a_save; a->obs = io->obs;
+  a->rew = io->rew; a->done = io->done; a->viol = io->viol; a->g = io->g; a->g_pre = io->g_pre;
+  a->nsteps = io->nsteps; a->B = io->B; a->env_offset = p->env_offset;
+  return PCG_OK;
+}
+
+static inline unsigned grid_for(int64_t B, int block = BLOCK) { return (unsigned)((B + block - 1) / block); }
+
+int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void* stream) {
+  StepArgs a;
+  int rc = fill_args(p, io, &a);
+  if (rc != PCG_OK) return rc;
+  if (!io->x || !io->a || !io->obs || !io->rew || !io->done) return PCG_E_NULL;
+  const DevConst& c = p->hc;
+  if ((c.flags & PCG_F_A_DELTA) && !io->a_save) return PCG_E_NULL;
+  if (io->B == 0) return PCG_OK;
+  a.t_scalar = t;
+  a.seed = seed;
+  const bool per_env_t = io->t != nullptr;
+  const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5;
+  const Kernels& k = kernels(p->model_id);
+  const int block = tb(lds_st);
+  size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
+  if (per_env_t) {
+    const size_t sb = sizeof(double) * (size_t)(c.nsp + c.nd) * c.N;
+    if (sb > 0 && shmem + sb <= 64 * 1024) {
+      a.sched_in_lds = 1;
+      shmem += sb;
+    }
+  }
+  // lean variant when no noise / Gaussian disturbance / constraint work is configured
+  const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST)) || c.ncon > 0;
+  StepFn fn = k.step[p->integrator_id][per_env_t ? 1 : 0][lds_st ? 1 : 0][extras ? 1 : 0];
+  if (shmem > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(fn, dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int pcg_rollout(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t T, const double* a_seq, double* obs_seq,
+                double* rew_seq, uint64_t seed, void* stream) {
+  StepArgs a;
+  int rc = fill_args(p, io, &a);
+  if (rc != PCG_OK) return rc;
+  if (!io->x || !a_seq || !io->obs || !io->rew || !io->done) return PCG_E_NULL;
+  if (io->t) return PCG_E_UNSUPPORTED;  // lock-stepped only
+  if (T < 1) return PCG_E_VALUE;
+  const DevConst& c = p->hc;
+  if ((c.flags & PCG_F_A_DELTA) && !io->a_save) return PCG_E_NULL;
+  if (io->B == 0) return PCG_OK;
+  a.t_scalar = t0;
+  a.seed = seed;
+  a.T = T;
+  a.a_seq = a_seq;
+  a.obs_seq = obs_seq;
+  a.rew_seq = rew_seq;
+  const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5;
+  const Kernels& k = kernels(p->model_id);
+  const int block = tb(lds_st);
+  const size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
+  StepFn fn = k.rollout[p->integrator_id][lds_st ? 1 : 0];
+  if (shmem > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(fn, dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int pcg_reset(pcg_plan* p, const pcg_buffers* io, const uint8_t* mask, uint64_t seed, void* stream) {
+  StepArgs a;
+  int rc = fill_args(p, io, &a);
+  if (rc != PCG_OK) return rc;
+  if (!io->x || !io->obs) return PCG_E_NULL;
+  if (io->B == 0) return PCG_OK;
+  a.mask = mask;
+  a.seed = seed;
+  hipLaunchKernelGGL(reset_kernel, dim3(grid_for(io->B)), dim3(BLOCK), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int pcg_rhs(pcg_plan* p, int64_t B, const double* x, const double* u, double* dx, void* stream) {
+  if (!plan_ok(p)) return PCG_E_PLAN;
+  if (!x || !u || !dx) return PCG_E_NULL;
+  if (B <= 0) return B == 0 ? PCG_OK : PCG_E_DIM;
+  const Kernels& k = kernels(p->model_id);
+  hipLaunchKernelGGL(k.rhs, dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, p->dC, B, p->cfg_nu, x, u, dx);
+  return (int)hipGetLastError();
+}
+
+int pcg_integrate(pcg_plan* p, int64_t B, double* x, const double* u, int32_t* nsteps, void* stream) {
+  if (!plan_ok(p)) return PCG_E_PLAN;
+  if (!x || !u) return PCG_E_NULL;
+  if (B <= 0) return B == 0 ? PCG_OK : PCG_E_DIM;
+  const Kernels& k = kernels(p->model_id);
+  const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5;
+  const int block = tb(lds_st);
+  const size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
+  IntKFn fn = k.integ[p->integrator_id][lds_st ? 1 : 0];
+  if (shmem > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(fn, dim3(grid_for(B, block)), dim3(block), shmem, (hipStream_t)stream, p->dC, B, p->cfg_nu, x, u,
+                     nsteps);
+  return (int)hipGetLastError();
+}
+
+// Host-only validation of a cfg (what pcg_plan_create would return before touching the
+// device): lets the host logic be tested on machines without a GPU.
+int pcg_cfg_validate(const pcg_env_cfg* cfg) {
+  DevConst* d = new (std::nothrow) DevConst();
+  if (!d) return (int)hipErrorOutOfMemory;
+  int rc = build_devconst(cfg, d, nullptr);
+  delete d;
+  return rc;
+}
+
+}  // extern "C"

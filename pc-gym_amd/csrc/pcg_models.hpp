@@ -1,0 +1,309 @@
+// pcg_models.hpp -- ODE right-hand sides of the hot-path models as device functors.
+//
+// One struct per model: compile-time sizes, a POD of pre-folded constants (KP, read
+// through wave-uniform scalar loads -> SGPRs), a per-env-step `Hold` of everything
+// that depends only on the held input u (zero-order hold over [0,dt],
+// reference integrator.py:163-182), and rhs(kp, hold, x, dx).
+//
+// The arithmetic restates reference src/pcgym/model_classes.py (line ranges per
+// model below); constants that the reference recomputes on every call
+// (q/V, 1/(rho*C), ...) are folded once on the host in prep().
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/pcgym_hip.h"
+
+namespace pcg {
+
+#define PCG_DEV __device__ __forceinline__
+
+template <int ID>
+struct Model;
+
+// ---------------------------------------------------------------------------
+// cstr -- model_classes.py:23-62.  raw = q,V,rho,C,deltaHr,EA_over_R,k0,UA,Ti,Caf
+// u = [Tc | Ti, Caf]
+// ---------------------------------------------------------------------------
+template <>
+struct Model<PCG_MODEL_CSTR> {
+  static constexpr int NX = 2, NA = 1, NDM = 2, NRAW = 10;
+  static constexpr bool DYNAMIC = false;
+  struct KP {
+    double qV, c1, c2, k0, nEAR;
+  };
+  struct Hold {
+    double Tc, Ti, Caf;
+  };
+  static void prep(const double* r, int /*nx*/, int /*nu*/, double* kp_out, double* ddef) {
+    KP k;
+    k.qV = r[0] / r[1];
+    k.c1 = (-r[4]) * (1.0 / (r[2] * r[3]));
+    k.c2 = r[7] * (1.0 / (r[2] * r[3] * r[1]));
+    k.k0 = r[6];
+    k.nEAR = -r[5];
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+    ddef[0] = r[8];
+    ddef[1] = r[9];
+  }
+  PCG_DEV static Hold hold(const KP&, const double (&u)[NA + NDM]) { return Hold{u[0], u[1], u[2]}; }
+  PCG_DEV static void rhs(const KP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+    const double ca = x[0], T = x[1];
+    const double rA = k.k0 * exp(k.nEAR / T) * ca;
+    dx[0] = k.qV * (h.Caf - ca) - rA;
+    dx[1] = k.qV * (h.Ti - T) + k.c1 * rA + k.c2 * (h.Tc - T);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// four_tank -- model_classes.py:864-931.  raw = g,gamma_1,gamma_2,k1,k2,a1..a4,A1..A4
+// ---------------------------------------------------------------------------
+template <>
+struct Model<PCG_MODEL_FOUR_TANK> {
+  static constexpr int NX = 4, NA = 2, NDM = 0, NRAW = 13;
+  static constexpr bool DYNAMIC = false;
+  struct KP {
+    double g2;              // 2 g
+    double o1, o2, o3, o4;  // a_i / A_i
+    double i31, i42;        // a3/A1, a4/A2
+    double p1, p2, p3, p4;  // pump gains
+  };
+  struct Hold {
+    double q1, q2, q3, q4;  // pump inflow terms, constant over the step
+  };
+  static void prep(const double* r, int, int, double* kp_out, double*) {
+    KP k;
+    k.g2 = 2 * r[0];
+    k.o1 = r[5] / r[9];
+    k.o2 = r[6] / r[10];
+    k.o3 = r[7] / r[11];
+    k.o4 = r[8] / r[12];
+    k.i31 = r[7] / r[9];
+    k.i42 = r[8] / r[10];
+    k.p1 = (r[1] * r[3]) / r[9];
+    k.p2 = (r[2] * r[4]) / r[10];
+    k.p3 = ((1 - r[2]) * r[4]) / r[11];
+    k.p4 = ((1 - r[1]) * r[3]) / r[12];
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  PCG_DEV static Hold hold(const KP& k, const double (&u)[NA + NDM]) {
+    return Hold{k.p1 * u[0], k.p2 * u[1], k.p3 * u[1], k.p4 * u[0]};
+  }
+  PCG_DEV static void rhs(const KP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+    const double s1 = sqrt(k.g2 * x[0]), s2 = sqrt(k.g2 * x[1]);
+    const double s3 = sqrt(k.g2 * x[2]), s4 = sqrt(k.g2 * x[3]);
+    dx[0] = -k.o1 * s1 + k.i31 * s3 + h.q1;
+    dx[1] = -k.o2 * s2 + k.i42 * s4 + h.q2;
+    dx[2] = -k.o3 * s3 + h.q3;
+    dx[3] = -k.o4 * s4 + h.q4;
+  }
+};
+
+// Y^e/m for the extraction models: e == 2 (the reference default,
+// model_classes.py:365) is the hot case and is a multiply; any other exponent
+// goes through pow().  `sq` is wave-uniform.
+PCG_DEV double eq_curve(double Y, double e, double inv_m, bool sq) {
+  return (sq ? Y * Y : pow(Y, e)) * inv_m;
+}
+
+// ---------------------------------------------------------------------------
+// multistage_extraction -- model_classes.py:346-430.  raw = Vl,Vg,m,Kla,eq_exponent,X0,Y6
+// u = [L, G | X0, Y6];  x = X1,Y1,...,X5,Y5
+// ---------------------------------------------------------------------------
+template <>
+struct Model<PCG_MODEL_ME> {
+  static constexpr int NX = 10, NA = 2, NDM = 2, NRAW = 7;
+  static constexpr bool DYNAMIC = false;
+  struct KP {
+    double iVl, iVg, inv_m, KlaVl, e, sq;
+  };
+  struct Hold {
+    double L, G, X0, Y6;
+  };
+  static void prep(const double* r, int, int, double* kp_out, double* ddef) {
+    KP k;
+    k.iVl = 1 / r[0];
+    k.iVg = 1 / r[1];
+    k.inv_m = 1 / r[2];
+    k.KlaVl = r[3] * r[0];
+    k.e = r[4];
+    k.sq = (r[4] == 2.0) ? 1.0 : 0.0;
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+    ddef[0] = r[5];
+    ddef[1] = r[6];
+  }
+  PCG_DEV static Hold hold(const KP&, const double (&u)[NA + NDM]) { return Hold{u[0], u[1], u[2], u[3]}; }
+  PCG_DEV static void rhs(const KP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+    const bool sq = k.sq != 0.0;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const double X = x[2 * s], Y = x[2 * s + 1];
+      const double Q = k.KlaVl * (X - eq_curve(Y, k.e, k.inv_m, sq));
+      const double Xp = (s == 0) ? h.X0 : x[2 * s - 2];
+      const double Yn = (s == 4) ? h.Y6 : x[2 * s + 3];
+      dx[2 * s] = k.iVl * (h.L * (Xp - X) - Q);
+      dx[2 * s + 1] = k.iVg * (h.G * (Yn - Y) + Q);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// multistage_extraction_reactive -- model_classes.py:763-861.
+// raw = Vl,Vg,m,Kla,k,eq_exponent,XA0,YA6,YB6,YC6 ; x = (XA,YA,YB,YC) x 5
+// ---------------------------------------------------------------------------
+template <>
+struct Model<PCG_MODEL_ME_REACTIVE> {
+  static constexpr int NX = 20, NA = 2, NDM = 0, NRAW = 10;
+  static constexpr bool DYNAMIC = false;
+  struct KP {
+    double iVl, iVg, inv_m, KlaVl, kVg, e, sq, XA0, YA6, YB6, YC6;
+  };
+  struct Hold {
+    double L, G;
+  };
+  static void prep(const double* r, int, int, double* kp_out, double*) {
+    KP k;
+    k.iVl = 1 / r[0];
+    k.iVg = 1 / r[1];
+    k.inv_m = 1 / r[2];
+    k.KlaVl = r[3] * r[0];
+    k.kVg = r[4] * r[1];
+    k.e = r[5];
+    k.sq = (r[5] == 2.0) ? 1.0 : 0.0;
+    k.XA0 = r[6];
+    k.YA6 = r[7];
+    k.YB6 = r[8];
+    k.YC6 = r[9];
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  PCG_DEV static Hold hold(const KP&, const double (&u)[NA + NDM]) { return Hold{u[0], u[1]}; }
+  PCG_DEV static void rhs(const KP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+    const bool sq = k.sq != 0.0;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const double XA = x[4 * s], YA = x[4 * s + 1], YB = x[4 * s + 2], YC = x[4 * s + 3];
+      const double Q = k.KlaVl * (XA - eq_curve(YA, k.e, k.inv_m, sq));
+      const double rV = k.kVg * YA * YB;  // r * Vg
+      const double XAp = (s == 0) ? k.XA0 : x[4 * s - 4];
+      const double YAn = (s == 4) ? k.YA6 : x[4 * s + 5];
+      const double YBn = (s == 4) ? k.YB6 : x[4 * s + 6];
+      const double YCn = (s == 4) ? k.YC6 : x[4 * s + 7];
+      dx[4 * s + 0] = k.iVl * (h.L * (XAp - XA) - Q);
+      dx[4 * s + 1] = k.iVg * (h.G * (YAn - YA) + Q - rV);
+      dx[4 * s + 2] = k.iVg * (h.G * (YBn - YB) - rV);
+      dx[4 * s + 3] = k.iVg * (h.G * (YCn - YC) + rV);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// crystallization -- model_classes.py:1232-1345.
+// raw = ka,kb,kc,kd,kg,k1,k2,a,b,alfa,ro ; x = mu0..mu3,conc,CV,Ln ; u = [T degC]
+// The input-only factors (Ceq(T), exp(kb/Tk), exp(k1/Tk)) are constant over the
+// held step and are evaluated once per env step, not once per RK stage.
+// ---------------------------------------------------------------------------
+template <>
+struct Model<PCG_MODEL_CRYST> {
+  static constexpr int NX = 7, NA = 1, NDM = 0, NRAW = 11;
+  static constexpr bool DYNAMIC = false;
+  struct KP {
+    double ka, kb, kc2, kd2, kg, k1, k22, a, b, cc;  // kc2 = kc/2 ..., cc = -0.5*ro*alfa
+  };
+  struct Hold {
+    double Ceq, eB, eG;  // eB = ka*exp(kb/Tk), eG = kg*exp(k1/Tk)
+  };
+  static void prep(const double* r, int, int, double* kp_out, double*) {
+    KP k;
+    k.ka = r[0];
+    k.kb = r[1];
+    k.kc2 = r[2] / 2;
+    k.kd2 = r[3] / 2;
+    k.kg = r[4];
+    k.k1 = r[5];
+    k.k22 = r[6] / 2;
+    k.a = r[7];
+    k.b = r[8];
+    k.cc = -0.5 * r[10] * r[9];
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  PCG_DEV static Hold hold(const KP& k, const double (&u)[NA + NDM]) {
+    const double Tk = u[0] + 273.15;
+    Hold h;
+    h.Ceq = -686.2686 + 3.579165 * Tk - 0.00292874 * (Tk * Tk);
+    h.eB = k.ka * exp(k.kb / Tk);
+    h.eG = k.kg * exp(k.k1 / Tk);
+    return h;
+  }
+  PCG_DEV static void rhs(const KP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+    const double mu0 = x[0], mu1 = x[1], mu2 = x[2], mu3 = x[3], conc = x[4];
+    const double S = conc * 1e3 - h.Ceq;
+    const double S2 = S * S;
+    const double B0 = h.eB * pow(S2, k.kc2) * pow(mu3 * mu3, k.kd2);
+    const double Ginf = h.eG * pow(S2, k.k22);
+    const double m12 = k.a * mu1 * 1e-4 + k.b * mu2 * 1e-8;
+    const double m23 = k.a * mu2 * 1e-8 + k.b * mu3 * 1e-12;
+    const double d0 = B0;
+    const double d1 = Ginf * (k.a * mu0 + k.b * mu1 * 1e-4) * 1e4;
+    const double d2 = 2 * Ginf * m12 * 1e8;
+    const double d3 = 3 * Ginf * m23 * 1e12;
+    const double mu1sq = mu1 * mu1;
+    const double CV = sqrt(mu2 * mu0 / mu1sq - 1);
+    dx[0] = d0;
+    dx[1] = d1;
+    dx[2] = d2;
+    dx[3] = d3;
+    dx[4] = k.cc * Ginf * m23;
+    dx[5] = 1 / (2 * CV + 1e-10) * ((d2 * mu0 + mu2 * d0) * mu1sq - mu2 * mu0 * 2 * mu1 * d1) /
+            (mu1sq * mu1sq + 1e-10);
+    dx[6] = (d1 * mu0 - mu1 * d0) / (mu0 * mu0 + 1e-10);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// affine custom model -- dx = A x + B u + c  (pcgym.py:150-153 custom_model whose
+// RHS is affine; the reference's only KAT, tests/environment/
+// test_make_env_custom_model.py:66-86).  raw = A[nx][nx] | B[nx][nu] | c[nx].
+// Padded with zeros to 8 states / 4 inputs: padded states have dx = 0.
+// ---------------------------------------------------------------------------
+template <>
+struct Model<PCG_MODEL_AFFINE> {
+  static constexpr int NX = 8, NA = 4, NDM = 0, NRAW = -1;
+  static constexpr bool DYNAMIC = true;  // runtime nx<=8, na<=4
+  struct KP {
+    double A[8][8], Bm[8][4], c[8];
+  };
+  struct Hold {
+    double f[8];  // B u + c
+  };
+  static void prep(const double* r, int nx, int nu, double* kp_out, double*) {
+    KP k;
+    __builtin_memset(&k, 0, sizeof(k));
+    for (int i = 0; i < nx; ++i) {
+      for (int j = 0; j < nx; ++j) k.A[i][j] = r[i * nx + j];
+      for (int j = 0; j < nu; ++j) k.Bm[i][j] = r[nx * nx + i * nu + j];
+      k.c[i] = r[nx * nx + nx * nu + i];
+    }
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  PCG_DEV static Hold hold(const KP& k, const double (&u)[NA + NDM]) {
+    Hold h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      double s = k.c[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += k.Bm[i][j] * u[j];
+      h.f[i] = s;
+    }
+    return h;
+  }
+  PCG_DEV static void rhs(const KP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      double s = h.f[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += k.A[i][j] * x[j];
+      dx[i] = s;
+    }
+  }
+};
+
+}  // namespace pcg

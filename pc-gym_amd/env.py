@@ -1,0 +1,357 @@
+"""Gymnasium-shaped façade over the HIP engine.
+
+``make_env(env_params)`` keeps the reference's single-environment surface
+(src/pcgym/pcgym.py:31-500: ``reset() -> (obs, info)``,
+``step(a) -> (obs, float, bool, False, info)``, the attributes its callers read --
+policy_evaluation.py:86-128 -- and the ``env_params`` dict verbatim).
+``make_vec_env(env_params, n_envs)`` / ``VecEnv`` is the batched form: B
+environments stepped by one kernel launch, state held in torch tensors on the
+GPU in SoA layout ``field[component][B]``; observations are returned as the
+``(B, Nobs)`` strided view of that storage (no copy).
+
+There is no CPU path: constructing an env without the HIP library / a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as abi
+from . import _lib
+from .config import EnvSpec
+from .spaces import Box
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class VecEnv:
+    """B environments of one configuration on one GPU.
+
+    Parameters
+    ----------
+    env_params : dict        the reference's configuration dict (+ optional new keys, config.py)
+    n_envs : int             batch size B
+    device : torch.device | int | None   GPU holding the state (default: current CUDA device)
+    seed : int               base key of the counter-based RNG (noise / Gaussian disturbances /
+                             reset uncertainty); episode k uses seed + k
+    per_env_t : bool         every env carries its own step counter (needed for masked
+                             auto-reset when episodes can end at different times)
+    auto_reset : bool        reset finished envs inside step() (gymnasium "same-step" mode)
+    env_offset : int         global index of env 0 (multi-GPU sharding: keeps RNG streams disjoint)
+    """
+
+    def __init__(self, env_params, n_envs=1, device=None, seed=0, per_env_t=False, auto_reset=False,
+                 env_offset=0, lds_stages=False):
+        self.spec = s = EnvSpec(env_params)
+        self.env_params = s.env_params
+        if s.custom_reward is not None and not getattr(self, "_allow_custom_reward", False):
+            raise ValueError("custom_reward callables cannot run inside the batched kernel; use the built-in "
+                             "SP / terminal reward, or the single-env make_env() façade which evaluates the "
+                             "callable on the host exactly like the reference (pcgym.py:470-471)")
+        torch = _torch()
+        self._lib = _lib.load()  # raises when the HIP library is missing: no fallback
+        if not torch.cuda.is_available():
+            raise RuntimeError("pcgym_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU implementation of the step path")
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        elif isinstance(device, int):
+            device = torch.device("cuda", device)
+        self.device = torch.device(device)
+        self.B = int(n_envs)
+        self.seed0 = int(seed)
+        self.episode = 0
+        self.per_env_t = bool(per_env_t)
+        self.auto_reset = bool(auto_reset)
+        if self.auto_reset and s.done_on_constraint and not self.per_env_t:
+            raise ValueError("auto_reset with done_on_cons_vio needs per_env_t=True")
+        self.t = 0
+
+        # reference attribute names (pcgym.py:105-111, 160-199)
+        self.N, self.tsim, self.dt = s.N, s.tsim, s.dt
+        self.Nx, self.Nx_oracle = s.nobs, s.nx
+        self.Nu, self.Nd, self.Nd_model = s.nu, s.nd, s.ndm
+        self.SP, self.model = s.SP, s.model
+        self.constraint_active, self.n_con = s.constraint_active, s.ncon
+        self.normalise_a, self.normalise_o, self.a_delta = s.normalise_a, s.normalise_o, s.a_delta
+        self.observation_space_base = Box(s.o_low, s.o_high)
+        if s.normalise_o:
+            self.observation_space = Box(-np.ones(s.nobs), np.ones(s.nobs))
+        else:
+            self.observation_space = self.observation_space_base
+        if s.normalise_a:
+            self.action_space = Box(-np.ones(s.na), np.ones(s.na))
+        else:
+            self.action_space = Box(s.a_low, s.a_high)
+
+        cfg, keep = s.to_cfg()
+        plan = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.pcg_plan_create(C.byref(plan), C.byref(cfg)), "pcg_plan_create")
+        del keep
+        self._plan = plan
+        _lib.check(self._lib.pcg_plan_set_env_offset(plan, int(env_offset)), "pcg_plan_set_env_offset")
+        if lds_stages:
+            _lib.check(self._lib.pcg_plan_set_option(plan, abi.PCG_OPT_LDS_STAGES, 1), "pcg_plan_set_option")
+
+        B, dev, f64 = self.B, self.device, torch.float64
+        self.x = torch.zeros((s.nx, B), dtype=f64, device=dev)
+        self.obs_soa = torch.zeros((s.nobs, B), dtype=f64, device=dev)
+        self.rew = torch.zeros(B, dtype=f64, device=dev)
+        self.done = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self.viol = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self.a_save_t = torch.zeros((s.na, B), dtype=f64, device=dev) if s.a_delta else None
+        self.g = torch.zeros((s.ncon, B), dtype=f64, device=dev) if s.ncon else None
+        self.g_pre = torch.zeros((s.ncon, B), dtype=f64, device=dev) if s.ncon else None
+        self.t_env = torch.zeros(B, dtype=torch.int32, device=dev) if self.per_env_t else None
+        self.nsteps = (torch.zeros((2, B), dtype=torch.int32, device=dev)
+                       if s.integrator == "dopri5" else None)
+        b = self._buf = abi.pcg_buffers()
+        b.B = B
+        b.x = self.x.data_ptr()
+        b.obs = self.obs_soa.data_ptr()
+        b.rew = self.rew.data_ptr()
+        b.done = self.done.data_ptr()
+        b.viol = self.viol.data_ptr() if s.ncon else None
+        b.a_save = self.a_save_t.data_ptr() if self.a_save_t is not None else None
+        b.g = self.g.data_ptr() if self.g is not None else None
+        b.g_pre = self.g_pre.data_ptr() if self.g_pre is not None else None
+        b.t = self.t_env.data_ptr() if self.t_env is not None else None
+        b.nsteps = self.nsteps.data_ptr() if self.nsteps is not None else None
+        self._bufp = C.byref(b)
+        self._a_hold = None
+        self._d_hold = None
+
+    # ------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_plan", None):
+            self._lib.pcg_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _stream(self):
+        return _torch().cuda.current_stream(self.device).cuda_stream
+
+    @property
+    def obs(self):
+        """(B, Nobs) view of the SoA observation storage."""
+        return self.obs_soa.t()
+
+    @property
+    def bytes_per_env_step(self):
+        return int(self._lib.pcg_plan_bytes_per_env_step(self._plan, self._bufp))
+
+    def _episode_seed(self):
+        return (self.seed0 + self.episode) & 0xFFFFFFFFFFFFFFFF
+
+    def reset(self, seed=None, mask=None):
+        """Reset all envs (or those with mask != 0).  Returns (obs (B,Nobs), info)."""
+        if seed is not None:
+            self.seed0 = int(seed)
+        self.episode += 1
+        mptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=_torch().uint8).contiguous()
+            mptr = mask.data_ptr()
+        else:
+            self.t = 0
+        _lib.check(self._lib.pcg_reset(self._plan, self._bufp, mptr, self._episode_seed(), self._stream()),
+                   "pcg_reset")
+        return self.obs, {}
+
+    def _as_soa(self, v, rows, what):
+        torch = _torch()
+        if not torch.is_tensor(v):
+            v = torch.as_tensor(np.asarray(v, dtype=np.float64), device=self.device)
+        v = v.to(device=self.device, dtype=torch.float64)
+        if v.dim() == 1:
+            v = v.reshape(1, -1) if rows == 1 else v.reshape(-1, 1).expand(rows, self.B)
+        if v.shape == (rows, self.B):
+            return v.contiguous()
+        if v.shape == (self.B, rows):
+            return v.t().contiguous()
+        raise ValueError(f"{what} must have shape ({rows},{self.B}) [SoA, zero-copy] or ({self.B},{rows})")
+
+    def step(self, action, disturbance=None):
+        """One env step for all B envs (reference make_env.step, pcgym.py:350-500).
+
+        action : (na,B) SoA tensor (zero-copy) or (B,na); disturbance : optional (nd,B) per-env
+        values overriding the shared schedule.  Returns (obs, rew, done, truncated, info) with
+        batched tensors; all device-side and asynchronous on the current stream.
+        """
+        s = self.spec
+        a = self._as_soa(action, s.na, "action")
+        self._a_hold = a  # keep alive until the next call (async launch)
+        self._buf.a = a.data_ptr()
+        if disturbance is not None:
+            d = self._as_soa(disturbance, s.nd, "disturbance")
+            self._d_hold = d
+            self._buf.d = d.data_ptr()
+        else:
+            self._buf.d = None
+        _lib.check(self._lib.pcg_step(self._plan, self._bufp, self.t, self._episode_seed(), self._stream()),
+                   "pcg_step")
+        self.t += 1
+        info = {}
+        if s.ncon:
+            info["viol"] = self.viol
+            info["g"] = self.g
+        if self.nsteps is not None:
+            info["nsteps"] = self.nsteps
+        if self.auto_reset:
+            if self.per_env_t:
+                self.episode += 1
+                _lib.check(self._lib.pcg_reset(self._plan, self._bufp, self.done.data_ptr(),
+                                               self._episode_seed(), self._stream()), "pcg_reset")
+            elif self.t == self.N - 1:
+                self.reset()
+        return self.obs, self.rew, self.done.view(_torch().bool), False, info
+
+    def rollout(self, actions, collect_obs=False, collect_rew=True):
+        """Fused open-loop rollout: actions (T,na,B); state stays in registers for T steps."""
+        torch = _torch()
+        if self.per_env_t:
+            raise ValueError("rollout() is lock-stepped only")
+        s = self.spec
+        actions = actions.to(device=self.device, dtype=torch.float64).contiguous()
+        T = actions.shape[0]
+        if actions.shape != (T, s.na, self.B):
+            raise ValueError(f"actions must be (T,{s.na},{self.B})")
+        obs_seq = torch.empty((T, s.nobs, self.B), dtype=torch.float64, device=self.device) if collect_obs else None
+        rew_seq = torch.empty((T, self.B), dtype=torch.float64, device=self.device) if collect_rew else None
+        self._buf.d = None
+        _lib.check(self._lib.pcg_rollout(self._plan, self._bufp, self.t, T, actions.data_ptr(),
+                                         obs_seq.data_ptr() if collect_obs else None,
+                                         rew_seq.data_ptr() if collect_rew else None,
+                                         self._episode_seed(), self._stream()), "pcg_rollout")
+        self._a_hold = actions
+        self.t += T
+        return obs_seq, rew_seq
+
+    # state_dict for checkpoint/resume of the env batch
+    def state_dict(self):
+        d = {"x": self.x.clone(), "t": self.t, "episode": self.episode, "seed0": self.seed0}
+        if self.a_save_t is not None:
+            d["a_save"] = self.a_save_t.clone()
+        if self.t_env is not None:
+            d["t_env"] = self.t_env.clone()
+        return d
+
+    def load_state_dict(self, d):
+        self.x.copy_(d["x"])
+        self.t, self.episode, self.seed0 = int(d["t"]), int(d["episode"]), int(d["seed0"])
+        if self.a_save_t is not None:
+            self.a_save_t.copy_(d["a_save"])
+        if self.t_env is not None:
+            self.t_env.copy_(d["t_env"])
+
+
+def make_vec_env(env_params, n_envs, **kw):
+    return VecEnv(env_params, n_envs=n_envs, **kw)
+
+
+class make_env(VecEnv):
+    """Single environment with the reference's exact call surface (numpy in/out)."""
+
+    _allow_custom_reward = True
+
+    def __init__(self, env_params, device=None, seed=0):
+        if not isinstance(env_params, dict):
+            raise ValueError("env_params must be a dictionary")
+        super().__init__(env_params, n_envs=1, device=device, seed=seed)
+        s = self.spec
+        self.info = {}
+        if s.constraint_active:
+            self.info["cons_info"] = np.zeros((s.ncon, s.N, 1))
+        self.custom_reward = s.custom_reward is not None
+        self.custom_reward_f = s.custom_reward
+        self.x0 = s.x0
+        self.integration_method = s.integration_method
+        self.state = s.x0_full().copy()
+        self.obs_np = self.state.copy()
+        self.a_save = s.a_0.copy() if s.a_delta else None
+
+    # -- host-side mirrors needed only for the callable custom_reward path -------------
+    def _host_uk(self, action):
+        s = self.spec
+        a = np.asarray(action, dtype=np.float64).reshape(-1).copy()
+        if s.normalise_a:
+            a = (a + 1) * (s.a_high - s.a_low) / 2 + s.a_low
+        if s.normalise_a and s.a_delta:
+            if s.reference_compat:
+                a = (a + 1) * (s.a_high - s.a_low) / 2 + s.a_low
+            a = self.a_save + a
+        uk = np.zeros(s.nu)
+        uk[:s.na] = a
+        if s.ndm:
+            uk[s.na:] = s.d_default
+            tn = min(self.t + 1, s.N - 1)
+            for k in range(s.nd):
+                uk[s.na + s.d_slot[k]] = s.d_sched[k, tn]
+        return uk
+
+    def _sync_state(self):
+        s = self.spec
+        self.state[:s.nx] = self.x[:, 0].cpu().numpy()
+
+    def reset(self, seed=0, **kwargs):
+        s = self.spec
+        obs, _ = super().reset()
+        self.state = s.x0_full().copy()
+        self._sync_state()
+        if s.a_delta:
+            self.a_save = s.a_0.copy()
+        o = obs[0].cpu().numpy().copy()
+        self.obs_np = self.state.copy()
+        self.info["obs"] = o.copy()
+        self.info["r_init"] = 0
+        self.done_flag = False
+        return o, self.info
+
+    def step(self, action):
+        s = self.spec
+        t_old = self.t
+        uk = self._host_uk(action) if (self.custom_reward or s.a_delta) else None
+        a = np.asarray(action, dtype=np.float64).reshape(s.na, 1)
+        obs, rew, done, _, _ = super().step(_torch().as_tensor(a, device=self.device))
+        o = obs[0].cpu().numpy().copy()
+        self._sync_state()
+        tc, tn = min(t_old, s.N - 1), min(t_old + 1, s.N - 1)
+        for k in range(s.nsp):
+            self.state[s.nx + k] = s.sp[k, tc]
+        for k in range(s.nd):
+            self.state[s.nx + s.nsp + k] = s.d_sched[k, tn]
+        if s.a_delta:
+            self.a_save = self.a_save_t[:, 0].cpu().numpy().copy()
+        violated = False
+        if s.ncon:
+            violated = bool(self.viol[0].item())
+            if t_old == 0:
+                self.info["cons_info"][:, 0, 0] = self.g_pre[:, 0].cpu().numpy()
+            if self.t < s.N:
+                self.info["cons_info"][:, self.t, 0] = self.g[:, 0].cpu().numpy()
+        r = float(rew[0].item())
+        if self.custom_reward:
+            # the reference hands the callable the un-normalised (noisy) observation (pcgym.py:470-471)
+            if s.normalise_o:
+                with np.errstate(all="ignore"):
+                    obs_un = (o + 1) / 2 * (s.o_high - s.o_low) + s.o_low
+            else:
+                obs_un = o.copy()
+            if s.obs_mask is not None:
+                m = s.obs_mask == 0
+                obs_un[:s.nx][m] = self.state[:s.nx][m]
+            self.obs_np = obs_un
+            r = self.custom_reward_f(self, obs_un, uk, violated)
+        self.info["obs"] = o.copy()
+        return o, r, bool(done[0].item()), False, self.info
