@@ -63,9 +63,11 @@ struct DevConst {
   uint32_t flags;
 };
 
+using CDevConst = const PCG_CONSTANT DevConst;
+
 struct StepArgs {
-  const DevConst* C;
-  const double* sched;  // [nsp + nd][N]
+  CDevConst* C;                       // constant address space: uniform reads -> s_load
+  const PCG_CONSTANT double* sched;   // [nsp + nd][N]
   double* x;
   const double* a;
   const double* d;
@@ -143,7 +145,7 @@ PCG_DEV double pick(const double (&v)[N], int idx) {
 
 template <class M>
 struct RhsFn {
-  const typename M::KP& kp;
+  typename M::CKP& kp;
   const typename M::Hold& hold;
   PCG_DEV void operator()(const double (&x)[M::NX], double (&dx)[M::NX]) const { M::rhs(kp, hold, x, dx); }
 };
@@ -151,12 +153,12 @@ struct RhsFn {
 // constraint rows g = A.[x|sp|d|u] - b  (affine form of the reference's callable, pcgym.py:560-577);
 // writes rows to gout (if non-null) and returns "any row > 0".
 template <class M>
-PCG_DEV bool constraint_rows(const DevConst& c, const double (&x)[M::NX], const double (&spv)[PCG_MAX_NSP],
+PCG_DEV bool constraint_rows(CDevConst& c, const double (&x)[M::NX], const double (&spv)[PCG_MAX_NSP],
                              const double (&dv)[PCG_MAX_NDM], const double (&u)[M::NA + M::NDM], double* gout,
                              int64_t B, int64_t e) {
   bool violated = false;
   for (int r = 0; r < c.ncon; ++r) {
-    const double* row = c.con_A[r];
+    const PCG_CONSTANT double* row = c.con_A[r];
     double g = -c.con_b[r];
 #pragma unroll
     for (int i = 0; i < M::NX; ++i) g += row[i] * x[i];
@@ -177,7 +179,7 @@ PCG_DEV bool constraint_rows(const DevConst& c, const double (&x)[M::NX], const 
 
 // schedule lookup: lock-stepped -> uniform scalar load; per-env t -> LDS table (or global)
 template <bool PER_ENV_T>
-PCG_DEV double sched_at(const double* sched_g, const double* sched_l, bool in_lds, int row, int N, int idx) {
+PCG_DEV double sched_at(const PCG_CONSTANT double* sched_g, const double* sched_l, bool in_lds, int row, int N, int idx) {
   if (PER_ENV_T && in_lds) return sched_l[row * N + idx];
   return sched_g[(size_t)row * N + idx];
 }
@@ -188,7 +190,7 @@ PCG_DEV double sched_at(const double* sched_g, const double* sched_l, bool in_ld
 // Returns through out-params; does all global stores except x itself.
 // ---------------------------------------------------------------------------
 template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS>
-PCG_DEV void env_step(const StepArgs& A, const DevConst& c, const double* sched_l, double* stage_l, int64_t e,
+PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, double* stage_l, int64_t e,
                       int t, const double (&a_in)[M::NA], double (&x)[M::NX], double* obs_out, double* rew_out) {
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
   const int64_t B = A.B;
@@ -199,7 +201,7 @@ PCG_DEV void env_step(const StepArgs& A, const DevConst& c, const double* sched_
   const int tn = min(t + 1, N - 1);  // schedule index clamp (the reference would IndexError)
   const int tc = min(t, N - 1);
   const uint64_t env_id = (uint64_t)(A.env_offset + e);
-  const typename M::KP& kp = *reinterpret_cast<const typename M::KP*>(c.kp);
+  typename M::CKP& kp = *(typename M::CKP*)(c.kp);
 
   // ---- action map (pcgym.py:371-383) ----
   double u[NA + NDM];
@@ -333,7 +335,7 @@ PCG_DEV void env_step(const StepArgs& A, const DevConst& c, const double* sched_
 }
 
 // cooperative copy of the schedules into LDS (per-env-t kernels)
-PCG_DEV void stage_schedules(const StepArgs& A, const DevConst& c, double* sched_l) {
+PCG_DEV void stage_schedules(const StepArgs& A, CDevConst& c, double* sched_l) {
   if (A.sched_in_lds) {
     const int n = (c.nsp + c.nd) * c.N;
     for (int i = threadIdx.x; i < n; i += blockDim.x) sched_l[i] = A.sched[i];
@@ -344,7 +346,7 @@ PCG_DEV void stage_schedules(const StepArgs& A, const DevConst& c, double* sched
 template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS>
 __global__ __launch_bounds__(tb(LDS_STAGES)) void step_kernel(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const DevConst& c = *A.C;
+  CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA;
   double* stage_l = lds;
   double* sched_l = lds + (LDS_STAGES ? 6 * NX * BLOCK_LDS : 0);
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(tb(LDS_STAGES)) void step_kernel(const StepArgs A) 
 template <class M, int INTEG, bool LDS_STAGES>
 __global__ __launch_bounds__(tb(LDS_STAGES)) void rollout_kernel(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const DevConst& c = *A.C;
+  CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA;
   const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES) + threadIdx.x;
   if (e >= A.B) return;
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(tb(LDS_STAGES)) void rollout_kernel(const StepArgs 
 
 // reset (pcgym.py:263-349)
 __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs A) {
-  const DevConst& c = *A.C;
+  CDevConst& c = *A.C;
   const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (e >= A.B) return;
   if (A.mask && !A.mask[e]) return;
@@ -444,9 +446,9 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs A) {
 
 // test hooks ------------------------------------------------------------------
 template <class M>
-__global__ __launch_bounds__(BLOCK) void rhs_kernel(const DevConst* C, int64_t B, int nu_rows, const double* xg,
+__global__ __launch_bounds__(BLOCK) void rhs_kernel(CDevConst* C, int64_t B, int nu_rows, const double* xg,
                                                     const double* ug, double* dxg) {
-  const DevConst& c = *C;
+  CDevConst& c = *C;
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
   const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (e >= B) return;
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(BLOCK) void rhs_kernel(const DevConst* C, int64_t B
   for (int i = 0; i < NA; ++i) u[i] = (i < na) ? ug[(size_t)i * B + e] : 0.0;
 #pragma unroll
   for (int j = 0; j < NDM; ++j) u[NA + j] = (na + j < nu_rows) ? ug[(size_t)(na + j) * B + e] : c.d_default[j];
-  const typename M::KP& kp = *reinterpret_cast<const typename M::KP*>(c.kp);
+  typename M::CKP& kp = *(typename M::CKP*)(c.kp);
   const typename M::Hold hold = M::hold(kp, u);
   M::rhs(kp, hold, x, dx);
 #pragma unroll
@@ -468,10 +470,10 @@ __global__ __launch_bounds__(BLOCK) void rhs_kernel(const DevConst* C, int64_t B
 }
 
 template <class M, int INTEG, bool LDS_STAGES>
-__global__ __launch_bounds__(tb(LDS_STAGES)) void integrate_kernel(const DevConst* C, int64_t B, int nu_rows,
+__global__ __launch_bounds__(tb(LDS_STAGES)) void integrate_kernel(CDevConst* C, int64_t B, int nu_rows,
                                                                    double* xg, const double* ug, int32_t* nsteps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const DevConst& c = *C;
+  CDevConst& c = *C;
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
   const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES) + threadIdx.x;
   if (e >= B) return;
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(tb(LDS_STAGES)) void integrate_kernel(const DevCons
   for (int i = 0; i < NA; ++i) u[i] = (i < na) ? ug[(size_t)i * B + e] : 0.0;
 #pragma unroll
   for (int j = 0; j < NDM; ++j) u[NA + j] = (na + j < nu_rows) ? ug[(size_t)(na + j) * B + e] : c.d_default[j];
-  const typename M::KP& kp = *reinterpret_cast<const typename M::KP*>(c.kp);
+  typename M::CKP& kp = *(typename M::CKP*)(c.kp);
   const typename M::Hold hold = M::hold(kp, u);
   const RhsFn<M> f{kp, hold};
   if (INTEG == PCG_INT_RK4) {
@@ -512,8 +514,8 @@ __global__ __launch_bounds__(tb(LDS_STAGES)) void integrate_kernel(const DevCons
 // host side
 // ---------------------------------------------------------------------------
 using StepFn = void (*)(const StepArgs);
-using RhsKFn = void (*)(const DevConst*, int64_t, int, const double*, const double*, double*);
-using IntKFn = void (*)(const DevConst*, int64_t, int, double*, const double*, int32_t*);
+using RhsKFn = void (*)(CDevConst*, int64_t, int, const double*, const double*, double*);
+using IntKFn = void (*)(CDevConst*, int64_t, int, double*, const double*, int32_t*);
 
 struct Kernels {
   StepFn step[PCG_INT_COUNT][2][2][2];  // [integrator][per_env_t][lds_stages][extras]
@@ -865,7 +867,7 @@ static int fill_args(const pcg_plan* p, const pcg_buffers* io, StepArgs* a) {
   if (!io) return PCG_E_NULL;
   if (io->B < 0) return PCG_E_DIM;
   std::memset(a, 0, sizeof(*a));
-  a->C = p->dC; a->sched = p->dsched;
+  a->C = (CDevConst*)p->dC; a->sched = (const PCG_CONSTANT double*)p->dsched;
   a->x = io->x; a->a = io->a; a->d = io->d; a->t = io->t; a->a_save = io->a_save; a->obs = io->obs;
   a->rew = io->rew; a->done = io->done; a->viol = io->viol; a->g = io->g; a->g_pre = io->g_pre;
   a->nsteps = io->nsteps; a->B = io->B; a->env_offset = p->env_offset;
@@ -950,7 +952,7 @@ int pcg_rhs(pcg_plan* p, int64_t B, const double* x, const double* u, double* dx
   if (!x || !u || !dx) return PCG_E_NULL;
   if (B <= 0) return B == 0 ? PCG_OK : PCG_E_DIM;
   const Kernels& k = kernels(p->model_id);
-  hipLaunchKernelGGL(k.rhs, dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, p->dC, B, p->cfg_nu, x, u, dx);
+  hipLaunchKernelGGL(k.rhs, dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, (CDevConst*)p->dC, B, p->cfg_nu, x, u, dx);
   return (int)hipGetLastError();
 }
 
@@ -965,8 +967,8 @@ int pcg_integrate(pcg_plan* p, int64_t B, double* x, const double* u, int32_t* n
   IntKFn fn = k.integ[p->integrator_id][lds_st ? 1 : 0];
   if (shmem > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(fn, dim3(grid_for(B, block)), dim3(block), shmem, (hipStream_t)stream, p->dC, B, p->cfg_nu, x, u,
-                     nsteps);
+  hipLaunchKernelGGL(fn, dim3(grid_for(B, block)), dim3(block), shmem, (hipStream_t)stream, (CDevConst*)p->dC, B, p->cfg_nu, x,
+                     u, nsteps);
   return (int)hipGetLastError();
 }
 

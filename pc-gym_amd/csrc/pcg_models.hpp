@@ -16,6 +16,11 @@
 namespace pcg {
 
 #define PCG_DEV __device__ __forceinline__
+// Plan constants are read through the CONSTANT address space (AMDGPU addrspace 4): a load with a
+// wave-uniform address then always becomes a scalar s_load (SGPR destination, scalar cache), even
+// after the kernel has issued vector stores -- with a plain global pointer the compiler must assume
+// the stores may alias and falls back to per-lane global_load (51 of them in the first build).
+#define PCG_CONSTANT __attribute__((address_space(4)))
 
 template <int ID>
 struct Model;
@@ -31,6 +36,7 @@ struct Model<PCG_MODEL_CSTR> {
   struct KP {
     double qV, c1, c2, k0, nEAR;
   };
+  using CKP = const PCG_CONSTANT KP;
   struct Hold {
     double Tc, Ti, Caf;
   };
@@ -45,8 +51,8 @@ struct Model<PCG_MODEL_CSTR> {
     ddef[0] = r[8];
     ddef[1] = r[9];
   }
-  PCG_DEV static Hold hold(const KP&, const double (&u)[NA + NDM]) { return Hold{u[0], u[1], u[2]}; }
-  PCG_DEV static void rhs(const KP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+  PCG_DEV static Hold hold(CKP&, const double (&u)[NA + NDM]) { return Hold{u[0], u[1], u[2]}; }
+  PCG_DEV static void rhs(CKP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
     const double ca = x[0], T = x[1];
     const double rA = k.k0 * exp(k.nEAR / T) * ca;
     dx[0] = k.qV * (h.Caf - ca) - rA;
@@ -67,6 +73,7 @@ struct Model<PCG_MODEL_FOUR_TANK> {
     double i31, i42;        // a3/A1, a4/A2
     double p1, p2, p3, p4;  // pump gains
   };
+  using CKP = const PCG_CONSTANT KP;
   struct Hold {
     double q1, q2, q3, q4;  // pump inflow terms, constant over the step
   };
@@ -85,10 +92,10 @@ struct Model<PCG_MODEL_FOUR_TANK> {
     k.p4 = ((1 - r[1]) * r[3]) / r[12];
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  PCG_DEV static Hold hold(const KP& k, const double (&u)[NA + NDM]) {
+  PCG_DEV static Hold hold(CKP& k, const double (&u)[NA + NDM]) {
     return Hold{k.p1 * u[0], k.p2 * u[1], k.p3 * u[1], k.p4 * u[0]};
   }
-  PCG_DEV static void rhs(const KP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+  PCG_DEV static void rhs(CKP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
     const double s1 = sqrt(k.g2 * x[0]), s2 = sqrt(k.g2 * x[1]);
     const double s3 = sqrt(k.g2 * x[2]), s4 = sqrt(k.g2 * x[3]);
     dx[0] = -k.o1 * s1 + k.i31 * s3 + h.q1;
@@ -116,6 +123,7 @@ struct Model<PCG_MODEL_ME> {
   struct KP {
     double iVl, iVg, inv_m, KlaVl, e, sq;
   };
+  using CKP = const PCG_CONSTANT KP;
   struct Hold {
     double L, G, X0, Y6;
   };
@@ -131,8 +139,8 @@ struct Model<PCG_MODEL_ME> {
     ddef[0] = r[5];
     ddef[1] = r[6];
   }
-  PCG_DEV static Hold hold(const KP&, const double (&u)[NA + NDM]) { return Hold{u[0], u[1], u[2], u[3]}; }
-  PCG_DEV static void rhs(const KP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+  PCG_DEV static Hold hold(CKP&, const double (&u)[NA + NDM]) { return Hold{u[0], u[1], u[2], u[3]}; }
+  PCG_DEV static void rhs(CKP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
     const bool sq = k.sq != 0.0;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
@@ -157,6 +165,7 @@ struct Model<PCG_MODEL_ME_REACTIVE> {
   struct KP {
     double iVl, iVg, inv_m, KlaVl, kVg, e, sq, XA0, YA6, YB6, YC6;
   };
+  using CKP = const PCG_CONSTANT KP;
   struct Hold {
     double L, G;
   };
@@ -175,8 +184,8 @@ struct Model<PCG_MODEL_ME_REACTIVE> {
     k.YC6 = r[9];
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  PCG_DEV static Hold hold(const KP&, const double (&u)[NA + NDM]) { return Hold{u[0], u[1]}; }
-  PCG_DEV static void rhs(const KP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+  PCG_DEV static Hold hold(CKP&, const double (&u)[NA + NDM]) { return Hold{u[0], u[1]}; }
+  PCG_DEV static void rhs(CKP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
     const bool sq = k.sq != 0.0;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
@@ -208,6 +217,7 @@ struct Model<PCG_MODEL_CRYST> {
   struct KP {
     double ka, kb, kc2, kd2, kg, k1, k22, a, b, cc;  // kc2 = kc/2 ..., cc = -0.5*ro*alfa
   };
+  using CKP = const PCG_CONSTANT KP;
   struct Hold {
     double Ceq, eB, eG;  // eB = ka*exp(kb/Tk), eG = kg*exp(k1/Tk)
   };
@@ -225,7 +235,7 @@ struct Model<PCG_MODEL_CRYST> {
     k.cc = -0.5 * r[10] * r[9];
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  PCG_DEV static Hold hold(const KP& k, const double (&u)[NA + NDM]) {
+  PCG_DEV static Hold hold(CKP& k, const double (&u)[NA + NDM]) {
     const double Tk = u[0] + 273.15;
     Hold h;
     h.Ceq = -686.2686 + 3.579165 * Tk - 0.00292874 * (Tk * Tk);
@@ -233,7 +243,7 @@ struct Model<PCG_MODEL_CRYST> {
     h.eG = k.kg * exp(k.k1 / Tk);
     return h;
   }
-  PCG_DEV static void rhs(const KP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+  PCG_DEV static void rhs(CKP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
     const double mu0 = x[0], mu1 = x[1], mu2 = x[2], mu3 = x[3], conc = x[4];
     const double S = conc * 1e3 - h.Ceq;
     const double S2 = S * S;
@@ -271,6 +281,7 @@ struct Model<PCG_MODEL_AFFINE> {
   struct KP {
     double A[8][8], Bm[8][4], c[8];
   };
+  using CKP = const PCG_CONSTANT KP;
   struct Hold {
     double f[8];  // B u + c
   };
@@ -284,7 +295,7 @@ struct Model<PCG_MODEL_AFFINE> {
     }
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  PCG_DEV static Hold hold(const KP& k, const double (&u)[NA + NDM]) {
+  PCG_DEV static Hold hold(CKP& k, const double (&u)[NA + NDM]) {
     Hold h;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -295,7 +306,7 @@ struct Model<PCG_MODEL_AFFINE> {
     }
     return h;
   }
-  PCG_DEV static void rhs(const KP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+  PCG_DEV static void rhs(CKP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       double s = h.f[i];

@@ -327,10 +327,10 @@ class make_env(VecEnv):
         o = obs[0].cpu().numpy().copy()
         self._sync_state()
         tc, tn = min(t_old, s.N - 1), min(t_old + 1, s.N - 1)
-        for k in range(s.nsp):
+        for k in range(s.nsp_obs):
             self.state[s.nx + k] = s.sp[k, tc]
         for k in range(s.nd):
-            self.state[s.nx + s.nsp + k] = s.d_sched[k, tn]
+            self.state[s.nx + s.nsp_obs + k] = s.d_sched[k, tn]
         if s.a_delta:
             self.a_save = self.a_save_t[:, 0].cpu().numpy().copy()
         violated = False

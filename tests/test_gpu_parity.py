@@ -1,0 +1,463 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the
+C ABI (libpcgym_hip.so via pcgym_amd); the oracle is only the checker.
+
+Bars: RHS / fixed-step integration / epilogue vs the oracle running the SAME
+algorithm: <= 1e-12 relative (OCML vs glibc transcendental ulps, FMA contraction);
+vs the reference recordings (golden): the integrator's accuracy class, tightened
+by using tight integrator settings so the epilogue is checked at ~1e-9.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as H
+import scenarios as SC
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU test selected but no GPU visible"
+    return torch
+
+
+def _loaded_native():
+    """fail loudly if the HIP extension is not the thing that runs"""
+    from pcgym_amd import _lib
+
+    lib = _lib.load()
+    assert lib.pcg_version() == 1
+    return lib
+
+
+def test_native_library_loaded():
+    _torch()
+    _loaded_native()
+    with open("/proc/self/maps") as f:
+        assert "libpcgym_hip.so" in f.read()
+
+
+# ------------------------------------------------------------------ RHS ------
+RHS_CASES = [("cstr", "cstr"), ("cstr_d", "cstr"), ("four_tank", "four_tank"),
+             ("multistage_extraction", "multistage_extraction"),
+             ("multistage_extraction_d", "multistage_extraction"),
+             ("multistage_extraction_reactive", "multistage_extraction_reactive"),
+             ("crystallization", "crystallization")]
+
+
+def _plan_for(spec, torch):
+    from pcgym_amd import _lib
+
+    lib = _lib.load()
+    cfg, keep = spec.to_cfg()
+    plan = C.c_void_p()
+    _lib.check(lib.pcg_plan_create(C.byref(plan), C.byref(cfg)), "pcg_plan_create")
+    return lib, plan
+
+
+@pytest.mark.parametrize("fix,model", RHS_CASES)
+def test_rhs_vs_reference_and_oracle(fix, model):
+    torch = _torch()
+    from oracle import oracle as O
+    from pcgym_amd import models as M
+    from test_oracle_golden import _spec_for_integration
+
+    g = H.gold("rhs_" + fix)
+    mi = M.get_model(model)
+    spec = _spec_for_integration(model, 1.0, g["u"].shape[1])
+    lib, plan = _plan_for(spec, torch)
+    x = torch.tensor(g["x"].T.copy(), device="cuda")
+    u = torch.tensor(g["u"].T.copy(), device="cuda")
+    dx = torch.zeros_like(x)
+    assert lib.pcg_rhs(plan, x.shape[1], x.data_ptr(), u.data_ptr(), dx.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    got = dx.cpu().numpy().T
+    lib.pcg_plan_destroy(plan)
+    want_ref = g["dx"]
+    want_orc = O.rhs(mi.model_id, mi.param_vector(), g["x"].T, g["u"].T).T
+    scale = np.maximum(np.abs(want_ref), 1e-3 * np.max(np.abs(want_ref), axis=0, keepdims=True))
+    assert np.max(np.abs(got - want_orc) / scale) <= 1e-12
+    assert np.max(np.abs(got - want_ref) / scale) <= 1e-12
+
+
+# ------------------------------------------------------------ integrate ------
+INT_CASES = [
+    ("cstr", "cstr", dict(integrator="rk4", substeps=4), 1e-12),
+    ("cstr", "cstr", dict(integrator="dopri5"), 1e-9),
+    ("cstr_d", "cstr", dict(integrator="rk4", substeps=16), 1e-12),
+    ("four_tank", "four_tank", dict(integrator="rk4", substeps=4), 1e-12),
+    ("four_tank", "four_tank", dict(integrator="dopri5"), 1e-9),
+    ("multistage_extraction", "multistage_extraction", dict(integrator="dopri5"), 1e-9),
+    ("multistage_extraction", "multistage_extraction", dict(integrator="rk4", substeps=256), 1e-11),
+    ("multistage_extraction_d", "multistage_extraction", dict(integrator="dopri5"), 1e-9),
+    ("multistage_extraction_reactive", "multistage_extraction_reactive", dict(integrator="dopri5"), 1e-9),
+    ("multistage_extraction_reactive", "multistage_extraction_reactive", dict(integrator="rk4", substeps=64), 1e-12),
+    ("crystallization", "crystallization", dict(integrator="rk4", substeps=32), 1e-11),
+    ("crystallization", "crystallization", dict(integrator="dopri5"), 1e-9),
+]
+
+
+@pytest.mark.parametrize("fix,model,kw,tol", INT_CASES)
+@pytest.mark.parametrize("lds_stages", [False, True])
+def test_integrate_vs_oracle(fix, model, kw, tol, lds_stages):
+    if lds_stages and kw["integrator"] != "dopri5":
+        pytest.skip("stage store only exists for dopri5")
+    torch = _torch()
+    from oracle import oracle as O
+    from pcgym_amd import _abi as abi
+    from test_oracle_golden import _spec_for_integration
+
+    g = H.gold("tight_" + fix)
+    spec = _spec_for_integration(model, float(g["dt"]), g["u"].shape[1], **kw)
+    lib, plan = _plan_for(spec, torch)
+    if lds_stages:
+        assert lib.pcg_plan_set_option(plan, abi.PCG_OPT_LDS_STAGES, 1) == 0
+    ok = np.ones(g["x"].shape[0], dtype=bool)
+    if model == "cstr" and kw["integrator"] == "rk4":
+        ok = g["xf"][:, 1] < 360.0  # ignition samples diverge under fixed-step RK4 on CPU and GPU alike
+    xs, us = g["x"][ok].T.copy(), g["u"][ok].T.copy()
+    x = torch.tensor(xs, device="cuda")
+    u = torch.tensor(us, device="cuda")
+    ns = torch.zeros((2, x.shape[1]), dtype=torch.int32, device="cuda")
+    assert lib.pcg_integrate(plan, x.shape[1], x.data_ptr(), u.data_ptr(), ns.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    lib.pcg_plan_destroy(plan)
+    got = x.cpu().numpy()
+    want, ns_o = O.integrate(spec, xs, us)
+    scale = np.maximum(np.abs(want), 1e-6 * np.max(np.abs(want), axis=1, keepdims=True))
+    assert np.max(np.abs(got - want) / scale) <= tol
+    if kw["integrator"] == "dopri5":
+        ns_g = ns.cpu().numpy()
+        # same controller: accepted/rejected counts agree except for razor-edge decisions
+        assert np.mean(ns_g == ns_o) >= 0.9
+    # and against the LSODA(1e-13) truth, in the integrator's accuracy class
+    t = g["xf"][ok].T
+    assert np.all(np.abs(got - t) <= 1e-5 * np.abs(t) + 1e-7)
+
+
+# ------------------------------------------- reference step tuples (B = 1) ---
+STEP_SCENARIOS = sorted(SC.scenarios().keys())
+
+
+@pytest.mark.parametrize("name", STEP_SCENARIOS)
+def test_make_env_matches_reference_recordings(name):
+    """the reference's own make_env.reset()/step() tuples (tests/golden/step_*.npz),
+    replayed through pcgym_amd.make_env == libpcgym_hip.so on the GPU."""
+    _torch()
+    import copy
+
+    from pcgym_amd import make_env
+
+    g = H.gold("step_" + name)
+    sc = SC.scenarios()[name]
+    p = copy.deepcopy(sc["env_params"])
+    p.update(H.tight_for(p))
+    env = make_env(p)
+    A = SC.actions_for(name, sc)
+    obs, info = env.reset()
+    assert obs.shape == g["obs"][0].shape
+    assert np.all(np.abs(obs - g["obs"][0]) <= 1e-12 * np.maximum(1.0, np.abs(g["obs"][0])))
+    first_done = None
+    for i in range(sc["steps"]):
+        o, r, d, trunc, info = env.step(A[i])
+        want = g["obs"][i + 1]
+        assert isinstance(r, float) and isinstance(d, bool) and trunc is False
+        assert np.all(np.abs(o - want) <= 2e-9 * np.maximum(np.abs(want), 1.0)), (name, i, o, want)
+        assert abs(r - g["rew"][i]) <= 1e-7 * max(1.0, abs(g["rew"][i])), (name, i, r, g["rew"][i])
+        if first_done is None:
+            assert d == bool(g["done"][i]), (name, i)
+            if d:
+                first_done = i
+        st = g["state"][i + 1]
+        assert np.all(np.abs(env.state - st) <= 2e-9 * np.maximum(np.abs(st), 1.0)), (name, i)
+    if "cons_info" in g.files:
+        ci = g["cons_info"]
+        T = sc["steps"]
+        assert np.allclose(info["cons_info"][:, : T + 1, 0], ci[:, : T + 1], rtol=1e-8,
+                           atol=1e-9 * np.max(np.abs(ci)))
+    env.close()
+
+
+def test_reference_kat_custom_linear_model_on_gpu():
+    """tests/environment/test_make_env_custom_model.py:66-86 through the HIP path,
+    default integrator settings, the reference's own tolerance (np.isclose)."""
+    _torch()
+    from pcgym_amd import make_env
+
+    sc = SC.scenarios()["custom_linear_kat"]
+    env = make_env(sc["env_params"])
+    obs, _ = env.reset()
+    assert np.allclose(obs, np.array([1.0, 1.0]))
+    obs, reward, done, truncated, info = env.step(np.array([0.5]))
+    assert np.isclose(obs[0], 1.21578082)
+    assert np.isclose(obs[1], 1.28403262)
+    env.close()
+
+
+# ------------------------------------------- batched vs oracle, same algorithm
+BATCH_CASES = [
+    ("cstr_canonical", {}, 1e-12),
+    ("cstr_cons_pen_norm", {}, 1e-12),
+    ("cstr_cons_done_raw", {}, 1e-12),
+    ("cstr_dist_both", {}, 1e-12),
+    ("four_tank_canonical", {}, 1e-12),
+    ("me_canonical", dict(integrator="rk4", substeps=64), 1e-11),
+    ("me_canonical", {}, 1e-9),
+    ("me_dist_cons", {}, 1e-9),
+    ("cryst_adelta", {}, 1e-10),
+    ("me_reactive", dict(integrator="rk4", substeps=32), 1e-11),
+    ("cstr_batch_reward", {}, 1e-12),
+    ("cstr_partial_obs", {}, 1e-12),
+]
+
+
+def _rand_actions(spec, T, B, seed):
+    rng = np.random.default_rng(seed)
+    if spec.normalise_a:
+        return rng.uniform(-1, 1, (T, spec.na, B))
+    return rng.uniform(spec.a_low[None, :, None], spec.a_high[None, :, None], (T, spec.na, B))
+
+
+@pytest.mark.parametrize("name,kw,tol", BATCH_CASES)
+@pytest.mark.parametrize("per_env_t", [False, True])
+def test_batched_step_vs_oracle(name, kw, tol, per_env_t):
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    B, T = 777, 12  # ragged: not a multiple of the wave or block size
+    sc = SC.scenarios()[name]
+    p = copy.deepcopy(sc["env_params"])
+    p.update(kw)
+    # keep the ME cases in a moderately stiff regime so the CPU oracle finishes in seconds
+    env = VecEnv(p, n_envs=B, seed=5, per_env_t=per_env_t)
+    spec = env.spec
+    orc = O.OracleEnv(spec, B, seed=5, per_env_t=per_env_t)
+    acts = _rand_actions(spec, T, B, 3)
+    if spec.model.name.startswith("multistage"):
+        acts = acts * 0.2 - 0.7 if spec.normalise_a else acts
+    o_g, _ = env.reset()
+    o_c = orc.reset()
+    rng = np.random.default_rng(9)
+    x0 = orc.x * (1 + 0.02 * rng.uniform(-1, 1, orc.x.shape))
+    if spec.model.name == "crystallization":
+        x0[5] = np.sqrt(x0[2] * x0[0] / x0[1] ** 2 - 1)
+        x0[6] = x0[1] / x0[0]
+    orc.x[:] = x0
+    env.x.copy_(torch.tensor(x0, device=env.device))
+    assert np.allclose(o_g.cpu().numpy().T, o_c, rtol=1e-13, atol=1e-13)
+    for i in range(T):
+        a = acts[i]
+        og, rg, dg, _, info = env.step(torch.tensor(a, device=env.device))
+        oc, rc, dc = orc.step(a)
+        torch.cuda.synchronize()
+        og, rg, dg = og.cpu().numpy().T, rg.cpu().numpy(), dg.cpu().numpy()
+        sc_o = np.maximum(np.abs(oc), 1e-3)
+        assert np.max(np.abs(og - oc) / sc_o) <= tol * 10, (name, i)
+        xs = np.maximum(np.abs(orc.x), 1e-6 * np.max(np.abs(orc.x), axis=1, keepdims=True))
+        assert np.max(np.abs(env.x.cpu().numpy() - orc.x) / xs) <= tol, (name, i)
+        assert np.max(np.abs(rg - rc) / np.maximum(np.abs(rc), 1.0)) <= max(tol * 100, 1e-10), (name, i)
+        assert np.array_equal(dg.astype(np.uint8), dc), (name, i)
+        if spec.ncon:
+            assert np.mean(env.viol.cpu().numpy() == orc.viol) >= 0.999
+            gs = np.maximum(np.abs(orc.g), 1e-3 * np.max(np.abs(orc.g)))
+            assert np.max(np.abs(env.g.cpu().numpy() - orc.g) / gs) <= max(tol * 100, 1e-10)
+        if spec.a_delta:
+            assert np.allclose(env.a_save_t.cpu().numpy(), orc.a_save, rtol=1e-13)
+        if per_env_t:
+            assert np.array_equal(env.t_env.cpu().numpy(), orc.t_env)
+    env.close()
+
+
+def test_noise_and_gaussian_disturbance_vs_oracle():
+    """counter-based RNG: same Philox stream on both sides -> same noise to ~1e-13"""
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    sc = SC.scenarios()["cstr_dist_Ti"]
+    p = copy.deepcopy(sc["env_params"])
+    p.update(noise=True, noise_percentage=0.01, gaussian_disturbances={"Ti": 2.0})
+    B = 1000
+    env = VecEnv(p, n_envs=B, seed=77, env_offset=123456789012)
+    orc = O.OracleEnv(env.spec, B, seed=77, env_offset=123456789012)
+    env.reset()
+    orc.reset()
+    acts = _rand_actions(env.spec, 6, B, 1)
+    for i in range(6):
+        og, rg, dg, _, _ = env.step(torch.tensor(acts[i], device=env.device))
+        oc, rc, dc = orc.step(acts[i])
+        og = og.cpu().numpy().T
+        assert np.max(np.abs(og - oc)) <= 1e-11
+        assert np.max(np.abs(env.x.cpu().numpy() - orc.x) / np.abs(orc.x)) <= 1e-12
+    # the disturbance slot really is noisy and clipped to its bounds
+    d = (og[3] + 1) / 2 * 40 + 320
+    assert d.std() > 1.0 and d.min() >= 320 - 1e-9 and d.max() <= 360 + 1e-9
+    # noise statistics (pcgym.py:457-459: multiplicative, pct = 1 %)
+    env.close()
+
+
+def test_reset_uncertainty_and_masked_reset():
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    sc = SC.scenarios()["cstr_canonical"]
+    for dist in ("uniform", "normal"):
+        p = copy.deepcopy(sc["env_params"])
+        p.update(uncertainty_percentages={"x0": [0.05, 0.01]}, distribution=dist,
+                 uncertainty_bounds={"low": np.zeros(0), "high": np.zeros(0)})
+        B = 4096
+        env = VecEnv(p, n_envs=B, seed=3, per_env_t=True)
+        orc = O.OracleEnv(env.spec, B, seed=3, per_env_t=True)
+        og, _ = env.reset()
+        oc = orc.reset()
+        assert np.max(np.abs(env.x.cpu().numpy() - orc.x) / np.abs(orc.x)) <= 1e-13
+        assert np.max(np.abs(og.cpu().numpy().T - oc)) <= 1e-12
+        x = env.x.cpu().numpy()
+        assert abs(x[0].mean() / 0.8 - 1) < 5e-3 and x[0].std() > 0.8 * 0.05 / 3
+        # masked reset touches only the selected envs
+        a = _rand_actions(env.spec, 1, B, 0)[0]
+        env.step(torch.tensor(a, device=env.device))
+        orc.step(a)
+        mask = (np.arange(B) % 3 == 0).astype(np.uint8)
+        before = env.x.cpu().numpy().copy()
+        env.reset(mask=torch.tensor(mask, device=env.device))
+        orc.reset(mask=mask)
+        after = env.x.cpu().numpy()
+        assert np.array_equal(after[:, mask == 0], before[:, mask == 0])
+        assert np.max(np.abs(after - orc.x) / np.abs(orc.x)) <= 1e-13
+        assert np.array_equal(env.t_env.cpu().numpy(), orc.t_env)
+        env.close()
+
+
+def test_rollout_equals_stepping():
+    torch = _torch()
+    import copy
+
+    from pcgym_amd import VecEnv
+
+    for name in ("cstr_canonical", "four_tank_canonical"):
+        sc = SC.scenarios()[name]
+        B, T = 1000, 20
+        e1 = VecEnv(copy.deepcopy(sc["env_params"]), n_envs=B)
+        e2 = VecEnv(copy.deepcopy(sc["env_params"]), n_envs=B)
+        acts = torch.tensor(_rand_actions(e1.spec, T, B, 4), device=e1.device)
+        e1.reset()
+        e2.reset()
+        obs_seq, rew_seq = e2.rollout(acts, collect_obs=True, collect_rew=True)
+        for i in range(T):
+            o, r, d, _, _ = e1.step(acts[i])
+            # two different kernels (lean step vs fused rollout): same arithmetic, but the compiler is
+            # free to contract FMAs differently -> 1e-13, not bitwise
+            assert torch.allclose(o.t().contiguous(), obs_seq[i], rtol=1e-13, atol=1e-13), (name, i)
+            assert torch.allclose(r, rew_seq[i], rtol=1e-12, atol=1e-13)
+        assert torch.allclose(e1.x, e2.x, rtol=1e-13, atol=0)
+        assert torch.equal(e1.done, e2.done)
+        assert torch.allclose(e1.obs_soa, e2.obs_soa, rtol=1e-13, atol=1e-13)
+        e1.close()
+        e2.close()
+
+
+# ------------------------------------------------ full-size property tests ---
+def test_full_size_cstr_properties():
+    """BASELINE.json configs[1] size (B = 2^20): size-independent properties.
+    (1) every env of a batch started from the same state with the same action is bit-identical,
+    (2) a shuffled batch gives the shuffled result (lane independence / no cross-env term),
+    (3) a 4096-env slice matches the oracle, (4) no NaN, done exactly at t == N-1."""
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    B = 1 << 20
+    sc = SC.scenarios()["cstr_canonical"]
+    p = copy.deepcopy(sc["env_params"])
+    p.update(integrator="rk4", substeps=1, tsim=60.0)  # dt = 1.0 model time unit, one RK4 step
+    env = VecEnv(p, n_envs=B)
+    env.reset()
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    x0 = torch.stack([0.7 + 0.3 * torch.rand(B, generator=gen, device="cuda", dtype=torch.float64),
+                      310 + 30 * torch.rand(B, generator=gen, device="cuda", dtype=torch.float64)])
+    env.x.copy_(x0)
+    T = env.N - 1
+    acts = 2 * torch.rand((T, 1, B), generator=gen, device="cuda", dtype=torch.float64) - 1
+    perm = torch.randperm(B, generator=gen, device="cuda")
+    env2 = VecEnv(p, n_envs=B)
+    env2.reset()
+    env2.x.copy_(x0[:, perm])
+    n_or = 4096
+    orc = O.OracleEnv(env.spec, n_or)
+    orc.reset()
+    orc.x[:] = x0[:, :n_or].cpu().numpy()
+    for i in range(T):
+        o, r, d, _, _ = env.step(acts[i])
+        o2, r2, d2, _, _ = env2.step(acts[i][:, perm])
+        oc, rc, dc = orc.step(acts[i][:, :n_or].cpu().numpy())
+        if i % 10 == 0 or i == T - 1:
+            assert torch.equal(env.x[:, perm], env2.x)
+            assert torch.equal(r[perm], r2)
+            assert torch.isfinite(env.x).all() and torch.isfinite(r).all()
+            assert np.max(np.abs(env.x[:, :n_or].cpu().numpy() - orc.x) / np.abs(orc.x)) <= 1e-12
+            assert bool(d.all()) == (i == T - 1) and bool(d.any()) == (i == T - 1)
+    # identical envs stay identical
+    env.reset()
+    env.x[0].fill_(0.8)
+    env.x[1].fill_(330.0)
+    a = torch.full((1, B), 0.3, device="cuda", dtype=torch.float64)
+    for i in range(5):
+        env.step(a)
+    assert (env.x[0] == env.x[0, 0]).all() and (env.x[1] == env.x[1, 0]).all()
+    env.close()
+    env2.close()
+
+
+def test_edge_cases_empty_and_ragged():
+    torch = _torch()
+    import copy
+
+    from pcgym_amd import VecEnv
+
+    sc = SC.scenarios()["cstr_canonical"]
+    for B in (0, 1, 63, 64, 65, 255, 257):
+        env = VecEnv(copy.deepcopy(sc["env_params"]), n_envs=B)
+        o, _ = env.reset()
+        assert o.shape == (B, 3)
+        o, r, d, _, _ = env.step(torch.zeros((1, B), device="cuda", dtype=torch.float64))
+        torch.cuda.synchronize()
+        assert o.shape == (B, 3) and r.shape == (B,)
+        if B:
+            assert torch.isfinite(o).all()
+            assert (o == o[0]).all()
+        env.close()
+
+
+def test_bad_arguments_return_status_not_crash():
+    torch = _torch()
+    from pcgym_amd import _abi as abi
+    from pcgym_amd import _lib
+    from pcgym_amd.config import EnvSpec
+
+    lib = _lib.load()
+    spec = EnvSpec(SC.scenarios()["cstr_canonical"]["env_params"])
+    cfg, keep = spec.to_cfg()
+    plan = C.c_void_p()
+    assert lib.pcg_plan_create(C.byref(plan), C.byref(cfg)) == 0
+    buf = abi.pcg_buffers()
+    buf.B = 16
+    assert lib.pcg_step(plan, C.byref(buf), 0, 0, None) == abi.PCG_E_NULL
+    assert lib.pcg_step(None, C.byref(buf), 0, 0, None) == abi.PCG_E_PLAN
+    cfg.model_id = 99
+    p2 = C.c_void_p()
+    assert lib.pcg_plan_create(C.byref(p2), C.byref(cfg)) == abi.PCG_E_MODEL
+    assert lib.pcg_plan_destroy(plan) == 0
