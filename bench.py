@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=59)
     ap.add_argument("--batch", type=int, default=1 << 20, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--substeps", type=int, default=1,
+                    help="RK4 sub-steps per env step (1 = the headline workload; other values are probes)")
     args = ap.parse_args()
 
     import numpy as np
@@ -159,6 +161,7 @@ def main():
 
     B, K, W = args.batch, args.steps, args.warmup
     params = workload_params(B)
+    params["substeps"] = args.substeps
     # shard: rank r owns global envs [r*B, (r+1)*B)  (weak scaling; RNG streams keyed by global index)
     env = VecEnv(params, n_envs=B, device=dev, seed=1234, auto_reset=True, env_offset=rank * B)
     lib = _lib.load()

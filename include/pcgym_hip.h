@@ -234,6 +234,12 @@ PCG_API int pcg_plan_set_env_offset(pcg_plan* plan, int64_t env_offset);
 #define PCG_OPT_ENV_OFFSET 1  /* same as pcg_plan_set_env_offset                              */
 #define PCG_OPT_LDS_STAGES 2  /* DOPRI5: keep stage vectors k1..k6 in LDS [stage][comp][lane]
                                  (64-thread workgroups) instead of VGPRs; default 0           */
+#define PCG_OPT_VARIANT 3     /* step-kernel selection: 0 auto (default), 1 classic one-env-per-lane
+                                 grid, 2 streaming persistent kernel 1 env/lane, 3 streaming 2 envs/lane
+                                 (16 B per lane accesses); non-auto values are for A/B measurement      */
+#define PCG_OPT_STREAM_BLOCKS_PER_CU 4 /* streaming kernel: resident workgroups per CU (0 = occupancy query) */
+#define PCG_OPT_NT_STORES 5   /* streaming kernel: non-temporal stores for obs / reward (not re-read by the step) */
+#define PCG_OPT_STREAM_UNROLL 6 /* streaming kernel: log2(sub-tiles per workgroup), 0..2 */
 PCG_API int pcg_plan_set_option(pcg_plan* plan, int option, int64_t value);
 
 /* Host-only validation of a cfg: the status pcg_plan_create() would return before it

@@ -335,8 +335,8 @@ class EnvSpec:
         self.rtol = float(p.get("rtol", 1e-8))
         self.atol = float(p.get("atol", 1e-8))
         self.max_steps = int(p.get("max_steps", 100000))
-        if self.substeps < 1:
-            raise ValueError("substeps must be >= 1")
+        if self.substeps < 0:
+            raise ValueError("substeps must be >= 1 (0 = skip the integration: memory-roofline probe only)")
 
         for name, lim in (("nx", abi.PCG_MAX_NX), ("na", abi.PCG_MAX_NA), ("ndm", abi.PCG_MAX_NDM),
                           ("nsp", abi.PCG_MAX_NSP)):

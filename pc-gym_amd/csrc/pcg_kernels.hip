@@ -32,6 +32,33 @@
 #include "pcg_integrators.hpp"
 #include "pcg_models.hpp"
 
+// Optional per-wave timeline instrumentation (tools/timeline.py builds a second .so with
+// -DPCG_TIMELINE): s_memtime stamps at kernel entry / loads landed / arithmetic done / stores issued
+// / stores acknowledged, written for lane 0 of every wave into the `nsteps` debug buffer
+// (8 x uint64 per wave).  Compiled out of the product library.
+#ifdef PCG_TIMELINE
+#define PCG_TL_DECL unsigned long long tl_[6] = {0, 0, 0, 0, 0, 0}
+#define PCG_TL_STAMP(i) tl_[i] = __builtin_amdgcn_s_memtime()
+#define PCG_TL_WAIT_STAMP(i)                      \
+  do {                                            \
+    __builtin_amdgcn_s_waitcnt(0);                \
+    tl_[i] = __builtin_amdgcn_s_memtime();        \
+  } while (0)
+#define PCG_TL_FLUSH(e)                                                                   \
+  do {                                                                                    \
+    if ((threadIdx.x & 63) == 0 && A.nsteps) {                                            \
+      unsigned long long* q = reinterpret_cast<unsigned long long*>(A.nsteps) + ((e) >> 6) * 8; \
+      for (int i_ = 0; i_ < 5; ++i_) q[i_] = tl_[i_];                                     \
+      q[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); /* HW_ID */     \
+    }                                                                                     \
+  } while (0)
+#else
+#define PCG_TL_DECL
+#define PCG_TL_STAMP(i)
+#define PCG_TL_WAIT_STAMP(i)
+#define PCG_TL_FLUSH(e)
+#endif
+
 namespace pcg {
 
 constexpr int BLOCK = 256;      // threads per workgroup (4 waves, one per SIMD)
@@ -86,6 +113,7 @@ struct StepArgs {
   uint64_t seed;
   int32_t t_scalar;
   int32_t sched_in_lds;  // per-env-t kernels: schedules staged in LDS
+  int32_t nt_stores;     // stream kernels: non-temporal stores for obs / reward
   // rollout
   const double* a_seq;
   double* obs_seq;
@@ -184,14 +212,25 @@ PCG_DEV double sched_at(const PCG_CONSTANT double* sched_g, const double* sched_
   return sched_g[(size_t)row * N + idx];
 }
 
+// per-env results of one step, kept in registers so the caller chooses the store width
+template <class M>
+struct EnvOut {
+  double ox[M::NX];          // observation rows of the physical states
+  double osp[PCG_MAX_NSP];   // SP slots
+  double od[PCG_MAX_NDM];    // disturbance slots
+  double rew;
+  bool done, viol;
+};
+
 // ---------------------------------------------------------------------------
 // One env step for the lane's environment.  Statement order follows
-// make_env.step (pcgym.py:350-500).  `x` is the lane's physical state (in/out).
-// Returns through out-params; does all global stores except x itself.
+// make_env.step (pcgym.py:350-500).  `x` is the lane's physical state (in/out);
+// everything the hot path writes comes back in `out` (registers).  Only the rare
+// side outputs (a_save, constraint rows, DOPRI5 step counts) are stored here.
 // ---------------------------------------------------------------------------
 template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS>
 PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, double* stage_l, int64_t e,
-                      int t, const double (&a_in)[M::NA], double (&x)[M::NX], double* obs_out, double* rew_out) {
+                      int t, const double (&a_in)[M::NA], double (&x)[M::NX], EnvOut<M>& out) {
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
   const int64_t B = A.B;
   const uint32_t flags = c.flags;
@@ -284,8 +323,8 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
     done |= violated && (flags & PCG_F_DONE_ON_CONS);
   }
   done |= (t_new == N - 1);  // pcgym.py:448-449
-  A.done[e] = done ? 1 : 0;
-  if (A.viol) A.viol[e] = violated ? 1 : 0;
+  out.done = done;
+  out.viol = violated;
   // ---- reward on the noise-free state (pcgym.py:470-482) ----
   double r = 0.0;
   if (flags & PCG_F_REWARD_BATCH) {  // pcgym.py:502-532
@@ -305,7 +344,7 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
         if ((flags & PCG_F_R_PENALTY) && violated) r -= 1000.0;  // Q4: once per SP key
       }
   }
-  *rew_out = r;
+  out.rew = r;
   // ---- observation: noise (pcgym.py:452-466), normalise (:483-489), mask (:495-498) ----
   double zn[NX];
   if (EXTRAS && (flags & PCG_F_NOISE)) {
@@ -322,16 +361,34 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
     if (i < nx) {
       double o = x[i];
       if (EXTRAS && (flags & PCG_F_NOISE)) o += zn[i] * x[i] * c.noise_pct[i];
-      obs_out[(size_t)i * B] = (o - c.o_lo[i]) * c.o_sc[i] + c.o_off[i];
+      out.ox[i] = (o - c.o_lo[i]) * c.o_sc[i] + c.o_off[i];
     }
 #pragma unroll
   for (int k = 0; k < PCG_MAX_NSP; ++k)
-    if (k < nso) obs_out[(size_t)(nx + k) * B] = (spv[k] - c.o_lo[nx + k]) * c.o_sc[nx + k] + c.o_off[nx + k];
+    if (k < nso) out.osp[k] = (spv[k] - c.o_lo[nx + k]) * c.o_sc[nx + k] + c.o_off[nx + k];
 #pragma unroll
   for (int k = 0; k < PCG_MAX_NDM; ++k)
-    if (k < nd)
-      obs_out[(size_t)(nx + nso + k) * B] =
-          (dv[k] - c.o_lo[nx + nso + k]) * c.o_sc[nx + nso + k] + c.o_off[nx + nso + k];
+    if (k < nd) out.od[k] = (dv[k] - c.o_lo[nx + nso + k]) * c.o_sc[nx + nso + k] + c.o_off[nx + nso + k];
+}
+
+// scalar (8 B per lane) store of one env's outputs; obs_base = &obs[0][e] of the destination
+template <class M>
+PCG_DEV void store_out(const StepArgs& A, CDevConst& c, int64_t e, const EnvOut<M>& out, double* obs_base) {
+  const int64_t B = A.B;
+  const int nx = M::DYNAMIC ? c.nx : M::NX;
+  const int nso = c.nsp_obs, nd = c.nd;
+#pragma unroll
+  for (int i = 0; i < M::NX; ++i)
+    if (i < nx) obs_base[(size_t)i * B] = out.ox[i];
+#pragma unroll
+  for (int k = 0; k < PCG_MAX_NSP; ++k)
+    if (k < nso) obs_base[(size_t)(nx + k) * B] = out.osp[k];
+#pragma unroll
+  for (int k = 0; k < PCG_MAX_NDM; ++k)
+    if (k < nd) obs_base[(size_t)(nx + nso + k) * B] = out.od[k];
+  A.rew[e] = out.rew;
+  A.done[e] = out.done ? 1 : 0;
+  if (A.viol) A.viol[e] = out.viol ? 1 : 0;
 }
 
 // cooperative copy of the schedules into LDS (per-env-t kernels)
@@ -357,18 +414,149 @@ __global__ __launch_bounds__(tb(LDS_STAGES)) void step_kernel(const StepArgs A) 
   const int nx = M::DYNAMIC ? c.nx : NX;
   const int na = M::DYNAMIC ? c.na : NA;
   const int t = PER_ENV_T ? A.t[e] : A.t_scalar;
+  PCG_TL_DECL;
+  PCG_TL_STAMP(0);
   double x[NX], a[NA];
 #pragma unroll
   for (int i = 0; i < NX; ++i) x[i] = (i < nx) ? A.x[(size_t)i * B + e] : 0.0;
 #pragma unroll
   for (int i = 0; i < NA; ++i) a[i] = (i < na) ? A.a[(size_t)i * B + e] : 0.0;
-  double r;
-  env_step<M, INTEG, PER_ENV_T, LDS_STAGES, EXTRAS>(A, c, sched_l, stage_l, e, t, a, x, A.obs + e, &r);
+  PCG_TL_WAIT_STAMP(1);  // loads landed
+  EnvOut<M> out;
+  env_step<M, INTEG, PER_ENV_T, LDS_STAGES, EXTRAS>(A, c, sched_l, stage_l, e, t, a, x, out);
+  PCG_TL_STAMP(2);  // integration + epilogue arithmetic done
 #pragma unroll
   for (int i = 0; i < NX; ++i)
     if (i < nx) A.x[(size_t)i * B + e] = x[i];
-  A.rew[e] = r;
+  store_out<M>(A, c, e, out, A.obs + e);
   if (PER_ENV_T) A.t[e] = t + 1;
+  PCG_TL_STAMP(3);       // stores issued
+  PCG_TL_WAIT_STAMP(4);  // stores acknowledged
+  PCG_TL_FLUSH(e);
+}
+
+// ---------------------------------------------------------------------------
+// Streaming variant for the lean, lock-stepped hot path (BASELINE configs[1]):
+//   * persistent grid (all workgroups resident), grid-stride over tiles of 256*EPL envs;
+//   * EPL = 2 environments per lane -> every global access is 16 B per lane (dwordx4),
+//     1 KiB contiguous per wave-instruction, and the two envs give the VALU two
+//     independent dependency chains through exp/div;
+//   * the loads of tile i+1 are issued before tile i is integrated, so each wave has HBM
+//     reads in flight while it computes, and waves drift out of phase instead of
+//     alternating chip-wide "all load / all compute / all store" rounds.
+// Preconditions (checked on the host): no per-env t, no extras, no a_delta, no per-env d,
+// B % EPL == 0 and 16-byte aligned rows when EPL == 2.
+// ---------------------------------------------------------------------------
+template <int EPL>
+struct Vec;
+template <>
+struct Vec<1> {
+  using T = double;
+  PCG_DEV static double get(const T& v, int) { return v; }
+  PCG_DEV static T make(const double (&s)[1]) { return s[0]; }
+  // streaming store: the data is not re-read by this kernel (obs / reward go to the policy)
+  PCG_DEV static void store_nt(double* p, const double (&s)[1]) { __builtin_nontemporal_store(s[0], p); }
+};
+template <>
+struct Vec<2> {
+  using T = double2;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  PCG_DEV static double get(const T& v, int j) { return j ? v.y : v.x; }
+  PCG_DEV static T make(const double (&s)[2]) { return make_double2(s[0], s[1]); }
+  PCG_DEV static void store_nt(double* p, const double (&s)[2]) {
+    __builtin_nontemporal_store(d2{s[0], s[1]}, reinterpret_cast<d2*>(p));
+  }
+};
+
+template <class M, int INTEG, int EPL, int UNR>
+__global__ __launch_bounds__(BLOCK) void step_kernel_stream(const StepArgs A) {
+  // One workgroup = UNR sub-tiles of 256*EPL envs.  All UNR sub-tiles' inputs are requested up front
+  // (UNR * (NX+NA) loads in flight per lane), then the sub-tiles are integrated and stored one after
+  // the other: the memory system works on sub-tile u+1.. while the VALU integrates sub-tile u, and
+  // results leave as soon as each sub-tile is done instead of in one burst per wave.
+  CDevConst& c = *A.C;
+  constexpr int NX = M::NX, NA = M::NA;
+  using V = typename Vec<EPL>::T;
+  const int64_t B = A.B;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  const int na = M::DYNAMIC ? c.na : NA;
+  const int nso = c.nsp_obs;
+  const int t = A.t_scalar;
+  const bool nt = A.nt_stores != 0;
+  constexpr int64_t SUB = (int64_t)BLOCK * EPL;  // envs per sub-tile
+  const int64_t tile = SUB * UNR;
+  const int64_t ntile = (B + tile - 1) / tile;
+  for (int64_t it = blockIdx.x; it < ntile; it += gridDim.x) {
+    V xv[UNR][NX], av[UNR][NA];
+    bool live[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t e0 = it * tile + u * SUB + (int64_t)threadIdx.x * EPL;
+      live[u] = e0 < B;
+      if (live[u]) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+          if (i < nx) xv[u][i] = *reinterpret_cast<const V*>(A.x + (size_t)i * B + e0);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+          if (i < na) av[u][i] = *reinterpret_cast<const V*>(A.a + (size_t)i * B + e0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t e0 = it * tile + u * SUB + (int64_t)threadIdx.x * EPL;
+      if (!live[u]) continue;
+      EnvOut<M> out[EPL];
+      double xs[EPL][NX];
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        double a[NA];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xs[j][i] = (i < nx) ? Vec<EPL>::get(xv[u][i], j) : 0.0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a[i] = (i < na) ? Vec<EPL>::get(av[u][i], j) : 0.0;
+        env_step<M, INTEG, false, false, false>(A, c, nullptr, nullptr, e0 + j, t, a, xs[j], out[j]);
+      }
+      double tmp[EPL];
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        if (i < nx) {
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) tmp[j] = xs[j][i];
+          *reinterpret_cast<V*>(A.x + (size_t)i * B + e0) = Vec<EPL>::make(tmp);
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) tmp[j] = out[j].ox[i];
+          if (nt) Vec<EPL>::store_nt(A.obs + (size_t)i * B + e0, tmp);
+          else *reinterpret_cast<V*>(A.obs + (size_t)i * B + e0) = Vec<EPL>::make(tmp);
+        }
+#pragma unroll
+      for (int k = 0; k < PCG_MAX_NSP; ++k)
+        if (k < nso) {
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) tmp[j] = out[j].osp[k];
+          if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + k) * B + e0, tmp);
+          else *reinterpret_cast<V*>(A.obs + (size_t)(nx + k) * B + e0) = Vec<EPL>::make(tmp);
+        }
+#pragma unroll
+      for (int k = 0; k < M::NDM; ++k)
+        if (k < c.nd) {
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) tmp[j] = out[j].od[k];
+          if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + nso + k) * B + e0, tmp);
+          else *reinterpret_cast<V*>(A.obs + (size_t)(nx + nso + k) * B + e0) = Vec<EPL>::make(tmp);
+        }
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) tmp[j] = out[j].rew;
+      if (nt) Vec<EPL>::store_nt(A.rew + e0, tmp);
+      else *reinterpret_cast<V*>(A.rew + e0) = Vec<EPL>::make(tmp);
+      if (EPL == 2) {
+        *reinterpret_cast<uint16_t*>(A.done + e0) =
+            (uint16_t)((out[0].done ? 1u : 0u) | (out[EPL - 1].done ? 0x100u : 0u));
+      } else {
+        A.done[e0] = out[0].done ? 1 : 0;
+      }
+    }
+  }
 }
 
 // Open-loop fused rollout: T env steps with x in registers ("next" row f-1).
@@ -391,16 +579,11 @@ __global__ __launch_bounds__(tb(LDS_STAGES)) void rollout_kernel(const StepArgs 
 #pragma unroll
     for (int i = 0; i < NA; ++i) a[i] = (i < na) ? as[(size_t)i * B + e] : 0.0;
     const bool last = (s == A.T - 1);
-    double* obs_dst = A.obs_seq ? A.obs_seq + (size_t)s * nobs * B + e : A.obs + e;
-    double r;
-    env_step<M, INTEG, false, LDS_STAGES, true>(A, c, lds, lds, e, A.t_scalar + s, a, x, obs_dst, &r);
-    if (A.rew_seq) A.rew_seq[(size_t)s * B + e] = r;
-    if (last) {
-      A.rew[e] = r;
-      if (A.obs_seq) {  // also mirror the final observation into io->obs
-        for (int i = 0; i < nobs; ++i) A.obs[(size_t)i * B + e] = obs_dst[(size_t)i * B];
-      }
-    }
+    EnvOut<M> out;
+    env_step<M, INTEG, false, LDS_STAGES, true>(A, c, lds, lds, e, A.t_scalar + s, a, x, out);
+    if (A.rew_seq) A.rew_seq[(size_t)s * B + e] = out.rew;
+    if (A.obs_seq) store_out<M>(A, c, e, out, A.obs_seq + (size_t)s * nobs * B + e);
+    if (last || !A.obs_seq) store_out<M>(A, c, e, out, A.obs + e);  // io->obs/rew/done hold the last step
   }
 #pragma unroll
   for (int i = 0; i < NX; ++i)
@@ -519,6 +702,7 @@ using IntKFn = void (*)(CDevConst*, int64_t, int, double*, const double*, int32_
 
 struct Kernels {
   StepFn step[PCG_INT_COUNT][2][2][2];  // [integrator][per_env_t][lds_stages][extras]
+  StepFn stream[PCG_INT_COUNT][2][3];   // [integrator][EPL-1][log2 UNR]  (entries may be null)
   StepFn rollout[PCG_INT_COUNT][2];  // [integrator][lds_stages]
   RhsKFn rhs;
   IntKFn integ[PCG_INT_COUNT][2];
@@ -546,6 +730,19 @@ Kernels make_kernels() {
   k.step[PCG_INT_DOPRI5][0][1][1] = step_kernel<M, PCG_INT_DOPRI5, false, true, true>;
   k.step[PCG_INT_DOPRI5][1][1][0] = step_kernel<M, PCG_INT_DOPRI5, true, true, false>;
   k.step[PCG_INT_DOPRI5][1][1][1] = step_kernel<M, PCG_INT_DOPRI5, true, true, true>;
+  for (int a = 0; a < PCG_INT_COUNT; ++a)
+    for (int b = 0; b < 2; ++b)
+      for (int u = 0; u < 3; ++u) k.stream[a][b][u] = nullptr;
+  k.stream[PCG_INT_RK4][0][0] = step_kernel_stream<M, PCG_INT_RK4, 1, 1>;
+  k.stream[PCG_INT_DOPRI5][0][0] = step_kernel_stream<M, PCG_INT_DOPRI5, 1, 1>;
+  // several envs per lane / sub-tiles per workgroup only where the per-env register footprint is
+  // small (the HBM-bound models)
+  if constexpr (M::NX <= 4) {
+    k.stream[PCG_INT_RK4][0][1] = step_kernel_stream<M, PCG_INT_RK4, 1, 2>;
+    k.stream[PCG_INT_RK4][0][2] = step_kernel_stream<M, PCG_INT_RK4, 1, 4>;
+    k.stream[PCG_INT_RK4][1][0] = step_kernel_stream<M, PCG_INT_RK4, 2, 1>;
+    k.stream[PCG_INT_RK4][1][1] = step_kernel_stream<M, PCG_INT_RK4, 2, 2>;
+  }
   k.rollout[PCG_INT_RK4][0] = rollout_kernel<M, PCG_INT_RK4, false>;
   k.rollout[PCG_INT_RK4][1] = k.rollout[PCG_INT_RK4][0];
   k.rollout[PCG_INT_DOPRI5][0] = rollout_kernel<M, PCG_INT_DOPRI5, false>;
@@ -591,6 +788,12 @@ struct pcg_plan {
   int device;
   int model_id, integrator_id;
   int lds_stages;
+  int variant;       // PCG_OPT_VARIANT: 0 auto, 1 classic, 2 stream EPL=1, 3 stream EPL=2
+  int stream_bpc;    // PCG_OPT_STREAM_BLOCKS_PER_CU: 0 = occupancy query
+  int nt_stores;     // PCG_OPT_NT_STORES
+  int num_cus;
+  int stream_occ[2][3]; // resident workgroups per CU of the stream kernels (0 = not queried yet)
+  int stream_unr;    // PCG_OPT_STREAM_UNROLL: log2(sub-tiles per workgroup)
   int64_t env_offset;
   DevConst hc;       // host copy
   DevConst* dC;      // device copy
@@ -673,7 +876,7 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   if (nrew < 0 || nrew > PCG_MAX_NX) return PCG_E_DIM;
   if (c->N < 2 || c->N > PCG_MAX_N) return PCG_E_DIM;
   if (!(c->dt > 0.0) || !std::isfinite(c->dt)) return PCG_E_VALUE;
-  if (c->integrator_id == PCG_INT_RK4 && c->substeps < 1) return PCG_E_VALUE;
+  if (c->integrator_id == PCG_INT_RK4 && c->substeps < 0) return PCG_E_VALUE;  // 0 = no integration (I/O probe)
   if (c->integrator_id == PCG_INT_DOPRI5 && (!(c->rtol > 0) || !(c->atol >= 0) || c->max_steps < 1))
     return PCG_E_VALUE;
   const int nobs = nx + nso + nd, cnu = na + ndm;
@@ -796,10 +999,17 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   p->model_id = cfg->model_id;
   p->integrator_id = cfg->integrator_id;
   p->lds_stages = 0;
+  p->variant = 0;
+  p->stream_bpc = 0;
+  p->nt_stores = 0;
+  p->num_cus = 0;
+  for (auto& r : p->stream_occ) for (int& v : r) v = 0;
+  p->stream_unr = 0;
   p->env_offset = 0;
   p->dC = nullptr;
   p->dsched = nullptr;
   hipError_t e = hipGetDevice(&p->device);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&p->num_cus, hipDeviceAttributeMultiprocessorCount, p->device);
   if (e != hipSuccess) { delete p; return (int)e; }
   const int rows = cfg->nsp + cfg->nd;
   p->sched_bytes = sizeof(double) * (size_t)(rows > 0 ? rows : 1) * cfg->N;
@@ -844,6 +1054,13 @@ int pcg_plan_set_option(pcg_plan* p, int option, int64_t value) {
   switch (option) {
     case PCG_OPT_ENV_OFFSET: p->env_offset = value; return PCG_OK;
     case PCG_OPT_LDS_STAGES: p->lds_stages = value ? 1 : 0; return PCG_OK;
+    case PCG_OPT_STREAM_BLOCKS_PER_CU: p->stream_bpc = (int)value; return PCG_OK;
+    case PCG_OPT_NT_STORES: p->nt_stores = value ? 1 : 0; return PCG_OK;
+    case PCG_OPT_STREAM_UNROLL: p->stream_unr = (int)value; return PCG_OK;
+    case PCG_OPT_VARIANT:
+      if (value < 0 || value > 3) return PCG_E_VALUE;
+      p->variant = (int)value;
+      return PCG_OK;
     default: return PCG_E_VALUE;
   }
 }
@@ -880,10 +1097,10 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   StepArgs a;
   int rc = fill_args(p, io, &a);
   if (rc != PCG_OK) return rc;
+  if (io->B == 0) return PCG_OK;  // empty batch: nothing to do (zero-size buffers may be NULL)
   if (!io->x || !io->a || !io->obs || !io->rew || !io->done) return PCG_E_NULL;
   const DevConst& c = p->hc;
   if ((c.flags & PCG_F_A_DELTA) && !io->a_save) return PCG_E_NULL;
-  if (io->B == 0) return PCG_OK;
   a.t_scalar = t;
   a.seed = seed;
   const bool per_env_t = io->t != nullptr;
@@ -900,6 +1117,32 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   }
   // lean variant when no noise / Gaussian disturbance / constraint work is configured
   const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST)) || c.ncon > 0;
+  // streaming (persistent, prefetching, 16 B/lane) kernel for the lean lock-stepped path
+  if (!per_env_t && !extras && !lds_st && !io->viol && p->variant != 1) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    const bool epl2_ok = k.stream[p->integrator_id][1] && (io->B % 2 == 0) && al16(io->x) && al16(io->a) &&
+                         al16(io->obs) && al16(io->rew) && (reinterpret_cast<uintptr_t>(io->done) & 1u) == 0;
+    int epl = (p->variant == 2) ? 1 : (epl2_ok ? 2 : 1);
+    if (p->variant == 3 && !epl2_ok) return PCG_E_UNSUPPORTED;
+    int lu = p->stream_unr;  // log2(sub-tiles per workgroup)
+    if (lu < 0 || lu > 2 || !k.stream[p->integrator_id][epl - 1][lu]) lu = 0;
+    StepFn sfn = k.stream[p->integrator_id][epl - 1][lu];
+    int& occ = p->stream_occ[epl - 1][lu];
+    if (occ == 0) {
+      int nb = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)sfn, BLOCK, 0));
+      occ = nb > 0 ? nb : 1;
+    }
+    const int64_t tile_envs = (int64_t)BLOCK * epl * (1 << lu);
+    const int64_t ntile = (io->B + tile_envs - 1) / tile_envs;
+    int bpc = occ;
+    if (p->stream_bpc > 0 && p->stream_bpc < bpc) bpc = p->stream_bpc;
+    int64_t grid = (int64_t)p->num_cus * bpc;
+    if (grid > ntile) grid = ntile;
+    a.nt_stores = p->nt_stores;
+    hipLaunchKernelGGL(sfn, dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
   StepFn fn = k.step[p->integrator_id][per_env_t ? 1 : 0][lds_st ? 1 : 0][extras ? 1 : 0];
   if (shmem > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -912,12 +1155,12 @@ int pcg_rollout(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t T, const
   StepArgs a;
   int rc = fill_args(p, io, &a);
   if (rc != PCG_OK) return rc;
-  if (!io->x || !a_seq || !io->obs || !io->rew || !io->done) return PCG_E_NULL;
   if (io->t) return PCG_E_UNSUPPORTED;  // lock-stepped only
   if (T < 1) return PCG_E_VALUE;
+  if (io->B == 0) return PCG_OK;
+  if (!io->x || !a_seq || !io->obs || !io->rew || !io->done) return PCG_E_NULL;
   const DevConst& c = p->hc;
   if ((c.flags & PCG_F_A_DELTA) && !io->a_save) return PCG_E_NULL;
-  if (io->B == 0) return PCG_OK;
   a.t_scalar = t0;
   a.seed = seed;
   a.T = T;
@@ -939,8 +1182,8 @@ int pcg_reset(pcg_plan* p, const pcg_buffers* io, const uint8_t* mask, uint64_t 
   StepArgs a;
   int rc = fill_args(p, io, &a);
   if (rc != PCG_OK) return rc;
-  if (!io->x || !io->obs) return PCG_E_NULL;
   if (io->B == 0) return PCG_OK;
+  if (!io->x || !io->obs) return PCG_E_NULL;
   a.mask = mask;
   a.seed = seed;
   hipLaunchKernelGGL(reset_kernel, dim3(grid_for(io->B)), dim3(BLOCK), 0, (hipStream_t)stream, a);

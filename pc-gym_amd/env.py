@@ -14,6 +14,7 @@ There is no CPU path: constructing an env without the HIP library / a GPU raises
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -46,7 +47,7 @@ class VecEnv:
     """
 
     def __init__(self, env_params, n_envs=1, device=None, seed=0, per_env_t=False, auto_reset=False,
-                 env_offset=0, lds_stages=False):
+                 env_offset=0, lds_stages=False, variant=None):
         self.spec = s = EnvSpec(env_params)
         self.env_params = s.env_params
         if s.custom_reward is not None and not getattr(self, "_allow_custom_reward", False):
@@ -98,6 +99,15 @@ class VecEnv:
         _lib.check(self._lib.pcg_plan_set_env_offset(plan, int(env_offset)), "pcg_plan_set_env_offset")
         if lds_stages:
             _lib.check(self._lib.pcg_plan_set_option(plan, abi.PCG_OPT_LDS_STAGES, 1), "pcg_plan_set_option")
+        if variant is None:
+            variant = int(os.environ.get("PCG_VARIANT", "0"))  # A/B switch for measurements
+        if variant:
+            _lib.check(self._lib.pcg_plan_set_option(plan, abi.PCG_OPT_VARIANT, int(variant)),
+                       "pcg_plan_set_option")
+        for key, opt in (("PCG_BPC", abi.PCG_OPT_STREAM_BLOCKS_PER_CU), ("PCG_NT", abi.PCG_OPT_NT_STORES),
+                         ("PCG_UNR", abi.PCG_OPT_STREAM_UNROLL)):
+            if os.environ.get(key):  # measurement switches
+                _lib.check(self._lib.pcg_plan_set_option(plan, opt, int(os.environ[key])), "pcg_plan_set_option")
 
         B, dev, f64 = self.B, self.device, torch.float64
         self.x = torch.zeros((s.nx, B), dtype=f64, device=dev)
