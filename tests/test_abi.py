@@ -1,0 +1,132 @@
+"""CPU: the C ABI -- header <-> python mirror, exported symbols, host-side validation."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import scenarios as SC
+from pcgym_amd import _abi as abi
+from pcgym_amd import _lib
+from pcgym_amd import models as M
+from pcgym_amd.config import EnvSpec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = open(os.path.join(ROOT, "include", "pcgym_hip.h")).read()
+
+
+def test_defines_match_header():
+    for name, val in re.findall(r"#define (PCG_[A-Z0-9_]+) (-?(?:0x)?[0-9A-Fa-f]+)u?\b", HDR):
+        if name in ("PCG_API",):
+            continue
+        assert hasattr(abi, name), name
+        assert getattr(abi, name) == int(val, 0), name
+
+
+def test_enums_match_header():
+    ids = dict(re.findall(r"(PCG_MODEL_[A-Z_]+) = (\d+)", HDR))
+    assert int(ids["PCG_MODEL_CSTR"]) == M.CSTR and int(ids["PCG_MODEL_FOUR_TANK"]) == M.FOUR_TANK
+    assert int(ids["PCG_MODEL_ME"]) == M.ME and int(ids["PCG_MODEL_ME_REACTIVE"]) == M.ME_REACTIVE
+    assert int(ids["PCG_MODEL_CRYST"]) == M.CRYST and int(ids["PCG_MODEL_AFFINE"]) == M.AFFINE
+    ints = dict(re.findall(r"(PCG_INT_[A-Z0-9]+) = (\d+)", HDR))
+    assert int(ints["PCG_INT_RK4"]) == abi.PCG_INT_RK4 and int(ints["PCG_INT_DOPRI5"]) == abi.PCG_INT_DOPRI5
+
+
+def _struct_fields(name):
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), HDR, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(",")
+        first = names[0].split()
+        out.append(first[-1].lstrip("*"))
+        out += [n.strip().lstrip("*") for n in names[1:]]
+    return out
+
+
+def test_struct_field_order_matches_header():
+    assert _struct_fields("pcg_env_cfg") == [f[0] for f in abi.pcg_env_cfg._fields_]
+    assert _struct_fields("pcg_buffers") == [f[0] for f in abi.pcg_buffers._fields_]
+
+
+def test_library_exports_every_declared_symbol():
+    declared = set(re.findall(r"PCG_API [\w\s\*]+?\b(pcg_\w+)\(", HDR))
+    assert declared == set(abi.EXPORTS), declared ^ set(abi.EXPORTS)
+    lib = _lib.load()  # loads without a GPU (no HIP call is made)
+    for s in abi.EXPORTS:
+        assert getattr(lib, s) is not None
+    assert lib.pcg_version() == abi.PCG_ABI_VERSION
+    assert b"NULL" in lib.pcg_strerror(abi.PCG_E_NULL)
+
+
+def test_model_metadata_and_default_params_agree_with_host_registry():
+    lib = _lib.load()
+    for name in M.model_names():
+        mi = M.get_model(name)
+        nx, nu, ndm, npar = (C.c_int32() for _ in range(4))
+        assert lib.pcg_model_info(mi.model_id, nx, nu, ndm, npar) == 0
+        assert (nx.value, nu.value, ndm.value) == (len(mi.states), len(mi.inputs), len(mi.disturbances))
+        buf = (C.c_double * npar.value)()
+        assert lib.pcg_model_default_params(mi.model_id, buf, npar.value) == 0
+        assert list(buf) == mi.param_vector()
+    assert lib.pcg_model_info(99, None, None, None, None) == abi.PCG_E_MODEL
+
+
+@pytest.mark.parametrize("name", sorted(SC.scenarios()))
+def test_cfg_validate_accepts_all_scenarios(name):
+    lib = _lib.load()
+    cfg, keep = EnvSpec(SC.scenarios()[name]["env_params"]).to_cfg()
+    assert lib.pcg_cfg_validate(C.byref(cfg)) == 0
+
+
+def test_cfg_validate_rejects_bad_input():
+    lib = _lib.load()
+    base = SC.scenarios()["cstr_canonical"]["env_params"]
+    cfg, keep = EnvSpec(base).to_cfg()
+    assert lib.pcg_cfg_validate(None) == abi.PCG_E_NULL
+    for field, val, code in [("model_id", 77, abi.PCG_E_MODEL), ("integrator_id", 5, abi.PCG_E_MODEL),
+                             ("nx", 3, abi.PCG_E_DIM), ("N", 1, abi.PCG_E_DIM), ("dt", -1.0, abi.PCG_E_VALUE),
+                             ("nsp", 9, abi.PCG_E_DIM), ("n_params", 3, abi.PCG_E_DIM)]:
+        c2, k2 = EnvSpec(base).to_cfg()
+        setattr(c2, field, val)
+        assert lib.pcg_cfg_validate(C.byref(c2)) == code, field
+    c2, k2 = EnvSpec(base).to_cfg()
+    c2.o_low = None
+    assert lib.pcg_cfg_validate(C.byref(c2)) == abi.PCG_E_NULL
+    c2, k2 = EnvSpec(base).to_cfg()
+    bad = np.array([0], dtype=np.int32)
+    bad[0] = 7
+    c2.sp_index = bad.ctypes.data_as(C.POINTER(C.c_int32))
+    assert lib.pcg_cfg_validate(C.byref(c2)) == abi.PCG_E_DIM
+
+
+def test_philox_host_entry_matches_random123():
+    lib = _lib.load()
+
+    def ph(ctr, key):
+        c = (C.c_uint32 * 4)(*ctr)
+        k = (C.c_uint32 * 2)(*key)
+        o = (C.c_uint32 * 4)()
+        lib.pcg_philox4x32_10(c, k, o)
+        return list(o)
+
+    assert ph([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert ph([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """the product must refuse to run without a GPU: no CPU path exists"""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pcgym_amd import make_env
+
+    with pytest.raises(RuntimeError, match="no CPU"):
+        make_env(SC.scenarios()["cstr_quickstart"]["env_params"])

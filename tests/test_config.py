@@ -1,0 +1,178 @@
+"""CPU: host logic -- env_params parsing mirrors the reference make_env.__init__ (pcgym.py:32-253)."""
+import copy
+
+import numpy as np
+import pytest
+
+import scenarios as SC
+from pcgym_amd import _abi as abi
+from pcgym_amd.config import EnvSpec, default_substeps, probe_affine
+from pcgym_amd import models as M
+
+
+def P(name):
+    return copy.deepcopy(SC.scenarios()[name]["env_params"])
+
+
+def test_not_a_dict_raises_like_reference():
+    with pytest.raises(ValueError, match="env_params must be a dictionary"):  # pcgym.py:40-41
+        EnvSpec([1, 2])
+
+
+def test_unknown_model_raises_like_reference():
+    p = P("cstr_canonical")
+    p["model"] = "nope"
+    with pytest.raises(ValueError, match="not found in model_mapping"):  # pcgym.py:157
+        EnvSpec(p)
+    p["model"] = "biofilm_reactor"
+    with pytest.raises(ValueError, match="no HIP kernel"):
+        EnvSpec(p)
+
+
+def test_dimensions_follow_reference_bookkeeping():
+    s = EnvSpec(P("cstr_quickstart"))
+    assert (s.nx, s.na, s.nsp, s.nobs, s.nu, s.nd, s.ndm) == (2, 1, 1, 3, 1, 0, 0)
+    assert s.dt == 25 / 100 and s.N == 100
+    assert s.normalise_a and s.normalise_o and not s.a_delta  # defaults pcgym.py:59-60
+    s = EnvSpec(P("cstr_dist_both"))
+    # Nu += len(model disturbances); Nx += len(disturbances) (pcgym.py:176-178)
+    assert (s.nu, s.nd, s.ndm, s.nobs) == (3, 2, 2, 5)
+    # slots follow the MODEL's disturbance order (Ti, Caf), not the dict order (Caf, Ti)
+    assert s.d_keys == ["Ti", "Caf"] and list(s.d_slot) == [0, 1]
+    assert np.allclose(s.d_default, [350.0, 1.0])
+    s = EnvSpec(P("cstr_dist_Ti"))
+    assert (s.nu, s.nd, s.ndm) == (3, 1, 2) and list(s.d_slot) == [0]
+    s = EnvSpec(P("me_dist_cons"))
+    assert s.d_keys == ["X0"] and s.nobs == 12 and s.ncon == 2
+
+
+def test_flags():
+    s = EnvSpec(P("cryst_adelta"))
+    f = s.flags()
+    assert f & abi.PCG_F_A_DELTA and f & abi.PCG_F_NORMALISE_A and f & abi.PCG_F_REF_COMPAT
+    assert not (f & abi.PCG_F_REWARD_BATCH)
+    p = P("cryst_adelta")
+    p["normalise_a"] = False  # the reference only accumulates when normalise_a is on (pcgym.py:376)
+    assert not (EnvSpec(p).flags() & abi.PCG_F_A_DELTA)
+    f = EnvSpec(P("cstr_batch_reward")).flags()
+    assert f & abi.PCG_F_REWARD_BATCH and not (f & abi.PCG_F_MAXIMISE)
+
+
+def test_batch_reward_indices_follow_reward_states_order():
+    s = EnvSpec(P("cstr_batch_reward"))
+    assert list(s.rew_index) == [0, 1] and np.allclose(s.r_scale, [1.0, 0.01])
+
+
+def test_constraint_callable_is_probed_into_affine_rows():
+    s = EnvSpec(P("cstr_cons_pen_raw"))
+    # cons = [319 - x[1], x[1] - 331]
+    A = np.zeros((2, s.nobs + s.nu))
+    A[0, 1], A[1, 1] = -1, 1
+    assert np.allclose(s.con_A, A) and np.allclose(s.con_b, [-319, 331])
+    s = EnvSpec(P("cstr_cons_done_raw"))  # rows mixing states and the input
+    assert s.con_A.shape == (3, 4) and s.con_A[1, 3] == -1 and np.isclose(s.con_b[1], -295.2)
+    assert np.allclose(s.con_A[2], [0.5, 0.001, 0, 0]) and np.isclose(s.con_b[2], 0.8)
+
+
+def test_nonaffine_callables_are_rejected_loudly():
+    p = P("cstr_cons_pen_raw")
+    p["constraints"] = lambda x, u: np.array([x[1] ** 2 - 1e5])
+    with pytest.raises(ValueError, match="not affine"):
+        EnvSpec(p)
+    p["constraints"] = lambda x, u: np.array([np.log(x[0])])
+    with pytest.raises(ValueError, match="not affine"):
+        EnvSpec(p)
+
+
+def test_declarative_constraints():
+    p = P("cstr_cons_pen_raw")
+    p["constraints"] = {"A": [[0, 1, 0, 0]], "b": [331.0]}
+    s = EnvSpec(p)
+    assert s.ncon == 1 and s.con_A.shape == (1, 4)
+
+
+def test_custom_affine_model_is_recovered_exactly():
+    s = EnvSpec(P("custom_linear_kat"))
+    assert s.model.model_id == M.AFFINE
+    A, B, c = s.affine_AB
+    assert np.array_equal(A, [[1.5, 0], [0, 2.5]]) and np.array_equal(B, [[1.0], [0.0]]) and np.array_equal(c, [0, 0])
+    assert s.nsp_obs == 0 and s.nobs == 2  # x0 without the SP slot: the reference drops it silently
+
+
+def test_probe_affine_exact_on_affine_maps():
+    rng = np.random.default_rng(0)
+    A0, c0 = rng.normal(size=(3, 5)), rng.normal(size=3)
+    A, c = probe_affine(lambda x, u: A0 @ np.concatenate([x, u]) + c0, [3, 2], [rng.normal(size=5)], "t")
+    assert np.allclose(A, A0, atol=1e-15) and np.allclose(c, c0, atol=1e-15)
+
+
+def test_registry_shaped_custom_model_reuses_kernel_with_its_parameters():
+    class cstr:  # same name and states as the registry model -> cstr kernel, user's parameter values
+        def __init__(self):
+            self.int_method = "casadi"
+
+        def __call__(self, x, u):
+            raise AssertionError("never evaluated on the host")
+
+        def info(self):
+            d = M.get_model("cstr").info()
+            d["parameters"]["UA"] = 6e4
+            return d
+
+    p = P("cstr_canonical")
+    del p["model"]
+    p["custom_model"] = cstr()
+    s = EnvSpec(p)
+    assert s.model.model_id == M.CSTR and s.model.parameters["UA"] == 6e4
+
+
+def test_integrator_selection():
+    assert EnvSpec(P("cstr_canonical")).integrator == "rk4"
+    assert EnvSpec(P("cstr_canonical")).substeps == 4          # dt = 26/60
+    assert EnvSpec(P("me_canonical")).integrator == "dopri5"   # stiff: adaptive by default
+    p = P("cstr_canonical")
+    p["integration_method"] = "jax"                            # reference's adaptive 5(4) path
+    s = EnvSpec(p)
+    assert s.integrator == "dopri5" and s.rtol == 1e-8 and s.atol == 1e-8  # integrator.py:61
+    p["integration_method"] = "scipy"
+    with pytest.raises(ValueError):
+        EnvSpec(p)
+    assert default_substeps(M.CSTR, 1.0) == 10 and default_substeps(M.CRYST, 1.0) == 32
+
+
+def test_shape_errors():
+    p = P("cstr_canonical")
+    p["x0"] = np.array([0.8, 330, 0.8, 1.0])
+    with pytest.raises(ValueError, match="x0"):
+        EnvSpec(p)
+    p = P("cstr_canonical")
+    p["o_space"] = {"low": np.zeros(2), "high": np.ones(2)}
+    with pytest.raises(ValueError, match="o_space"):
+        EnvSpec(p)
+    p = P("cstr_dist_Ti")
+    p["disturbances"] = {"bogus": np.zeros(60)}
+    with pytest.raises(ValueError, match="not an input"):
+        EnvSpec(p)
+    p = P("cstr_canonical")
+    p["uncertainty_percentages"] = {"q": 0.1}
+    with pytest.raises(ValueError, match="not built yet"):
+        EnvSpec(p)
+
+
+def test_reference_broadcast_error_is_reproduced():
+    """normalise_a + disturbances + constraints with na>1 raises in the reference itself
+    (pcgym.py:597-600); we raise the same kind of error instead of inventing semantics."""
+    p = P("me_dist_cons")
+    p["normalise_a"] = True
+    with pytest.raises(ValueError, match="broadcast"):
+        EnvSpec(p)
+    p["reference_compat"] = False
+    EnvSpec(p)
+
+
+def test_cfg_marshalling_roundtrip():
+    s = EnvSpec(P("cstr_dist_both"))
+    cfg, keep = s.to_cfg()
+    assert (cfg.nx, cfg.na, cfg.ndm, cfg.nd, cfg.nsp, cfg.nsp_obs, cfg.N) == (2, 1, 2, 2, 1, 1, 60)
+    assert np.allclose(np.ctypeslib.as_array(cfg.o_low, (5,)), s.o_low)
+    assert np.allclose(np.ctypeslib.as_array(cfg.d_sched, (2 * 60,)).reshape(2, 60), s.d_sched)
