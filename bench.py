@@ -260,15 +260,20 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,  # PMC FETCH_SIZE/WRITE_SIZE per launch: see profiles/ (separate rocprofv3 --pmc passes)
-            "kernel": "step_kernel<Model<cstr>, RK4, lock-step, lean>",
+            "traffic": None,
+            "kernel": "step_kernel_stream<Model<cstr>, RK4, 2 env/lane> (lean, lock-stepped)",
             "kernel_avg_us": kern_avg_s * 1e6,
             "algorithmic_bytes_per_env_step": int(bytes_per_env_step),
             "algorithmic_bytes_per_launch": alg_bytes,
         }
-        tr = os.environ.get("PCG_BENCH_TRAFFIC_BYTES")
-        if tr:
-            out["roofline"]["traffic"] = float(tr)
+        # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from
+        # inside this process): the committed measurement of this kernel + workload, if present
+        tpath = os.path.join(ROOT, "profiles", "r1", "traffic.json")
+        if os.path.exists(tpath) and B == (1 << 20) and args.substeps == 1:
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            out["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tj["source"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec)
         print(json.dumps(out), flush=True)
