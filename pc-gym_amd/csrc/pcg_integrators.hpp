@@ -18,9 +18,9 @@
 
 namespace pcg {
 
-template <int NX, class F>
-PCG_DEV void rk4(const F& f, double (&x)[NX], double h, int nsub) {
-  double k[NX], acc[NX], y[NX];
+template <int NX, class F, class R>
+PCG_DEV void rk4(const F& f, R (&x)[NX], double h, int nsub) {
+  R k[NX], acc[NX], y[NX];
   const double h2 = 0.5 * h, h6 = h / 6.0;
   for (int s = 0; s < nsub; ++s) {
     f(x, k);
@@ -32,18 +32,18 @@ PCG_DEV void rk4(const F& f, double (&x)[NX], double h, int nsub) {
     f(y, k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      acc[i] += 2.0 * k[i];
+      acc[i] = acc[i] + 2.0 * k[i];
       y[i] = x[i] + h2 * k[i];
     }
     f(y, k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      acc[i] += 2.0 * k[i];
+      acc[i] = acc[i] + 2.0 * k[i];
       y[i] = x[i] + h * k[i];
     }
     f(y, k);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] += h6 * (acc[i] + k[i]);
+    for (int i = 0; i < NX; ++i) x[i] = x[i] + h6 * (acc[i] + k[i]);
   }
 }
 

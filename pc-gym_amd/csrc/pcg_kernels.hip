@@ -198,11 +198,11 @@ PCG_DEV double pick(const double (&v)[N], int idx) {
   return r;
 }
 
-template <class M>
+template <class M, class R = double>
 struct RhsFn {
   typename M::CKP& kp;
-  const typename M::Hold& hold;
-  PCG_DEV void operator()(const double (&x)[M::NX], double (&dx)[M::NX]) const { M::rhs(kp, hold, x, dx); }
+  const typename M::template HoldT<R>& hold;
+  PCG_DEV void operator()(const R (&x)[M::NX], R (&dx)[M::NX]) const { M::rhs(kp, hold, x, dx); }
 };
 
 // constraint rows g = A.[x|sp|d|u] - b  (affine form of the reference's callable, pcgym.py:560-577);
@@ -475,6 +475,81 @@ __global__ __launch_bounds__(tb(LDS_STAGES)) void step_kernel(const StepArgs A) 
 // Preconditions (checked on the host): no per-env t, no extras, no a_delta, no per-env d,
 // B % EPL == 0 and 16-byte aligned rows when EPL == 2.
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// Lean env step for W envs per lane (Pack<W>): the hot path of BASELINE configs[1].
+// Same statements as env_step with everything the lean plan cannot contain removed (a_delta,
+// per-env / Gaussian disturbances, noise, constraints, terminal reward); the lock-stepped batch makes
+// the SP / disturbance slots, `done` and all schedule values wave-uniform scalars.
+// ---------------------------------------------------------------------------
+template <int NX, int W>
+PCG_DEV Pack<W> pick(const Pack<W> (&v)[NX], int idx) {
+  Pack<W> r(0.0);
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+#pragma unroll
+    for (int j = 0; j < W; ++j) r.v[j] = (i == idx) ? v[i].v[j] : r.v[j];
+  return r;
+}
+
+template <class M, int W>
+struct LeanOut {
+  Pack<W> ox[M::NX];
+  Pack<W> rew;
+  double osp[PCG_MAX_NSP];  // wave-uniform
+  double od[PCG_MAX_NDM];   // wave-uniform
+  bool done;                // wave-uniform
+};
+
+template <class M, int W>
+PCG_DEV void env_step_lean(const StepArgs& A, CDevConst& c, int t, const Pack<W> (&a_in)[M::NA],
+                           Pack<W> (&x)[M::NX], LeanOut<M, W>& out) {
+  constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
+  using R = Pack<W>;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  const int na = M::DYNAMIC ? c.na : NA;
+  const int N = c.N, nsp = c.nsp, nso = c.nsp_obs, nd = c.nd;
+  const int tn = min(t + 1, N - 1), tc = min(t, N - 1);
+  typename M::CKP& kp = *(typename M::CKP*)(M::DYNAMIC ? c.kp_big : c.kp);
+  // action map (pcgym.py:371-375) and held disturbance inputs (pcgym.py:386-404)
+  R u[NA + NDM];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+    u[i] = (i < na) ? (a_in[i] + c.amap[i].pre) * c.amap[i].scale + c.amap[i].off : R(0.0);
+  double ud[NDM > 0 ? NDM : 1];
+#pragma unroll
+  for (int j = 0; j < NDM; ++j) ud[j] = c.d_default[j];
+#pragma unroll
+  for (int k = 0; k < NDM; ++k)
+    if (k < nd) {
+      const double v = A.sched[(size_t)(nsp + k) * N + tn];  // Q6: index t+1
+      out.od[k] = (v - c.omap[nx + nso + k].lo) * c.omap[nx + nso + k].sc + c.omap[nx + nso + k].off;
+      const int slot = c.d_slot[k];
+#pragma unroll
+      for (int j = 0; j < NDM; ++j) ud[j] = (j == slot) ? v : ud[j];
+    }
+#pragma unroll
+  for (int j = 0; j < NDM; ++j) u[NA + j] = R(ud[j]);
+  // integrate over [0,dt] with the input held (integrator.py:163-182)
+  const typename M::template HoldT<R> hold = M::template hold<R>(kp, u);
+  const RhsFn<M, R> f{kp, hold};
+  rk4<NX>(f, x, c.h, c.substeps);
+  // SP slot = SP[t_old] (Q5), reward against SP[t_new] (pcgym.py:432-441, 535-558)
+  R r(0.0);
+#pragma unroll
+  for (int k = 0; k < PCG_MAX_NSP; ++k)
+    if (k < nsp) {
+      const double spv = A.sched[(size_t)k * N + tc], spn = A.sched[(size_t)k * N + tn];
+      if (k < nso) out.osp[k] = (spv - c.omap[nx + k].lo) * c.omap[nx + k].sc + c.omap[nx + k].off;
+      const R dd = pick<NX, W>(x, c.sp_index[k]) - spn;
+      r = r + (-(dd * dd)) * c.r_scale[k];
+    }
+  out.rew = r;
+  out.done = (t + 1 == N - 1);  // pcgym.py:448-449
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    if (i < nx) out.ox[i] = (x[i] - c.omap[i].lo) * c.omap[i].sc + c.omap[i].off;
+}
+
 template <int EPL>
 struct Vec;
 template <>
@@ -554,6 +629,48 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_stream(const StepArgs A) {
     for (int u = 0; u < UNR; ++u) {
       const int64_t e0 = it * tile + u * SUB + (int64_t)threadIdx.x * EPL;
       if (!live[u]) continue;
+      if constexpr (INTEG == PCG_INT_RK4) {
+        // W = EPL envs advance together through one instruction stream (independent chains -> ILP)
+        Pack<EPL> xs[NX], as[NA];
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) xs[i].v[j] = (i < nx) ? Vec<EPL>::get(xv[u][i], j) : 0.0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) as[i].v[j] = (i < na) ? Vec<EPL>::get(av[u][i], j) : 0.0;
+        LeanOut<M, EPL> out;
+        env_step_lean<M, EPL>(A, c, t, as, xs, out);
+        double tmp[EPL];
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+          if (i < nx) {
+            *reinterpret_cast<V*>(A.x + (size_t)i * B + e0) = Vec<EPL>::make(xs[i].v);
+            if (nt) Vec<EPL>::store_nt(A.obs + (size_t)i * B + e0, out.ox[i].v);
+            else *reinterpret_cast<V*>(A.obs + (size_t)i * B + e0) = Vec<EPL>::make(out.ox[i].v);
+          }
+#pragma unroll
+        for (int k = 0; k < PCG_MAX_NSP; ++k)
+          if (k < nso) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) tmp[j] = out.osp[k];
+            if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + k) * B + e0, tmp);
+            else *reinterpret_cast<V*>(A.obs + (size_t)(nx + k) * B + e0) = Vec<EPL>::make(tmp);
+          }
+#pragma unroll
+        for (int k = 0; k < M::NDM; ++k)
+          if (k < c.nd) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) tmp[j] = out.od[k];
+            if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + nso + k) * B + e0, tmp);
+            else *reinterpret_cast<V*>(A.obs + (size_t)(nx + nso + k) * B + e0) = Vec<EPL>::make(tmp);
+          }
+        if (nt) Vec<EPL>::store_nt(A.rew + e0, out.rew.v);
+        else *reinterpret_cast<V*>(A.rew + e0) = Vec<EPL>::make(out.rew.v);
+        if (EPL == 2) *reinterpret_cast<uint16_t*>(A.done + e0) = out.done ? (uint16_t)0x0101u : (uint16_t)0;
+        else A.done[e0] = out.done ? 1 : 0;
+      } else {
       EnvOut<M> out[EPL];
       double xs[EPL][NX];
 #pragma unroll
@@ -603,7 +720,110 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_stream(const StepArgs A) {
       } else {
         A.done[e0] = out[0].done ? 1 : 0;
       }
+      }  // INTEG
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Software-pipelined persistent variant of the lean kernel (PCG_OPT_VARIANT 4): each wave walks
+// over its tiles and always has the NEXT tile's inputs in flight while it integrates the current one.
+//   loop:  land(cur)            -- the only wait: cur's loads (issued one iteration ago) + previous stores
+//          issue loads(next)
+//          integrate(cur)       -- no memory operation inside the lean step
+//          issue stores(cur)    -- never waited for explicitly
+// The `land` placement matters: loads and stores share one in-order-per-kind counter (vmcnt), so the
+// compiler can only wait with vmcnt(0) once stores are pending; waiting BEFORE the prefetch is issued
+// keeps the prefetch out of that wait.
+// ---------------------------------------------------------------------------
+template <class M, int EPL>
+__global__ __launch_bounds__(BLOCK) void step_kernel_pipe(const StepArgs A) {
+  CDevConst& c = *A.C;
+  constexpr int NX = M::NX, NA = M::NA;
+  using V = typename Vec<EPL>::T;
+  const int64_t B = A.B;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  const int na = M::DYNAMIC ? c.na : NA;
+  const int nso = c.nsp_obs;
+  const int t = A.t_scalar;
+  const bool nt = A.nt_stores != 0;
+  constexpr int64_t TILE = (int64_t)BLOCK * EPL;
+  const int64_t ntile = (B + TILE - 1) / TILE;
+  int64_t it = blockIdx.x;
+  if (it >= ntile) return;
+  V xv[NX], av[NA];
+  int64_t e0 = it * TILE + (int64_t)threadIdx.x * EPL;
+  bool live = e0 < B;
+  auto load = [&](int64_t ee, V (&xd)[NX], V (&ad)[NA]) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      if (i < nx) xd[i] = *reinterpret_cast<const V*>(A.x + (size_t)i * B + ee);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (i < na) ad[i] = *reinterpret_cast<const V*>(A.a + (size_t)i * B + ee);
+  };
+  if (live) load(e0, xv, av);
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) land(xv[i]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) land(av[i]);
+    const int64_t itn = it + gridDim.x;
+    const int64_t e1 = itn * TILE + (int64_t)threadIdx.x * EPL;
+    const bool live_n = (itn < ntile) && (e1 < B);
+    V xn[NX], an[NA];
+    asm volatile("" ::: "memory");
+    if (live_n) load(e1, xn, an);
+    asm volatile("" ::: "memory");
+    if (live) {
+      Pack<EPL> xs[NX], as[NA];
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) xs[i].v[j] = (i < nx) ? Vec<EPL>::get(xv[i], j) : 0.0;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) as[i].v[j] = (i < na) ? Vec<EPL>::get(av[i], j) : 0.0;
+      LeanOut<M, EPL> out;
+      env_step_lean<M, EPL>(A, c, t, as, xs, out);
+      double tmp[EPL];
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        if (i < nx) {
+          *reinterpret_cast<V*>(A.x + (size_t)i * B + e0) = Vec<EPL>::make(xs[i].v);
+          if (nt) Vec<EPL>::store_nt(A.obs + (size_t)i * B + e0, out.ox[i].v);
+          else *reinterpret_cast<V*>(A.obs + (size_t)i * B + e0) = Vec<EPL>::make(out.ox[i].v);
+        }
+#pragma unroll
+      for (int k = 0; k < PCG_MAX_NSP; ++k)
+        if (k < nso) {
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) tmp[j] = out.osp[k];
+          if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + k) * B + e0, tmp);
+          else *reinterpret_cast<V*>(A.obs + (size_t)(nx + k) * B + e0) = Vec<EPL>::make(tmp);
+        }
+#pragma unroll
+      for (int k = 0; k < M::NDM; ++k)
+        if (k < c.nd) {
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) tmp[j] = out.od[k];
+          if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + nso + k) * B + e0, tmp);
+          else *reinterpret_cast<V*>(A.obs + (size_t)(nx + nso + k) * B + e0) = Vec<EPL>::make(tmp);
+        }
+      if (nt) Vec<EPL>::store_nt(A.rew + e0, out.rew.v);
+      else *reinterpret_cast<V*>(A.rew + e0) = Vec<EPL>::make(out.rew.v);
+      if (EPL == 2) *reinterpret_cast<uint16_t*>(A.done + e0) = out.done ? (uint16_t)0x0101u : (uint16_t)0;
+      else A.done[e0] = out.done ? 1 : 0;
+    }
+    if (itn >= ntile) break;
+    it = itn;
+    e0 = e1;
+    live = live_n;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xv[i] = xn[i];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) av[i] = an[i];
   }
 }
 
@@ -751,6 +971,7 @@ using IntKFn = void (*)(CDevConst*, int64_t, int, double*, const double*, int32_
 struct Kernels {
   StepFn step[PCG_INT_COUNT][2][2][2];  // [integrator][per_env_t][lds_stages][extras]
   StepFn stream[PCG_INT_COUNT][2][3];   // [integrator][EPL-1][log2 UNR]  (entries may be null)
+  StepFn pipe[2];                    // RK4 software-pipelined lean kernel [EPL-1] (may be null)
   StepFn rollout[PCG_INT_COUNT][2];  // [integrator][lds_stages]
   RhsKFn rhs;
   IntKFn integ[PCG_INT_COUNT][2];
@@ -781,6 +1002,11 @@ Kernels make_kernels() {
   for (int a = 0; a < PCG_INT_COUNT; ++a)
     for (int b = 0; b < 2; ++b)
       for (int u = 0; u < 3; ++u) k.stream[a][b][u] = nullptr;
+  k.pipe[0] = k.pipe[1] = nullptr;
+  if constexpr (M::NX <= 4) {
+    k.pipe[0] = step_kernel_pipe<M, 1>;
+    k.pipe[1] = step_kernel_pipe<M, 2>;
+  }
   k.stream[PCG_INT_RK4][0][0] = step_kernel_stream<M, PCG_INT_RK4, 1, 1>;
   k.stream[PCG_INT_DOPRI5][0][0] = step_kernel_stream<M, PCG_INT_DOPRI5, 1, 1>;
   // several envs per lane / sub-tiles per workgroup only where the per-env register footprint is
@@ -843,6 +1069,7 @@ struct pcg_plan {
   int num_cus;
   int stream_occ[2][3]; // resident workgroups per CU of the stream kernels (0 = not queried yet)
   int stream_unr;    // PCG_OPT_STREAM_UNROLL: log2(sub-tiles per workgroup)
+  int pipe_occ[2];
   int64_t env_offset;
   DevConst hc;       // host copy
   DevConst* dC;      // device copy
@@ -1055,6 +1282,7 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   p->num_cus = 0;
   for (auto& r : p->stream_occ) for (int& v : r) v = 0;
   p->stream_unr = 0;
+  p->pipe_occ[0] = p->pipe_occ[1] = 0;
   p->env_offset = 0;
   p->dC = nullptr;
   p->dsched = nullptr;
@@ -1109,7 +1337,7 @@ int pcg_plan_set_option(pcg_plan* p, int option, int64_t value) {
     case PCG_OPT_STREAM_UNROLL: p->stream_unr = (int)value; return PCG_OK;
     case PCG_OPT_PRIO_STAGGER: p->prio_mode = (int)value; return PCG_OK;
     case PCG_OPT_VARIANT:
-      if (value < 0 || value > 3) return PCG_E_VALUE;
+      if (value < 0 || value > 4) return PCG_E_VALUE;
       p->variant = (int)value;
       return PCG_OK;
     default: return PCG_E_VALUE;
@@ -1181,10 +1409,26 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
     int lu = p->stream_unr;  // log2(sub-tiles per workgroup)
     if (lu < 0 || lu > 2 || !k.stream[p->integrator_id][epl - 1][lu]) lu = 0;
     StepFn sfn = k.stream[p->integrator_id][epl - 1][lu];
-    int& occ = p->stream_occ[epl - 1][lu];
+    // auto (0): the software-pipelined kernel where it exists (measured best on the cstr workload:
+    // 14.9 us vs 15.0 two-sub-tile streaming vs 16.9 plain streaming vs 21 classic, profiles/r1)
+    const bool piped = (p->variant == 4 || p->variant == 0) && p->integrator_id == PCG_INT_RK4 && k.pipe[epl - 1];
+    if (piped) {
+      sfn = k.pipe[epl - 1];
+      lu = 0;
+    }
+    int& occ = piped ? p->pipe_occ[epl - 1] : p->stream_occ[epl - 1][lu];
     if (occ == 0) {
+      // resident 256-thread workgroups per CU = waves per SIMD.  The occupancy API over-reports by one for
+      // some register counts on ROCm 7.2 (MI355X_MICROARCH.md "Residency"), and a persistent grid with a
+      // non-resident workgroup serialises a whole extra round: bound it by the VGPR allocation too.
       int nb = 0;
       HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)sfn, BLOCK, 0));
+      hipFuncAttributes fa;
+      HIP_TRY(hipFuncGetAttributes(&fa, (const void*)sfn));
+      const int alloc = ((fa.numRegs + 7) / 8) * 8;
+      const int by_vgpr = alloc > 0 ? 512 / alloc : 8;
+      if (nb > by_vgpr) nb = by_vgpr;
+      if (nb > 8) nb = 8;
       occ = nb > 0 ? nb : 1;
     }
     const int64_t tile_envs = (int64_t)BLOCK * epl * (1 << lu);

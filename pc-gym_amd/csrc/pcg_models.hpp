@@ -12,8 +12,16 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/pcgym_hip.h"
+#include "pcg_pack.hpp"
 
 namespace pcg {
+
+// model code is written once for R = double (one env per lane) and R = Pack<W> (W envs per lane);
+// bring the scalar math functions into this namespace next to the Pack overloads
+using ::exp;
+using ::fabs;
+using ::pow;
+using ::sqrt;
 
 #define PCG_DEV __device__ __forceinline__
 // Plan constants are read through the CONSTANT address space (AMDGPU addrspace 4): a load with a
@@ -37,9 +45,11 @@ struct Model<PCG_MODEL_CSTR> {
     double qV, c1, c2, k0, nEAR;
   };
   using CKP = const PCG_CONSTANT KP;
-  struct Hold {
-    double Tc, Ti, Caf;
+  template <class R>
+  struct HoldT {
+    R Tc, Ti, Caf;
   };
+  using Hold = HoldT<double>;
   static void prep(const double* r, int /*nx*/, int /*nu*/, double* kp_out, double* ddef) {
     KP k;
     k.qV = r[0] / r[1];
@@ -51,10 +61,14 @@ struct Model<PCG_MODEL_CSTR> {
     ddef[0] = r[8];
     ddef[1] = r[9];
   }
-  PCG_DEV static Hold hold(CKP&, const double (&u)[NA + NDM]) { return Hold{u[0], u[1], u[2]}; }
-  PCG_DEV static void rhs(CKP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
-    const double ca = x[0], T = x[1];
-    const double rA = k.k0 * exp(k.nEAR / T) * ca;
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[0], u[1], u[2]};
+  }
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+    const R ca = x[0], T = x[1];
+    const R rA = k.k0 * exp(k.nEAR / T) * ca;
     dx[0] = k.qV * (h.Caf - ca) - rA;
     dx[1] = k.qV * (h.Ti - T) + k.c1 * rA + k.c2 * (h.Tc - T);
   }
@@ -74,9 +88,11 @@ struct Model<PCG_MODEL_FOUR_TANK> {
     double p1, p2, p3, p4;  // pump gains
   };
   using CKP = const PCG_CONSTANT KP;
-  struct Hold {
-    double q1, q2, q3, q4;  // pump inflow terms, constant over the step
+  template <class R>
+  struct HoldT {
+    R q1, q2, q3, q4;  // pump inflow terms, constant over the step
   };
+  using Hold = HoldT<double>;
   static void prep(const double* r, int, int, double* kp_out, double*) {
     KP k;
     k.g2 = 2 * r[0];
@@ -92,12 +108,14 @@ struct Model<PCG_MODEL_FOUR_TANK> {
     k.p4 = ((1 - r[1]) * r[3]) / r[12];
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  PCG_DEV static Hold hold(CKP& k, const double (&u)[NA + NDM]) {
-    return Hold{k.p1 * u[0], k.p2 * u[1], k.p3 * u[1], k.p4 * u[0]};
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP& k, const R (&u)[NA + NDM]) {
+    return HoldT<R>{k.p1 * u[0], k.p2 * u[1], k.p3 * u[1], k.p4 * u[0]};
   }
-  PCG_DEV static void rhs(CKP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
-    const double s1 = sqrt(k.g2 * x[0]), s2 = sqrt(k.g2 * x[1]);
-    const double s3 = sqrt(k.g2 * x[2]), s4 = sqrt(k.g2 * x[3]);
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+    const R s1 = sqrt(k.g2 * x[0]), s2 = sqrt(k.g2 * x[1]);
+    const R s3 = sqrt(k.g2 * x[2]), s4 = sqrt(k.g2 * x[3]);
     dx[0] = -k.o1 * s1 + k.i31 * s3 + h.q1;
     dx[1] = -k.o2 * s2 + k.i42 * s4 + h.q2;
     dx[2] = -k.o3 * s3 + h.q3;
@@ -108,7 +126,8 @@ struct Model<PCG_MODEL_FOUR_TANK> {
 // Y^e/m for the extraction models: e == 2 (the reference default,
 // model_classes.py:365) is the hot case and is a multiply; any other exponent
 // goes through pow().  `sq` is wave-uniform.
-PCG_DEV double eq_curve(double Y, double e, double inv_m, bool sq) {
+template <class R>
+PCG_DEV R eq_curve(const R& Y, double e, double inv_m, bool sq) {
   return (sq ? Y * Y : pow(Y, e)) * inv_m;
 }
 
@@ -124,9 +143,11 @@ struct Model<PCG_MODEL_ME> {
     double iVl, iVg, inv_m, KlaVl, e, sq;
   };
   using CKP = const PCG_CONSTANT KP;
-  struct Hold {
-    double L, G, X0, Y6;
+  template <class R>
+  struct HoldT {
+    R L, G, X0, Y6;
   };
+  using Hold = HoldT<double>;
   static void prep(const double* r, int, int, double* kp_out, double* ddef) {
     KP k;
     k.iVl = 1 / r[0];
@@ -139,15 +160,19 @@ struct Model<PCG_MODEL_ME> {
     ddef[0] = r[5];
     ddef[1] = r[6];
   }
-  PCG_DEV static Hold hold(CKP&, const double (&u)[NA + NDM]) { return Hold{u[0], u[1], u[2], u[3]}; }
-  PCG_DEV static void rhs(CKP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[0], u[1], u[2], u[3]};
+  }
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const bool sq = k.sq != 0.0;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
-      const double X = x[2 * s], Y = x[2 * s + 1];
-      const double Q = k.KlaVl * (X - eq_curve(Y, k.e, k.inv_m, sq));
-      const double Xp = (s == 0) ? h.X0 : x[2 * s - 2];
-      const double Yn = (s == 4) ? h.Y6 : x[2 * s + 3];
+      const R X = x[2 * s], Y = x[2 * s + 1];
+      const R Q = k.KlaVl * (X - eq_curve(Y, k.e, k.inv_m, sq));
+      const R Xp = (s == 0) ? h.X0 : x[2 * s - 2];
+      const R Yn = (s == 4) ? h.Y6 : x[2 * s + 3];
       dx[2 * s] = k.iVl * (h.L * (Xp - X) - Q);
       dx[2 * s + 1] = k.iVg * (h.G * (Yn - Y) + Q);
     }
@@ -166,9 +191,11 @@ struct Model<PCG_MODEL_ME_REACTIVE> {
     double iVl, iVg, inv_m, KlaVl, kVg, e, sq, XA0, YA6, YB6, YC6;
   };
   using CKP = const PCG_CONSTANT KP;
-  struct Hold {
-    double L, G;
+  template <class R>
+  struct HoldT {
+    R L, G;
   };
+  using Hold = HoldT<double>;
   static void prep(const double* r, int, int, double* kp_out, double*) {
     KP k;
     k.iVl = 1 / r[0];
@@ -184,18 +211,22 @@ struct Model<PCG_MODEL_ME_REACTIVE> {
     k.YC6 = r[9];
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  PCG_DEV static Hold hold(CKP&, const double (&u)[NA + NDM]) { return Hold{u[0], u[1]}; }
-  PCG_DEV static void rhs(CKP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[0], u[1]};
+  }
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const bool sq = k.sq != 0.0;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
-      const double XA = x[4 * s], YA = x[4 * s + 1], YB = x[4 * s + 2], YC = x[4 * s + 3];
-      const double Q = k.KlaVl * (XA - eq_curve(YA, k.e, k.inv_m, sq));
-      const double rV = k.kVg * YA * YB;  // r * Vg
-      const double XAp = (s == 0) ? k.XA0 : x[4 * s - 4];
-      const double YAn = (s == 4) ? k.YA6 : x[4 * s + 5];
-      const double YBn = (s == 4) ? k.YB6 : x[4 * s + 6];
-      const double YCn = (s == 4) ? k.YC6 : x[4 * s + 7];
+      const R XA = x[4 * s], YA = x[4 * s + 1], YB = x[4 * s + 2], YC = x[4 * s + 3];
+      const R Q = k.KlaVl * (XA - eq_curve(YA, k.e, k.inv_m, sq));
+      const R rV = k.kVg * YA * YB;  // r * Vg
+      const R XAp = (s == 0) ? R(k.XA0) : x[4 * s - 4];
+      const R YAn = (s == 4) ? R(k.YA6) : x[4 * s + 5];
+      const R YBn = (s == 4) ? R(k.YB6) : x[4 * s + 6];
+      const R YCn = (s == 4) ? R(k.YC6) : x[4 * s + 7];
       dx[4 * s + 0] = k.iVl * (h.L * (XAp - XA) - Q);
       dx[4 * s + 1] = k.iVg * (h.G * (YAn - YA) + Q - rV);
       dx[4 * s + 2] = k.iVg * (h.G * (YBn - YB) - rV);
@@ -218,9 +249,11 @@ struct Model<PCG_MODEL_CRYST> {
     double ka, kb, kc2, kd2, kg, k1, k22, a, b, cc;  // kc2 = kc/2 ..., cc = -0.5*ro*alfa
   };
   using CKP = const PCG_CONSTANT KP;
-  struct Hold {
-    double Ceq, eB, eG;  // eB = ka*exp(kb/Tk), eG = kg*exp(k1/Tk)
+  template <class R>
+  struct HoldT {
+    R Ceq, eB, eG;  // eB = ka*exp(kb/Tk), eG = kg*exp(k1/Tk)
   };
+  using Hold = HoldT<double>;
   static void prep(const double* r, int, int, double* kp_out, double*) {
     KP k;
     k.ka = r[0];
@@ -235,34 +268,36 @@ struct Model<PCG_MODEL_CRYST> {
     k.cc = -0.5 * r[10] * r[9];
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  PCG_DEV static Hold hold(CKP& k, const double (&u)[NA + NDM]) {
-    const double Tk = u[0] + 273.15;
-    Hold h;
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP& k, const R (&u)[NA + NDM]) {
+    const R Tk = u[0] + 273.15;
+    HoldT<R> h;
     h.Ceq = -686.2686 + 3.579165 * Tk - 0.00292874 * (Tk * Tk);
     h.eB = k.ka * exp(k.kb / Tk);
     h.eG = k.kg * exp(k.k1 / Tk);
     return h;
   }
-  PCG_DEV static void rhs(CKP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
-    const double mu0 = x[0], mu1 = x[1], mu2 = x[2], mu3 = x[3], conc = x[4];
-    const double S = conc * 1e3 - h.Ceq;
-    const double S2 = S * S;
-    const double B0 = h.eB * pow(S2, k.kc2) * pow(mu3 * mu3, k.kd2);
-    const double Ginf = h.eG * pow(S2, k.k22);
-    const double m12 = k.a * mu1 * 1e-4 + k.b * mu2 * 1e-8;
-    const double m23 = k.a * mu2 * 1e-8 + k.b * mu3 * 1e-12;
-    const double d0 = B0;
-    const double d1 = Ginf * (k.a * mu0 + k.b * mu1 * 1e-4) * 1e4;
-    const double d2 = 2 * Ginf * m12 * 1e8;
-    const double d3 = 3 * Ginf * m23 * 1e12;
-    const double mu1sq = mu1 * mu1;
-    const double CV = sqrt(mu2 * mu0 / mu1sq - 1);
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+    const R mu0 = x[0], mu1 = x[1], mu2 = x[2], mu3 = x[3], conc = x[4];
+    const R S = conc * 1e3 - h.Ceq;
+    const R S2 = S * S;
+    const R B0 = h.eB * pow(S2, k.kc2) * pow(mu3 * mu3, k.kd2);
+    const R Ginf = h.eG * pow(S2, k.k22);
+    const R m12 = k.a * mu1 * 1e-4 + k.b * mu2 * 1e-8;
+    const R m23 = k.a * mu2 * 1e-8 + k.b * mu3 * 1e-12;
+    const R d0 = B0;
+    const R d1 = Ginf * (k.a * mu0 + k.b * mu1 * 1e-4) * 1e4;
+    const R d2 = 2.0 * Ginf * m12 * 1e8;
+    const R d3 = 3.0 * Ginf * m23 * 1e12;
+    const R mu1sq = mu1 * mu1;
+    const R CV = sqrt(mu2 * mu0 / mu1sq - 1.0);
     dx[0] = d0;
     dx[1] = d1;
     dx[2] = d2;
     dx[3] = d3;
     dx[4] = k.cc * Ginf * m23;
-    dx[5] = 1 / (2 * CV + 1e-10) * ((d2 * mu0 + mu2 * d0) * mu1sq - mu2 * mu0 * 2 * mu1 * d1) /
+    dx[5] = 1.0 / (2.0 * CV + 1e-10) * ((d2 * mu0 + mu2 * d0) * mu1sq - mu2 * mu0 * 2.0 * mu1 * d1) /
             (mu1sq * mu1sq + 1e-10);
     dx[6] = (d1 * mu0 - mu1 * d0) / (mu0 * mu0 + 1e-10);
   }
@@ -282,9 +317,11 @@ struct Model<PCG_MODEL_AFFINE> {
     double A[8][8], Bm[8][4], c[8];
   };
   using CKP = const PCG_CONSTANT KP;
-  struct Hold {
-    double f[8];  // B u + c
+  template <class R>
+  struct HoldT {
+    R f[8];  // B u + c
   };
+  using Hold = HoldT<double>;
   static void prep(const double* r, int nx, int nu, double* kp_out, double*) {
     KP k;
     __builtin_memset(&k, 0, sizeof(k));
@@ -295,23 +332,25 @@ struct Model<PCG_MODEL_AFFINE> {
     }
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  PCG_DEV static Hold hold(CKP& k, const double (&u)[NA + NDM]) {
-    Hold h;
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP& k, const R (&u)[NA + NDM]) {
+    HoldT<R> h;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      double s = k.c[i];
+      R s = k.c[i];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s += k.Bm[i][j] * u[j];
+      for (int j = 0; j < 4; ++j) s = s + k.Bm[i][j] * u[j];
       h.f[i] = s;
     }
     return h;
   }
-  PCG_DEV static void rhs(CKP& k, const Hold& h, const double (&x)[NX], double (&dx)[NX]) {
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      double s = h.f[i];
+      R s = h.f[i];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += k.A[i][j] * x[j];
+      for (int j = 0; j < 8; ++j) s = s + k.A[i][j] * x[j];
       dx[i] = s;
     }
   }
