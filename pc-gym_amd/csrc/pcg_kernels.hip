@@ -1402,7 +1402,7 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   // streaming (persistent, prefetching, 16 B/lane) kernel for the lean lock-stepped path
   if (!per_env_t && !extras && !lds_st && !io->viol && p->variant != 1) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    const bool epl2_ok = k.stream[p->integrator_id][1] && (io->B % 2 == 0) && al16(io->x) && al16(io->a) &&
+    const bool epl2_ok = k.stream[p->integrator_id][1][0] && (io->B % 2 == 0) && al16(io->x) && al16(io->a) &&
                          al16(io->obs) && al16(io->rew) && (reinterpret_cast<uintptr_t>(io->done) & 1u) == 0;
     int epl = (p->variant == 2) ? 1 : (epl2_ok ? 2 : 1);
     if (p->variant == 3 && !epl2_ok) return PCG_E_UNSUPPORTED;
