@@ -65,6 +65,18 @@ struct LdsStages {
   static constexpr size_t bytes() { return sizeof(double) * 6 * NX * THREADS; }
 };
 
+// 1/x by hardware reciprocal estimate + two Newton steps (full double precision to ~1 ulp, no
+// special-case handling: callers guarantee a finite, positive, normal x)
+PCG_DEV double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+// E^(-1/5) for the step-size controller: exp(-0.2 log E) instead of pow() -- a third of the
+// instructions; the factor only steers h, it never enters the solution directly
+PCG_DEV double pow_neg_fifth(double E) { return exp(-0.2 * log(E)); }
+
 template <int NX>
 PCG_DEV double rms_scaled(const double (&v)[NX], const double (&y0)[NX], const double (&y1)[NX], int n,
                           double rtol, double atol) {
@@ -72,7 +84,7 @@ PCG_DEV double rms_scaled(const double (&v)[NX], const double (&y0)[NX], const d
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     const double sc = atol + rtol * fmax(fabs(y0[i]), fabs(y1[i]));
-    const double r = v[i] / sc;
+    const double r = v[i] * fast_rcp(sc);  // sc > 0; ~1 ulp reciprocal: 6 instructions instead of the 11 of an IEEE divide
     s += (i < n) ? r * r : 0.0;
   }
   return sqrt(s / n);
@@ -111,7 +123,7 @@ PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double 
     for (int i = 0; i < NX; ++i) w[i] -= kk[i];
     const double d2 = rms_scaled<NX>(w, x, x, n, rtol, atol) / h0;
     const double dm = fmax(d1, d2);
-    const double h1 = (dm <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / dm, 0.2);
+    const double h1 = (dm <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow_neg_fifth(dm * 100.0);
     h = fmin(fmin(100.0 * h0, h1), dt);
   }
   double t = 0.0;
@@ -166,7 +178,7 @@ PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double 
                   e6 * K.get(5, i) + e7 * kk[i]);
     const double E = rms_scaled<NX>(w, x, y, n, rtol, atol);
     if (E < 1.0) {
-      double fac = (E == 0.0) ? 10.0 : fmin(10.0, fmax(0.2, 0.9 * pow(E, -0.2)));
+      double fac = (E == 0.0) ? 10.0 : fmin(10.0, fmax(0.2, 0.9 * pow_neg_fifth(E)));
       if (rejected_last && fac > 1.0) fac = 1.0;
       t += h;
       h *= fac;
@@ -179,7 +191,7 @@ PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double 
       ++acc;
       if (last) break;
     } else {
-      double fac = (E == E) ? fmax(0.2, 0.9 * pow(E, -0.2)) : 0.2;  // NaN -> hardest shrink
+      double fac = (E == E) ? fmax(0.2, 0.9 * pow_neg_fifth(E)) : 0.2;  // NaN -> hardest shrink
       if (fac > 1.0) fac = 1.0;
       h *= fac;
       rejected_last = true;

@@ -59,11 +59,21 @@
 #define PCG_TL_FLUSH(e)
 #endif
 
+#ifndef PCG_LEAN_WPE
+#define PCG_LEAN_WPE 1  // min waves per SIMD requested from the register allocator for the lean kernels
+#endif
+
 namespace pcg {
 
 constexpr int BLOCK = 256;      // threads per workgroup (4 waves, one per SIMD)
 constexpr int BLOCK_LDS = 64;   // LDS-staged DOPRI5: 6*NX*8 B of stage storage per lane
 constexpr int tb(bool lds_stages) { return lds_stages ? BLOCK_LDS : BLOCK; }
+// Minimum waves per SIMD asked of the register allocator.  DOPRI5 with <= 10 states needs ~280 registers
+// when left alone (1 wave/SIMD, latency-bound: measured 14k cycles per attempted step against ~3.6k of
+// issue); capping it at 256 costs a few spills and doubles the resident waves.
+constexpr int wpe(int nx, int integ, bool lds_stages) {
+  return (integ == PCG_INT_DOPRI5 && !lds_stages && nx <= 10) ? 2 : 1;
+}
 constexpr int KNU = PCG_MAX_NA + PCG_MAX_NDM;                      // kernel-side u width
 constexpr int CON_W = PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + KNU; // padded constraint row
 
@@ -428,7 +438,7 @@ PCG_DEV void stage_schedules(const StepArgs& A, CDevConst& c, double* sched_l) {
 }
 
 template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS>
-__global__ __launch_bounds__(tb(LDS_STAGES)) void step_kernel(const StepArgs A) {
+__global__ __launch_bounds__(tb(LDS_STAGES), wpe(M::NX, INTEG, LDS_STAGES)) void step_kernel(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA;
@@ -578,7 +588,8 @@ PCG_DEV void land(double2& v) {
 }
 
 template <class M, int INTEG, int EPL, int UNR>
-__global__ __launch_bounds__(BLOCK) void step_kernel_stream(const StepArgs A) {
+__global__ __launch_bounds__(BLOCK, (PCG_LEAN_WPE > wpe(M::NX, INTEG, false) ? PCG_LEAN_WPE : wpe(M::NX, INTEG, false)))
+void step_kernel_stream(const StepArgs A) {
   // One workgroup = UNR sub-tiles of 256*EPL envs.  All UNR sub-tiles' inputs are requested up front
   // (UNR * (NX+NA) loads in flight per lane), then the sub-tiles are integrated and stored one after
   // the other: the memory system works on sub-tile u+1.. while the VALU integrates sub-tile u, and
@@ -737,7 +748,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_stream(const StepArgs A) {
 // keeps the prefetch out of that wait.
 // ---------------------------------------------------------------------------
 template <class M, int EPL>
-__global__ __launch_bounds__(BLOCK) void step_kernel_pipe(const StepArgs A) {
+__global__ __launch_bounds__(BLOCK, PCG_LEAN_WPE) void step_kernel_pipe(const StepArgs A) {
   CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA;
   using V = typename Vec<EPL>::T;
@@ -825,6 +836,99 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_pipe(const StepArgs A) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) av[i] = an[i];
   }
+}
+
+// Lean fused rollout: T lock-stepped env steps, W envs per lane, state in registers throughout;
+// per step only the action row(s) are read and reward (+ observation rows, if requested) written.
+template <class M, int EPL>
+__global__ __launch_bounds__(BLOCK) void rollout_kernel_lean(const StepArgs A) {
+  CDevConst& c = *A.C;
+  constexpr int NX = M::NX, NA = M::NA;
+  using V = typename Vec<EPL>::T;
+  const int64_t B = A.B;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  const int na = M::DYNAMIC ? c.na : NA;
+  const int nso = c.nsp_obs, nobs = c.nobs;
+  const int64_t e0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * EPL;
+  if (e0 >= B) return;
+  Pack<EPL> xs[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    V v;
+    if (i < nx) v = *reinterpret_cast<const V*>(A.x + (size_t)i * B + e0);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) xs[i].v[j] = (i < nx) ? Vec<EPL>::get(v, j) : 0.0;
+  }
+  V an[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+    if (i < na) an[i] = *reinterpret_cast<const V*>(A.a_seq + (size_t)i * B + e0);
+  LeanOut<M, EPL> out;
+  for (int s = 0; s < A.T; ++s) {
+    Pack<EPL> as[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      land(an[i]);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) as[i].v[j] = (i < na) ? Vec<EPL>::get(an[i], j) : 0.0;
+    }
+    asm volatile("" ::: "memory");
+    if (s + 1 < A.T) {  // next step's action in flight during this step's integration
+      const double* nxt = A.a_seq + (size_t)(s + 1) * na * B;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        if (i < na) an[i] = *reinterpret_cast<const V*>(nxt + (size_t)i * B + e0);
+    }
+    asm volatile("" ::: "memory");
+    env_step_lean<M, EPL>(A, c, A.t_scalar + s, as, xs, out);
+    if (A.rew_seq) Vec<EPL>::store_nt(A.rew_seq + (size_t)s * B + e0, out.rew.v);
+    if (A.obs_seq) {
+      double* o = A.obs_seq + (size_t)s * nobs * B + e0;
+      double tmp[EPL];
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        if (i < nx) Vec<EPL>::store_nt(o + (size_t)i * B, out.ox[i].v);
+#pragma unroll
+      for (int k = 0; k < PCG_MAX_NSP; ++k)
+        if (k < nso) {
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) tmp[j] = out.osp[k];
+          Vec<EPL>::store_nt(o + (size_t)(nx + k) * B, tmp);
+        }
+#pragma unroll
+      for (int k = 0; k < M::NDM; ++k)
+        if (k < c.nd) {
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) tmp[j] = out.od[k];
+          Vec<EPL>::store_nt(o + (size_t)(nx + nso + k) * B, tmp);
+        }
+    }
+  }
+  // final state and the last step's outputs into the regular per-step buffers
+  double tmp[EPL];
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    if (i < nx) {
+      *reinterpret_cast<V*>(A.x + (size_t)i * B + e0) = Vec<EPL>::make(xs[i].v);
+      *reinterpret_cast<V*>(A.obs + (size_t)i * B + e0) = Vec<EPL>::make(out.ox[i].v);
+    }
+#pragma unroll
+  for (int k = 0; k < PCG_MAX_NSP; ++k)
+    if (k < nso) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) tmp[j] = out.osp[k];
+      *reinterpret_cast<V*>(A.obs + (size_t)(nx + k) * B + e0) = Vec<EPL>::make(tmp);
+    }
+#pragma unroll
+  for (int k = 0; k < M::NDM; ++k)
+    if (k < c.nd) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) tmp[j] = out.od[k];
+      *reinterpret_cast<V*>(A.obs + (size_t)(nx + nso + k) * B + e0) = Vec<EPL>::make(tmp);
+    }
+  *reinterpret_cast<V*>(A.rew + e0) = Vec<EPL>::make(out.rew.v);
+  if (EPL == 2) *reinterpret_cast<uint16_t*>(A.done + e0) = out.done ? (uint16_t)0x0101u : (uint16_t)0;
+  else A.done[e0] = out.done ? 1 : 0;
 }
 
 // Open-loop fused rollout: T env steps with x in registers ("next" row f-1).
@@ -972,6 +1076,7 @@ struct Kernels {
   StepFn step[PCG_INT_COUNT][2][2][2];  // [integrator][per_env_t][lds_stages][extras]
   StepFn stream[PCG_INT_COUNT][2][3];   // [integrator][EPL-1][log2 UNR]  (entries may be null)
   StepFn pipe[2];                    // RK4 software-pipelined lean kernel [EPL-1] (may be null)
+  StepFn roll_lean[2];               // RK4 lean fused rollout [EPL-1] (may be null)
   StepFn rollout[PCG_INT_COUNT][2];  // [integrator][lds_stages]
   RhsKFn rhs;
   IntKFn integ[PCG_INT_COUNT][2];
@@ -1003,6 +1108,9 @@ Kernels make_kernels() {
     for (int b = 0; b < 2; ++b)
       for (int u = 0; u < 3; ++u) k.stream[a][b][u] = nullptr;
   k.pipe[0] = k.pipe[1] = nullptr;
+  k.roll_lean[0] = rollout_kernel_lean<M, 1>;
+  k.roll_lean[1] = nullptr;
+  if constexpr (M::NX <= 4) k.roll_lean[1] = rollout_kernel_lean<M, 2>;
   if constexpr (M::NX <= 4) {
     k.pipe[0] = step_kernel_pipe<M, 1>;
     k.pipe[1] = step_kernel_pipe<M, 2>;
@@ -1467,6 +1575,17 @@ int pcg_rollout(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t T, const
   a.rew_seq = rew_seq;
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5;
   const Kernels& k = kernels(p->model_id);
+  const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH)) ||
+                      c.ncon > 0 || io->d != nullptr;
+  if (!extras && p->integrator_id == PCG_INT_RK4 && !io->viol && p->variant != 1) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    const bool e2 = k.roll_lean[1] && (io->B % 2 == 0) && al16(io->x) && al16(a_seq) && al16(io->obs) &&
+                    al16(io->rew) && (!obs_seq || al16(obs_seq)) && (!rew_seq || al16(rew_seq)) &&
+                    (reinterpret_cast<uintptr_t>(io->done) & 1u) == 0;
+    const int epl = e2 ? 2 : 1;
+    hipLaunchKernelGGL(k.roll_lean[epl - 1], dim3(grid_for(io->B, BLOCK * epl)), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
   const int block = tb(lds_st);
   const size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
   StepFn fn = k.rollout[p->integrator_id][lds_st ? 1 : 0];

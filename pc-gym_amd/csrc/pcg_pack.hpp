@@ -72,6 +72,7 @@ PCG_PK Pack<W>& operator+=(Pack<W>& a, const Pack<W>& b) {
     return r;                                                        \
   }
 PCG_PACK_FN1(exp)
+PCG_PACK_FN1(log)
 PCG_PACK_FN1(sqrt)
 PCG_PACK_FN1(fabs)
 #undef PCG_PACK_FN1

@@ -29,7 +29,7 @@ from pcgym_amd import VecEnv
 
 FP64_PEAK_TFLOPS = 78.6
 FLOP_PER_RHS = {"cstr": 16 + 25 + 10, "four_tank": 20 + 4 * 12, "multistage_extraction": 65,
-                "multistage_extraction_reactive": 150, "crystallization": 80 + 3 * 60 + 12 + 6 * 10}
+                "multistage_extraction_reactive": 150, "crystallization": 60 + 4 * 25 + 12 + 6 * 10}  # 2 log + 2 exp + sqrt + 6 div
 
 
 def timed_steps(env, acts, K, W=5):
