@@ -478,3 +478,107 @@ def test_bad_arguments_return_status_not_crash():
     p2 = C.c_void_p()
     assert lib.pcg_plan_create(C.byref(p2), C.byref(cfg)) == abi.PCG_E_MODEL
     assert lib.pcg_plan_destroy(plan) == 0
+
+
+def test_full_size_me_and_cryst_properties():
+    """BASELINE.json configs[2],[3] sizes (B = 262,144): size-independent properties.
+    ME (adaptive DOPRI5): lane independence under a permutation (bitwise), oracle agreement on a slice,
+    and the physical steady-state solute balance L (X0 - X5) = G (Y1 - Y6) after holding the input.
+    cryst (RK4 x32): the augmented states track the moments, CV^2 + 1 = mu2 mu0 / mu1^2 and Ln = mu1/mu0."""
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    B = 1 << 18
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    # ---- multistage extraction --------------------------------------------------------------
+    p = copy.deepcopy(SC.scenarios()["me_canonical"]["env_params"])
+    p.update(integrator="dopri5", N=200, tsim=200.0, SP={"X5": [0.3] * 200})
+    env, env2 = VecEnv(p, n_envs=B), VecEnv(p, n_envs=B)
+    env.reset()
+    env2.reset()
+    x0 = env.x * (1 + 0.05 * (2 * torch.rand(env.x.shape, generator=gen, device="cuda", dtype=torch.float64) - 1))
+    perm = torch.randperm(B, generator=gen, device="cuda")
+    env.x.copy_(x0)
+    env2.x.copy_(x0[:, perm])
+    a = 0.3 * torch.rand((2, B), generator=gen, device="cuda", dtype=torch.float64) - 0.95  # low..moderate flows
+    n_or = 2048
+    orc = O.OracleEnv(env.spec, n_or)
+    orc.reset()
+    orc.x[:] = x0[:, :n_or].cpu().numpy()
+    for i in range(3):
+        env.step(a)
+        env2.step(a[:, perm])
+        orc.step(a[:, :n_or].cpu().numpy())
+    assert torch.equal(env.x[:, perm], env2.x) and torch.equal(env.rew[perm], env2.rew)
+    ex = np.abs(env.x[:, :n_or].cpu().numpy() - orc.x) / np.maximum(np.abs(orc.x), 1e-6)
+    assert np.mean(ex.max(axis=0) <= 1e-9) >= 0.97 and ex.max() <= 1e-5
+    for i in range(150):  # hold the input: the cascade settles (time constants of a few model time units)
+        env.step(a)
+    assert torch.isfinite(env.x).all()
+    lo, hi = torch.tensor([5.0, 10.0], device="cuda"), torch.tensor([500.0, 1000.0], device="cuda")
+    LG = (a + 1) * ((hi - lo) / 2)[:, None] + lo[:, None]
+    L, G = LG[0], LG[1]
+    X0, Y6 = 0.6, 0.05  # model defaults, model_classes.py:366-367
+    bal = L * (X0 - env.x[8]) - G * (env.x[1] - Y6)
+    assert (bal.abs() / (L * X0)).max().item() <= 1e-6
+    env.close()
+    env2.close()
+    # ---- crystallisation ---------------------------------------------------------------------
+    p = copy.deepcopy(SC.scenarios()["cryst_adelta"]["env_params"])
+    p.update(integrator="rk4", substeps=32)
+    env = VecEnv(p, n_envs=B)
+    env.reset()
+    x = env.x.clone()
+    x[:5] *= 1 + 0.01 * (2 * torch.rand((5, B), generator=gen, device="cuda", dtype=torch.float64) - 1)
+    x[5] = torch.sqrt(x[2] * x[0] / x[1] ** 2 - 1)
+    x[6] = x[1] / x[0]
+    env.x.copy_(x)
+    for i in range(10):
+        act = 0.3 * (2 * torch.rand((1, B), generator=gen, device="cuda", dtype=torch.float64) - 1) - 0.2
+        env.step(act)
+    X = env.x
+    assert torch.isfinite(X).all()
+    cv = torch.sqrt(X[2] * X[0] / X[1] ** 2 - 1)
+    ln = X[1] / X[0]
+    assert ((X[5] - cv).abs() / cv).max().item() <= 1e-5   # RK4 error of the augmented ODE, not round-off
+    assert ((X[6] - ln).abs() / ln).max().item() <= 1e-6
+    assert (X[0][1:] >= 0).all() and (X[4] < 0.2).all()    # nuclei only appear, solute only leaves
+    env.close()
+
+
+def test_affine_model_superposition():
+    """custom affine model: one env step is an affine map of (x, u), so
+    F(x1+x2, u1+u2) = F(x1,u1) + F(x2,u2) - F(0,0) -- checked on 2^18 random envs."""
+    torch = _torch()
+    import copy
+
+    from pcgym_amd import VecEnv
+
+    B = 1 << 18
+    p = copy.deepcopy(SC.scenarios()["custom_linear_kat"]["env_params"])
+    p.update(normalise_a=False, normalise_o=False)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    xs = [torch.randn((2, B), generator=gen, device="cuda", dtype=torch.float64) for _ in range(2)]
+    us = [torch.randn((1, B), generator=gen, device="cuda", dtype=torch.float64) for _ in range(2)]
+
+    def F(x, u):
+        env = VecEnv(p, n_envs=B)
+        env.reset()
+        env.x.copy_(x)
+        env.step(u)
+        out = env.x.clone()
+        env.close()
+        return out
+
+    z = torch.zeros((2, B), device="cuda", dtype=torch.float64)
+    lhs = F(xs[0] + xs[1], us[0] + us[1])
+    rhs = F(xs[0], us[0]) + F(xs[1], us[1]) - F(z, z[:1])
+    assert ((lhs - rhs).abs() / (1 + lhs.abs())).max().item() <= 1e-13
+    # and the closed form of the linear ODE (dt = 0.1): x1' = e^{1.5 dt} x1 + (e^{1.5 dt}-1)/1.5 u, x2' = e^{2.5 dt} x2
+    e1, e2 = np.exp(0.15), np.exp(0.25)
+    want = torch.stack([e1 * xs[0][0] + (e1 - 1) / 1.5 * us[0][0], e2 * xs[0][1]])
+    got = F(xs[0], us[0])
+    assert ((got - want).abs() / (1 + want.abs())).max().item() <= 1e-8
