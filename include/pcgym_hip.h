@@ -263,6 +263,15 @@ PCG_API int pcg_integrate(pcg_plan* plan, int64_t B, double* x, const double* u,
 PCG_API int pcg_rollout(pcg_plan* plan, const pcg_buffers* io, int32_t t0, int32_t T, const double* a_seq,
                 double* obs_seq, double* rew_seq, uint64_t seed, void* stream);
 
+/* pcg_rollout with explicit element strides (step, component) for the three sequences; the env index is
+ * unit-stride.  Lets the collector write straight into the reference's axis order
+ * x (Nx, N, reps), u (Nu, N, reps), r (1, N, reps)  (policy_evaluation.py:155-197):
+ * obs_comp_stride = N*B, obs_step_stride = B.  Strides must keep rows 16-byte aligned for the 2-env/lane path. */
+PCG_API int pcg_rollout_strided(pcg_plan* plan, const pcg_buffers* io, int32_t t0, int32_t T, const double* a_seq,
+                                int64_t a_step_stride, int64_t a_comp_stride, double* obs_seq,
+                                int64_t obs_step_stride, int64_t obs_comp_stride, double* rew_seq,
+                                int64_t rew_step_stride, uint64_t seed, void* stream);
+
 /* Raw Philox4x32-10 block for KAT tests: ctr[4], key[2] -> out[4]. (host) */
 PCG_API void pcg_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -136,6 +136,7 @@ EXPORTS = [
     "pcg_rhs",
     "pcg_integrate",
     "pcg_rollout",
+    "pcg_rollout_strided",
     "pcg_philox4x32_10",
 ]
 
@@ -174,6 +175,9 @@ def declare(lib):
     lib.pcg_rollout.restype = C.c_int
     lib.pcg_rollout.argtypes = [vp, C.POINTER(pcg_buffers), C.c_int32, C.c_int32, vp, vp, vp,
                                 C.c_uint64, vp]
+    lib.pcg_rollout_strided.restype = C.c_int
+    lib.pcg_rollout_strided.argtypes = [vp, C.POINTER(pcg_buffers), C.c_int32, C.c_int32, vp, C.c_int64, C.c_int64,
+                                        vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_uint64, vp]
     lib.pcg_philox4x32_10.restype = None
     lib.pcg_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]

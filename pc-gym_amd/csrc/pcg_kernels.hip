@@ -140,6 +140,8 @@ struct StepArgs {
   const double* a_seq;
   double* obs_seq;
   double* rew_seq;
+  // element strides of the sequences: (step, component); the env index is always unit-stride
+  int64_t a_ss, a_cs, o_ss, o_cs, r_ss;
   int32_t T;
 };
 
@@ -409,6 +411,22 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
 }
 
 // scalar (8 B per lane) store of one env's outputs; obs_base = &obs[0][e] of the destination
+template <class M>
+PCG_DEV void store_obs(const StepArgs& A, CDevConst& c, const EnvOut<M>& out, double* obs_base, int64_t B) {
+  // B here is the component stride of the destination
+  const int nx = M::DYNAMIC ? c.nx : M::NX;
+  const int nso = c.nsp_obs, nd = c.nd;
+#pragma unroll
+  for (int i = 0; i < M::NX; ++i)
+    if (i < nx) obs_base[(size_t)i * B] = out.ox[i];
+#pragma unroll
+  for (int k = 0; k < PCG_MAX_NSP; ++k)
+    if (k < nso) obs_base[(size_t)(nx + k) * B] = out.osp[k];
+#pragma unroll
+  for (int k = 0; k < PCG_MAX_NDM; ++k)
+    if (k < nd) obs_base[(size_t)(nx + nso + k) * B] = out.od[k];
+}
+
 template <class M>
 PCG_DEV void store_out(const StepArgs& A, CDevConst& c, int64_t e, const EnvOut<M>& out, double* obs_base) {
   const int64_t B = A.B;
@@ -862,7 +880,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel_lean(const StepArgs A) {
   V an[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i)
-    if (i < na) an[i] = *reinterpret_cast<const V*>(A.a_seq + (size_t)i * B + e0);
+    if (i < na) an[i] = *reinterpret_cast<const V*>(A.a_seq + (size_t)i * A.a_cs + e0);
   LeanOut<M, EPL> out;
   for (int s = 0; s < A.T; ++s) {
     Pack<EPL> as[NA];
@@ -874,33 +892,34 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel_lean(const StepArgs A) {
     }
     asm volatile("" ::: "memory");
     if (s + 1 < A.T) {  // next step's action in flight during this step's integration
-      const double* nxt = A.a_seq + (size_t)(s + 1) * na * B;
+      const double* nxt = A.a_seq + (size_t)(s + 1) * A.a_ss;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        if (i < na) an[i] = *reinterpret_cast<const V*>(nxt + (size_t)i * B + e0);
+        if (i < na) an[i] = *reinterpret_cast<const V*>(nxt + (size_t)i * A.a_cs + e0);
     }
     asm volatile("" ::: "memory");
     env_step_lean<M, EPL>(A, c, A.t_scalar + s, as, xs, out);
-    if (A.rew_seq) Vec<EPL>::store_nt(A.rew_seq + (size_t)s * B + e0, out.rew.v);
+    if (A.rew_seq) Vec<EPL>::store_nt(A.rew_seq + (size_t)s * A.r_ss + e0, out.rew.v);
     if (A.obs_seq) {
-      double* o = A.obs_seq + (size_t)s * nobs * B + e0;
+      double* o = A.obs_seq + (size_t)s * A.o_ss + e0;
+      const int64_t ocs = A.o_cs;
       double tmp[EPL];
 #pragma unroll
       for (int i = 0; i < NX; ++i)
-        if (i < nx) Vec<EPL>::store_nt(o + (size_t)i * B, out.ox[i].v);
+        if (i < nx) Vec<EPL>::store_nt(o + (size_t)i * ocs, out.ox[i].v);
 #pragma unroll
       for (int k = 0; k < PCG_MAX_NSP; ++k)
         if (k < nso) {
 #pragma unroll
           for (int j = 0; j < EPL; ++j) tmp[j] = out.osp[k];
-          Vec<EPL>::store_nt(o + (size_t)(nx + k) * B, tmp);
+          Vec<EPL>::store_nt(o + (size_t)(nx + k) * ocs, tmp);
         }
 #pragma unroll
       for (int k = 0; k < M::NDM; ++k)
         if (k < c.nd) {
 #pragma unroll
           for (int j = 0; j < EPL; ++j) tmp[j] = out.od[k];
-          Vec<EPL>::store_nt(o + (size_t)(nx + nso + k) * B, tmp);
+          Vec<EPL>::store_nt(o + (size_t)(nx + nso + k) * ocs, tmp);
         }
     }
   }
@@ -947,14 +966,14 @@ __global__ __launch_bounds__(tb(LDS_STAGES)) void rollout_kernel(const StepArgs 
 #pragma unroll
   for (int i = 0; i < NX; ++i) x[i] = (i < nx) ? A.x[(size_t)i * B + e] : 0.0;
   for (int s = 0; s < A.T; ++s) {
-    const double* as = A.a_seq + (size_t)s * na * B;
+    const double* as = A.a_seq + (size_t)s * A.a_ss;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) a[i] = (i < na) ? as[(size_t)i * B + e] : 0.0;
+    for (int i = 0; i < NA; ++i) a[i] = (i < na) ? as[(size_t)i * A.a_cs + e] : 0.0;
     const bool last = (s == A.T - 1);
     EnvOut<M> out;
     env_step<M, INTEG, false, LDS_STAGES, true>(A, c, lds, lds, e, A.t_scalar + s, a, x, out);
-    if (A.rew_seq) A.rew_seq[(size_t)s * B + e] = out.rew;
-    if (A.obs_seq) store_out<M>(A, c, e, out, A.obs_seq + (size_t)s * nobs * B + e);
+    if (A.rew_seq) A.rew_seq[(size_t)s * A.r_ss + e] = out.rew;
+    if (A.obs_seq) store_obs<M>(A, c, out, A.obs_seq + (size_t)s * A.o_ss + e, A.o_cs);
     if (last || !A.obs_seq) store_out<M>(A, c, e, out, A.obs + e);  // io->obs/rew/done hold the last step
   }
 #pragma unroll
@@ -1556,8 +1575,10 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   return (int)hipGetLastError();
 }
 
-int pcg_rollout(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t T, const double* a_seq, double* obs_seq,
-                double* rew_seq, uint64_t seed, void* stream) {
+int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t T, const double* a_seq,
+                        int64_t a_step_stride, int64_t a_comp_stride, double* obs_seq, int64_t obs_step_stride,
+                        int64_t obs_comp_stride, double* rew_seq, int64_t rew_step_stride, uint64_t seed,
+                        void* stream) {
   StepArgs a;
   int rc = fill_args(p, io, &a);
   if (rc != PCG_OK) return rc;
@@ -1573,13 +1594,18 @@ int pcg_rollout(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t T, const
   a.a_seq = a_seq;
   a.obs_seq = obs_seq;
   a.rew_seq = rew_seq;
+  a.a_ss = a_step_stride; a.a_cs = a_comp_stride;
+  a.o_ss = obs_step_stride; a.o_cs = obs_comp_stride;
+  a.r_ss = rew_step_stride;
+  if (a.a_cs < io->B || (obs_seq && a.o_cs < io->B)) return PCG_E_DIM;
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5;
   const Kernels& k = kernels(p->model_id);
   const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH)) ||
                       c.ncon > 0 || io->d != nullptr;
   if (!extras && p->integrator_id == PCG_INT_RK4 && !io->viol && p->variant != 1) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    const bool e2 = k.roll_lean[1] && (io->B % 2 == 0) && al16(io->x) && al16(a_seq) && al16(io->obs) &&
+    const bool ev = ((a.a_ss | a.a_cs | a.o_ss | a.o_cs | a.r_ss) & 1) == 0;  // 16-byte rows stay 16-byte aligned
+    const bool e2 = ev && k.roll_lean[1] && (io->B % 2 == 0) && al16(io->x) && al16(a_seq) && al16(io->obs) &&
                     al16(io->rew) && (!obs_seq || al16(obs_seq)) && (!rew_seq || al16(rew_seq)) &&
                     (reinterpret_cast<uintptr_t>(io->done) & 1u) == 0;
     const int epl = e2 ? 2 : 1;
@@ -1593,6 +1619,15 @@ int pcg_rollout(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t T, const
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(fn, dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
   return (int)hipGetLastError();
+}
+
+int pcg_rollout(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t T, const double* a_seq, double* obs_seq,
+                double* rew_seq, uint64_t seed, void* stream) {
+  if (!plan_ok(p)) return PCG_E_PLAN;
+  if (!io) return PCG_E_NULL;
+  const int64_t B = io->B;
+  return pcg_rollout_strided(p, io, t0, T, a_seq, (int64_t)p->hc.na * B, B, obs_seq, (int64_t)p->hc.nobs * B, B, rew_seq,
+                             B, seed, stream);
 }
 
 int pcg_reset(pcg_plan* p, const pcg_buffers* io, const uint8_t* mask, uint64_t seed, void* stream) {

@@ -582,3 +582,61 @@ def test_affine_model_superposition():
     want = torch.stack([e1 * xs[0][0] + (e1 - 1) / 1.5 * us[0][0], e2 * xs[0][1]])
     got = F(xs[0], us[0])
     assert ((got - want).abs() / (1 + want.abs())).max().item() <= 1e-8
+
+
+@pytest.mark.parametrize("name", ["cstr_canonical", "four_tank_canonical", "cstr_cons_pen_raw"])
+def test_collect_rollouts_reference_axis_order(name):
+    """row f-1: batched counterpart of policy_eval.rollout/get_rollouts (policy_evaluation.py:71-197):
+    r (1,N,B), x (Nx,N,B), u (na,N,B), g (ncon,N,1,B) -- against the reference make_env recordings
+    (x = de-normalised observation = the reference state vector when noise is off), open loop (fused
+    kernel where the plan is lean) and closed loop (scripted 'policy')."""
+    torch = _torch()
+    import copy
+
+    from pcgym_amd import VecEnv, collect_rollouts
+
+    g = H.gold("step_" + name)
+    sc = SC.scenarios()[name]
+    p = copy.deepcopy(sc["env_params"])
+    p.update(H.tight_for(p))
+    A = SC.actions_for(name, sc)                 # (T, na) scripted actions, T = N-1
+    B, N = 64, p["N"]
+    spec_na = A.shape[1]
+    acts = torch.zeros((N, spec_na, B), dtype=torch.float64, device="cuda")
+    acts[: A.shape[0]] = torch.tensor(A, device="cuda")[:, :, None]
+    env = VecEnv(p, n_envs=B)
+    d_open = collect_rollouts(env, actions=acts)
+    env2 = VecEnv(p, n_envs=B)
+    step = {"i": 0}
+
+    def policy(obs):
+        a = acts[step["i"]]
+        step["i"] += 1
+        return a
+
+    d_closed = collect_rollouts(env2, policy=policy)
+    for d in (d_open, d_closed):
+        assert d["x"].shape == (env.Nx, N, B) and d["u"].shape == (spec_na, N, B) and d["r"].shape == (1, N, B)
+        x = d["x"][:, :, 7].cpu().numpy()        # any env: they are identical
+        want = g["state"].T                      # (Nx, T+1)
+        T1 = want.shape[1]
+        assert np.all(np.abs(x[:, :T1] - want) <= 1e-8 * np.maximum(np.abs(want), 1.0))
+        r = d["r"][0, :, 7].cpu().numpy()
+        assert r[0] == 0.0
+        assert np.all(np.abs(r[1:T1] - g["rew"]) <= 1e-6 * np.maximum(np.abs(g["rew"]), 1.0))
+        assert (d["x"] == d["x"][:, :, :1]).all()
+    assert torch.allclose(d_open["x"], d_closed["x"], rtol=1e-12, atol=1e-12)
+    assert torch.allclose(d_open["r"], d_closed["r"], rtol=1e-10, atol=1e-12)
+    # u holds physical actions (policy_evaluation.py:101-104)
+    if env.spec.normalise_a:
+        lo, hi = env.spec.a_low, env.spec.a_high
+        want_u = (A + 1) * (hi - lo) / 2 + lo
+    else:
+        want_u = A
+    assert np.allclose(d_closed["u"][:, : A.shape[0], 3].cpu().numpy().T, want_u, rtol=1e-13)
+    if "cons_info" in g.files:
+        ci = g["cons_info"]
+        gg = d_closed["g"][:, :T1, 0, 5].cpu().numpy()
+        assert np.allclose(gg, ci[:, :T1], rtol=1e-7, atol=1e-8 * np.max(np.abs(ci)))
+    env.close()
+    env2.close()
