@@ -71,8 +71,18 @@ enum pcg_model {
   PCG_MODEL_CRYST = 4,         /* model_classes.py:1232-1345 nx=7  nu=1                */
   PCG_MODEL_AFFINE = 5,        /* custom_model whose RHS is affine: dx = A x + B u + c
                                   (pcgym.py:150-153; the reference's only KAT,
-                                  tests/environment/test_make_env_custom_model.py:66-86) */
-  PCG_MODEL_COUNT = 6
+                                  tests/environment/test_make_env_custom_model.py:66-86); also carries the
+                                  affine registry models hydraulic_tank :128-153, first_order_system :296-343,
+                                  nonsmooth_control :509-558 (matrices built on the host) */
+  /* "next" row f-2: further registry models (general kernels only, no streaming specialisation) */
+  PCG_MODEL_COMPLEX_CSTR = 6,  /* model_classes.py:65-125   nx=4 nu=1 (+Ti,Caf) */
+  PCG_MODEL_DISEASE = 7,       /* model_classes.py:156-183  nx=3 nu=1            */
+  PCG_MODEL_BATCH = 8,         /* model_classes.py:222-265  nx=4 nu=1            */
+  PCG_MODEL_PHOTO = 9,         /* model_classes.py:433-506  nx=3 nu=2 ("photobioreactor") */
+  PCG_MODEL_CSTR_SERIES = 10,  /* model_classes.py:611-679  nx=4 nu=4            */
+  PCG_MODEL_DISTILLATION = 11, /* model_classes.py:682-760  nx=9 nu=2            */
+  PCG_MODEL_POLYMER = 12,      /* model_classes.py:1158-1229 nx=3 nu=4           */
+  PCG_MODEL_COUNT = 13
 };
 
 /* integrators replacing integrator.py:90-107 (CVODES) / :65-88 (diffrax Tsit5) */

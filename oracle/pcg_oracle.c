@@ -166,6 +166,109 @@ static void rhs_affine(const double* p, int nx, const double* x, const double* u
   }
 }
 
+
+/* ---- "next" row f-2: further registry models ------------------------------------------------ */
+
+/* model_classes.py:98-125.  p = q,V,rho,C,deltaHr1,EA1_over_R,k01,deltaHr2,EA2_over_R,k02,UA,Ti,Caf */
+static void rhs_complex_cstr(const double* p, const double* x, const double* u, int nu, double* dx) {
+  double q = p[0], V = p[1], rho = p[2], C = p[3], deltaHr1 = p[4], EA1 = p[5], k01 = p[6], deltaHr2 = p[7],
+         EA2 = p[8], k02 = p[9], UA = p[10], Ti = p[11], Caf = p[12];
+  double ca = x[0], cb = x[1], cc = x[2], T = x[3];
+  double Tc = u[0];
+  if (nu != 1) { Ti = u[1]; Caf = u[2]; }
+  double r1 = k01 * exp(-EA1 / T) * ca;
+  double r2 = k02 * exp(-EA2 / T) * cb;
+  double heat_gen = (-deltaHr1 * r1) + (-deltaHr2 * r2);
+  dx[0] = (q / V) * (Caf - ca) - r1;
+  dx[1] = (q / V) * (0 - cb) + 2 * r1 - r2;
+  dx[2] = (q / V) * (0 - cc) + r2;
+  dx[3] = (q / V) * (Ti - T) + heat_gen / (rho * C) + (UA / (rho * C * V)) * (Tc - T);
+}
+
+/* model_classes.py:173-183.  p = beta, gamma */
+static void rhs_disease(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu;
+  double beta = p[0], gamma = p[1], S = x[0], I = x[1], u_in = u[0];
+  dx[0] = -beta * S * I - u_in * S;
+  dx[1] = beta * S * I - gamma * I;
+  dx[2] = gamma * I + u_in * S;
+}
+
+/* model_classes.py:248-265.  p = k01,k02,EA1,EA2,R,dH1,dH2,rho,Cp,UA,V */
+static void rhs_batch(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu;
+  double k01 = p[0], k02 = p[1], EA1 = p[2], EA2 = p[3], R = p[4], dH1 = p[5], dH2 = p[6], rho = p[7], Cp = p[8],
+         UA = p[9], V = p[10];
+  double CA = x[0], CB = x[1], T = x[3], Tc = u[0];
+  double r1 = k01 * exp(-EA1 / (R * T)) * CA;
+  double r2 = k02 * exp(-EA2 / (R * T)) * CB;
+  dx[0] = -r1;
+  dx[1] = 2 * r1 - r2;
+  dx[2] = r2;
+  dx[3] = -(dH1 * r1 + dH2 * r2) / (rho * Cp) + UA / (rho * Cp * V) * (Tc - T);
+}
+
+/* model_classes.py:473-490.  p = u_m,u_d,Y_NX,k_m,k_d,k_sq,K_Nq,k_iq,k_s,k_i,k_N ; u = I, F_N */
+static void rhs_photo(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu;
+  double u_m = p[0], u_d = p[1], Y_NX = p[2], k_m = p[3], k_d = p[4], k_sq = p[5], K_Nq = p[6], k_iq = p[7],
+         k_s = p[8], k_i = p[9], k_N = p[10];
+  double c_x = x[0], c_N = x[1], c_q = x[2], I = u[0], F_N = u[1];
+  dx[0] = u_m * I / (I + k_s + (I * I / k_i)) * c_x * c_N / (c_N + k_N) - u_d * c_x;
+  dx[1] = -Y_NX * u_m * I / (I + k_s + (I * I / k_i)) * c_x * c_N / (c_N + k_N) + F_N;
+  dx[2] = k_m * I / (I + k_sq + (I * I / k_iq)) * c_x - (k_d * c_q) / (c_N + K_Nq);
+}
+
+/* model_classes.py:646-665.  p = C_O,T_O,V1,V2,U1A1,U2A2,rho,cp,k,E,deltaH,R ; u = F,L,Tc1,Tc2 */
+static void rhs_cstr_series(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu;
+  double C_O = p[0], T_O = p[1], V1 = p[2], V2 = p[3], U1A1 = p[4], U2A2 = p[5], rho = p[6], cp = p[7], k = p[8],
+         E = p[9], deltaH = p[10], R = p[11];
+  double C1 = x[0], T1 = x[1], C2 = x[2], T2 = x[3], F = u[0], L = u[1], Tc1 = u[2], Tc2 = u[3];
+  dx[0] = (C_O / V1) * F + (1 / V1) * L * C2 - (1 / V1) * (F + L) * C1 - k * C1 * exp((-E / (R * T1)));
+  dx[1] = (T_O / V1) * F + (1 / V1) * L * T2 - ((U1A1) / (V1 * rho * cp)) * (T1 - Tc1) - (1 / V1) * (F + L) * T1 +
+          ((k * (-deltaH)) / (rho * cp)) * C1 * exp((-E / (R * T1)));
+  dx[2] = (1 / V2) * (F + L) * (C1 - C2) - k * C2 * exp((-E / (R * T2)));
+  dx[3] = (1 / V2) * (F + L) * (T1 - T2) - ((U2A2) / (V2 * rho * cp)) * (T2 - Tc2) +
+          ((k * (-deltaH)) / (rho * cp)) * C2 * exp((-E / (R * T2)));
+}
+
+/* model_classes.py:707-745.  p = D,q,alpha,X_feed,M0,Mb,M ; x = X0,X1,X2,X3,Xf,X4,X5,X6,Xb ; u = R,F */
+static void rhs_distillation(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu;
+  double D = p[0], q = p[1], alpha = p[2], X_feed = p[3], M0 = p[4], Mb = p[5], M = p[6];
+  double X0 = x[0], X1 = x[1], X2 = x[2], X3 = x[3], Xf = x[4], X4 = x[5], X5 = x[6], X6 = x[7], Xb = x[8];
+  double Rr = u[0], F = u[1];
+  double L = Rr * D, V = (Rr + 1) * D, L_dash = L + q * F, V_dash = V + (1 - q) * F, W = F - D;
+  double Y1 = (alpha * X1) / (1 + (alpha - 1) * X1), Y2 = (alpha * X2) / (1 + (alpha - 1) * X2);
+  double Y3 = (alpha * X3) / (1 + (alpha - 1) * X3), Yf = (alpha * Xf) / (1 + (alpha - 1) * Xf);
+  double Y4 = (alpha * X4) / (1 + (alpha - 1) * X4), Y5 = (alpha * X5) / (1 + (alpha - 1) * X5);
+  double Y6 = (alpha * X6) / (1 + (alpha - 1) * X6), Yb = (alpha * Xb) / (1 + (alpha - 1) * Xb);
+  dx[0] = (1 / M0) * ((V * Y1) - (L + D) * X0);
+  dx[1] = (1 / M) * (L * (X0 - X1) + V * (Y2 - Y1));
+  dx[2] = (1 / M) * (L * (X1 - X2) + V * (Y3 - Y2));
+  dx[3] = (1 / M) * (L * (X2 - X3) + V * (Yf - Y3));
+  dx[4] = (1 / M) * (L * X3 - L_dash * Xf + V_dash * Y4 - V * Yf + F * X_feed);
+  dx[5] = (1 / M) * (L_dash * (Xf - X4) + V_dash * (Y5 - Y4));
+  dx[6] = (1 / M) * (L_dash * (X4 - X5) + V_dash * (Y6 - Y5));
+  dx[7] = (1 / M) * (L_dash * (X5 - X6) + V_dash * (Yb - Y6));
+  dx[8] = (1 / Mb) * (L_dash * X6 - W * Xb - V_dash * Yb);
+}
+
+/* model_classes.py:1197-1213.  p = Ap,Ad,At,Ep_over_R,Ed_over_R,Et_over_R,f,V,deltaHp,rho,cp ; x = T,M,I ; u = F,Tf,Mf,If */
+static void rhs_polymer(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu;
+  double Ap = p[0], Ad = p[1], At = p[2], Ep = p[3], Ed = p[4], Et = p[5], f = p[6], V = p[7], deltaHp = p[8],
+         rho = p[9], cp = p[10];
+  double T = x[0], M = x[1], I = x[2], F = u[0], Tf = u[1], Mf = u[2], If = u[3];
+  double kp = Ap * exp(-Ep / T), kd = Ad * exp(-Ed / T), kt = At * exp(-Et / T);
+  double ri = 2 * f * kd * I;
+  double rp = kp * pow((f * kd * I) / kt, 0.5);
+  dx[0] = (F / V) * (Tf - T) + ((-deltaHp) / (rho * cp)) * rp;
+  dx[1] = (F / V) * (Mf - M) - rp;
+  dx[2] = (F / V) * (If - I) - ri;
+}
+
 typedef struct {
   int model_id, nx, nu;
   const double* p;
@@ -178,6 +281,13 @@ static void rhs(const orc_model* m, const double* x, const double* u, double* dx
     case PCG_MODEL_ME: rhs_me(m->p, x, u, m->nu, dx); break;
     case PCG_MODEL_ME_REACTIVE: rhs_me_reactive(m->p, x, u, m->nu, dx); break;
     case PCG_MODEL_CRYST: rhs_cryst(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_COMPLEX_CSTR: rhs_complex_cstr(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_DISEASE: rhs_disease(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_BATCH: rhs_batch(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_PHOTO: rhs_photo(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_CSTR_SERIES: rhs_cstr_series(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_DISTILLATION: rhs_distillation(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_POLYMER: rhs_polymer(m->p, x, u, m->nu, dx); break;
     default: rhs_affine(m->p, m->nx, x, u, m->nu, dx); break;
   }
 }

@@ -29,6 +29,8 @@ from . import models as M
 # default 'hip' map to the per-model default below; 'jax' (diffrax Tsit5,
 # rtol=atol=1e-8, integrator.py:56-61) maps to the adaptive 5(4) pair.
 DEFAULT_INTEGRATOR = {
+    M.COMPLEX_CSTR: "dopri5", M.DISEASE: "dopri5", M.BATCH: "dopri5", M.PHOTO: "dopri5", M.CSTR_SERIES: "dopri5",
+    M.DISTILLATION: "dopri5", M.POLYMER: "dopri5",   # no tuned fixed step yet: adaptive by default
     M.CSTR: "rk4",
     M.FOUR_TANK: "rk4",
     M.ME: "dopri5",           # stiff at high L,G (|lambda| dt up to ~240): adaptive
@@ -42,7 +44,8 @@ DEFAULT_INTEGRATOR = {
 # section 8a table).  Fixed-step RK4 is only conditionally stable: outside the canonical operating
 # range (cstr thermal runaway, ME at high flows) use integrator='dopri5'.
 DEFAULT_RK4_H = {M.CSTR: 26.0 / 60.0 / 4, M.FOUR_TANK: 1000.0 / 60.0 / 4, M.ME: 1.0 / 128,
-                 M.ME_REACTIVE: 1.0 / 32, M.CRYST: 1.0 / 32, M.AFFINE: None}
+                 M.ME_REACTIVE: 1.0 / 32, M.CRYST: 1.0 / 32, M.AFFINE: None, M.COMPLEX_CSTR: None, M.DISEASE: None,
+                 M.BATCH: None, M.PHOTO: None, M.CSTR_SERIES: None, M.DISTILLATION: None, M.POLYMER: None}
 
 
 def default_substeps(model_id, dt):
@@ -150,6 +153,10 @@ class EnvSpec:
             self.model = self._adopt_custom_model(p["custom_model"], p)
         else:
             self.model = M.get_model(p.get("model"))
+            if self.model.affine_builder is not None:
+                A, Bm, c = self.model.affine_builder(self.model.parameters)
+                self.affine_AB = (np.atleast_2d(np.asarray(A, dtype=_f64)), np.atleast_2d(np.asarray(Bm, dtype=_f64)),
+                                  np.asarray(c, dtype=_f64).reshape(-1))
         info = self.model.info()
         self.nx = len(info["states"])
         self.nu_inputs = len(info["inputs"])
@@ -331,7 +338,11 @@ class EnvSpec:
         self.integrator = p.get("integrator", d_int)
         if self.integrator not in ("rk4", "dopri5"):
             raise ValueError("integrator must be 'rk4' or 'dopri5'")
-        self.substeps = int(p.get("substeps", default_substeps(self.model.model_id, self.dt)))
+        d_sub = default_substeps(self.model.model_id, self.dt)
+        if self.affine_AB is not None:
+            # affine models: keep |A|_inf * h <= 0.05 (RK4 local error ~ (|A| h)^5 / 120)
+            d_sub = max(8, int(np.ceil(self.dt * np.abs(self.affine_AB[0]).sum(axis=1).max() / 0.05)))
+        self.substeps = int(p.get("substeps", d_sub))
         self.rtol = float(p.get("rtol", 1e-8))
         self.atol = float(p.get("atol", 1e-8))
         self.max_steps = int(p.get("max_steps", 100000))

@@ -1100,7 +1100,7 @@ struct Kernels {
   RhsKFn rhs;
   IntKFn integ[PCG_INT_COUNT][2];
   int nx, na, ndm, nraw;
-  bool dynamic;
+  bool dynamic, has_lds_stages;
   void (*prep)(const double*, int, int, double*, double*);
   size_t kp_bytes;
 };
@@ -1109,50 +1109,55 @@ template <int ID>
 Kernels make_kernels() {
   using M = Model<ID>;
   Kernels k;
+  std::memset(&k, 0, sizeof(k));
   k.step[PCG_INT_RK4][0][0][0] = step_kernel<M, PCG_INT_RK4, false, false, false>;
   k.step[PCG_INT_RK4][0][0][1] = step_kernel<M, PCG_INT_RK4, false, false, true>;
   k.step[PCG_INT_RK4][1][0][0] = step_kernel<M, PCG_INT_RK4, true, false, false>;
   k.step[PCG_INT_RK4][1][0][1] = step_kernel<M, PCG_INT_RK4, true, false, true>;
-  for (int pe = 0; pe < 2; ++pe)
-    for (int ex = 0; ex < 2; ++ex) k.step[PCG_INT_RK4][pe][1][ex] = k.step[PCG_INT_RK4][pe][0][ex];  // no stage store
   k.step[PCG_INT_DOPRI5][0][0][0] = step_kernel<M, PCG_INT_DOPRI5, false, false, false>;
   k.step[PCG_INT_DOPRI5][0][0][1] = step_kernel<M, PCG_INT_DOPRI5, false, false, true>;
   k.step[PCG_INT_DOPRI5][1][0][0] = step_kernel<M, PCG_INT_DOPRI5, true, false, false>;
   k.step[PCG_INT_DOPRI5][1][0][1] = step_kernel<M, PCG_INT_DOPRI5, true, false, true>;
-  k.step[PCG_INT_DOPRI5][0][1][0] = step_kernel<M, PCG_INT_DOPRI5, false, true, false>;
-  k.step[PCG_INT_DOPRI5][0][1][1] = step_kernel<M, PCG_INT_DOPRI5, false, true, true>;
-  k.step[PCG_INT_DOPRI5][1][1][0] = step_kernel<M, PCG_INT_DOPRI5, true, true, false>;
-  k.step[PCG_INT_DOPRI5][1][1][1] = step_kernel<M, PCG_INT_DOPRI5, true, true, true>;
-  for (int a = 0; a < PCG_INT_COUNT; ++a)
-    for (int b = 0; b < 2; ++b)
-      for (int u = 0; u < 3; ++u) k.stream[a][b][u] = nullptr;
-  k.pipe[0] = k.pipe[1] = nullptr;
-  k.roll_lean[0] = rollout_kernel_lean<M, 1>;
-  k.roll_lean[1] = nullptr;
-  if constexpr (M::NX <= 4) k.roll_lean[1] = rollout_kernel_lean<M, 2>;
-  if constexpr (M::NX <= 4) {
-    k.pipe[0] = step_kernel_pipe<M, 1>;
-    k.pipe[1] = step_kernel_pipe<M, 2>;
-  }
-  k.stream[PCG_INT_RK4][0][0] = step_kernel_stream<M, PCG_INT_RK4, 1, 1>;
-  k.stream[PCG_INT_DOPRI5][0][0] = step_kernel_stream<M, PCG_INT_DOPRI5, 1, 1>;
-  // several envs per lane / sub-tiles per workgroup only where the per-env register footprint is
-  // small (the HBM-bound models)
-  if constexpr (M::NX <= 4) {
-    k.stream[PCG_INT_RK4][0][1] = step_kernel_stream<M, PCG_INT_RK4, 1, 2>;
-    k.stream[PCG_INT_RK4][0][2] = step_kernel_stream<M, PCG_INT_RK4, 1, 4>;
-    k.stream[PCG_INT_RK4][1][0] = step_kernel_stream<M, PCG_INT_RK4, 2, 1>;
-    k.stream[PCG_INT_RK4][1][1] = step_kernel_stream<M, PCG_INT_RK4, 2, 2>;
-  }
   k.rollout[PCG_INT_RK4][0] = rollout_kernel<M, PCG_INT_RK4, false>;
-  k.rollout[PCG_INT_RK4][1] = k.rollout[PCG_INT_RK4][0];
   k.rollout[PCG_INT_DOPRI5][0] = rollout_kernel<M, PCG_INT_DOPRI5, false>;
-  k.rollout[PCG_INT_DOPRI5][1] = rollout_kernel<M, PCG_INT_DOPRI5, true>;
-  k.rhs = rhs_kernel<M>;
   k.integ[PCG_INT_RK4][0] = integrate_kernel<M, PCG_INT_RK4, false>;
-  k.integ[PCG_INT_RK4][1] = k.integ[PCG_INT_RK4][0];
   k.integ[PCG_INT_DOPRI5][0] = integrate_kernel<M, PCG_INT_DOPRI5, false>;
-  k.integ[PCG_INT_DOPRI5][1] = integrate_kernel<M, PCG_INT_DOPRI5, true>;
+  k.rhs = rhs_kernel<M>;
+  if constexpr (M::FULL) {
+    // DOPRI5 with the stage vectors in LDS (PCG_OPT_LDS_STAGES)
+    k.step[PCG_INT_DOPRI5][0][1][0] = step_kernel<M, PCG_INT_DOPRI5, false, true, false>;
+    k.step[PCG_INT_DOPRI5][0][1][1] = step_kernel<M, PCG_INT_DOPRI5, false, true, true>;
+    k.step[PCG_INT_DOPRI5][1][1][0] = step_kernel<M, PCG_INT_DOPRI5, true, true, false>;
+    k.step[PCG_INT_DOPRI5][1][1][1] = step_kernel<M, PCG_INT_DOPRI5, true, true, true>;
+    k.rollout[PCG_INT_DOPRI5][1] = rollout_kernel<M, PCG_INT_DOPRI5, true>;
+    k.integ[PCG_INT_DOPRI5][1] = integrate_kernel<M, PCG_INT_DOPRI5, true>;
+    // streaming / pipelined lean kernels
+    k.roll_lean[0] = rollout_kernel_lean<M, 1>;
+    k.stream[PCG_INT_RK4][0][0] = step_kernel_stream<M, PCG_INT_RK4, 1, 1>;
+    k.stream[PCG_INT_DOPRI5][0][0] = step_kernel_stream<M, PCG_INT_DOPRI5, 1, 1>;
+    // several envs per lane / sub-tiles per workgroup only where the per-env register footprint is
+    // small (the HBM-bound models)
+    if constexpr (M::NX <= 4) {
+      k.roll_lean[1] = rollout_kernel_lean<M, 2>;
+      k.pipe[0] = step_kernel_pipe<M, 1>;
+      k.pipe[1] = step_kernel_pipe<M, 2>;
+      k.stream[PCG_INT_RK4][0][1] = step_kernel_stream<M, PCG_INT_RK4, 1, 2>;
+      k.stream[PCG_INT_RK4][0][2] = step_kernel_stream<M, PCG_INT_RK4, 1, 4>;
+      k.stream[PCG_INT_RK4][1][0] = step_kernel_stream<M, PCG_INT_RK4, 2, 1>;
+      k.stream[PCG_INT_RK4][1][1] = step_kernel_stream<M, PCG_INT_RK4, 2, 2>;
+    }
+  }
+  // where no LDS-stage / RK4 variant exists the plain one is used
+  for (int pe = 0; pe < 2; ++pe)
+    for (int ex = 0; ex < 2; ++ex) {
+      k.step[PCG_INT_RK4][pe][1][ex] = k.step[PCG_INT_RK4][pe][0][ex];
+      if (!k.step[PCG_INT_DOPRI5][pe][1][ex]) k.step[PCG_INT_DOPRI5][pe][1][ex] = k.step[PCG_INT_DOPRI5][pe][0][ex];
+    }
+  k.rollout[PCG_INT_RK4][1] = k.rollout[PCG_INT_RK4][0];
+  if (!k.rollout[PCG_INT_DOPRI5][1]) k.rollout[PCG_INT_DOPRI5][1] = k.rollout[PCG_INT_DOPRI5][0];
+  k.integ[PCG_INT_RK4][1] = k.integ[PCG_INT_RK4][0];
+  if (!k.integ[PCG_INT_DOPRI5][1]) k.integ[PCG_INT_DOPRI5][1] = k.integ[PCG_INT_DOPRI5][0];
+  k.has_lds_stages = M::FULL;
   k.nx = M::NX;
   k.na = M::NA;
   k.ndm = M::NDM;
@@ -1167,7 +1172,11 @@ static const Kernels& kernels(int id) {
   static const Kernels K[PCG_MODEL_COUNT] = {
       make_kernels<PCG_MODEL_CSTR>(),        make_kernels<PCG_MODEL_FOUR_TANK>(),
       make_kernels<PCG_MODEL_ME>(),          make_kernels<PCG_MODEL_ME_REACTIVE>(),
-      make_kernels<PCG_MODEL_CRYST>(),       make_kernels<PCG_MODEL_AFFINE>()};
+      make_kernels<PCG_MODEL_CRYST>(),       make_kernels<PCG_MODEL_AFFINE>(),
+      make_kernels<PCG_MODEL_COMPLEX_CSTR>(), make_kernels<PCG_MODEL_DISEASE>(),
+      make_kernels<PCG_MODEL_BATCH>(),       make_kernels<PCG_MODEL_PHOTO>(),
+      make_kernels<PCG_MODEL_CSTR_SERIES>(), make_kernels<PCG_MODEL_DISTILLATION>(),
+      make_kernels<PCG_MODEL_POLYMER>()};
   return K[id];
 }
 
@@ -1178,7 +1187,17 @@ static const double DEF_ME[] = {5, 5, 1, 5, 2, 0.6, 0.05};
 static const double DEF_ME_REACTIVE[] = {5.0, 5.0, 1.0, 0.01, 0.1, 2.0, 2.00, 0.00, 2.00, 0.00};
 static const double DEF_CRYST[] = {0.923714966, -6754.878558, 0.92229965554, 1.341205945, 48.07514464, -4921.261419,
                                    1.871281405, 0.50523693,   7.271241375,   7.510905767, 2.658};
-static const double* const DEFAULTS[] = {DEF_CSTR, DEF_FOUR_TANK, DEF_ME, DEF_ME_REACTIVE, DEF_CRYST, nullptr};
+// model_classes.py:65-87, 156-158, 222-233, 443-453, 619-630, 689-695, 1172-1182
+static const double DEF_COMPLEX_CSTR[] = {100, 100, 1000, 0.239, -5e4, 8750, 7.2e10, -3e4, 9000, 1.0e10, 5e4, 350, 1};
+static const double DEF_DISEASE[] = {0.3, 0.1};
+static const double DEF_BATCH[] = {1.0, 0.5, 5000, 6000, 8.314, -1000, -1500, 1000, 4.0, 100, 1.0};
+static const double DEF_PHOTO[] = {0.0572, 0.0, 504.5, 0.00016, 0.281, 23.51, 16.89, 800.0, 178.9, 447.1, 393.1};
+static const double DEF_CSTR_SERIES[] = {97.35, 298, 1e-3, 2e-3, 0.461, 0.732, 1.05e3, 3.766, 3.118e5, 46.14, 58.41, 8.3145e-3};
+static const double DEF_DISTILLATION[] = {100.0, 1.0, 5.0, 0.2, 2000.0, 2000.0, 2000.0};
+static const double DEF_POLYMER[] = {6e10, 4e10, 9e10, 7750, 8500, 8250, 0.5, 1.0, -3e4, 1200.0, 2.0};
+static const double* const DEFAULTS[] = {DEF_CSTR,        DEF_FOUR_TANK, DEF_ME,    DEF_ME_REACTIVE, DEF_CRYST,
+                                         nullptr,         DEF_COMPLEX_CSTR, DEF_DISEASE, DEF_BATCH, DEF_PHOTO,
+                                         DEF_CSTR_SERIES, DEF_DISTILLATION, DEF_POLYMER};
 
 }  // namespace pcg
 
@@ -1511,8 +1530,8 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   a.t_scalar = t;
   a.seed = seed;
   const bool per_env_t = io->t != nullptr;
-  const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5;
   const Kernels& k = kernels(p->model_id);
+  const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
   const int block = tb(lds_st);
   size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
   if (per_env_t) {
@@ -1527,7 +1546,7 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH)) ||
                       c.ncon > 0 || io->d != nullptr;
   // streaming (persistent, prefetching, 16 B/lane) kernel for the lean lock-stepped path
-  if (!per_env_t && !extras && !lds_st && !io->viol && p->variant != 1) {
+  if (!per_env_t && !extras && !lds_st && !io->viol && p->variant != 1 && k.stream[p->integrator_id][0][0]) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool epl2_ok = k.stream[p->integrator_id][1][0] && (io->B % 2 == 0) && al16(io->x) && al16(io->a) &&
                          al16(io->obs) && al16(io->rew) && (reinterpret_cast<uintptr_t>(io->done) & 1u) == 0;
@@ -1598,11 +1617,11 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   a.o_ss = obs_step_stride; a.o_cs = obs_comp_stride;
   a.r_ss = rew_step_stride;
   if (a.a_cs < io->B || (obs_seq && a.o_cs < io->B)) return PCG_E_DIM;
-  const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5;
   const Kernels& k = kernels(p->model_id);
+  const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
   const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH)) ||
                       c.ncon > 0 || io->d != nullptr;
-  if (!extras && p->integrator_id == PCG_INT_RK4 && !io->viol && p->variant != 1) {
+  if (!extras && p->integrator_id == PCG_INT_RK4 && !io->viol && p->variant != 1 && k.roll_lean[0]) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool ev = ((a.a_ss | a.a_cs | a.o_ss | a.o_cs | a.r_ss) & 1) == 0;  // 16-byte rows stay 16-byte aligned
     const bool e2 = ev && k.roll_lean[1] && (io->B % 2 == 0) && al16(io->x) && al16(a_seq) && al16(io->obs) &&
@@ -1656,7 +1675,7 @@ int pcg_integrate(pcg_plan* p, int64_t B, double* x, const double* u, int32_t* n
   if (!x || !u) return PCG_E_NULL;
   if (B <= 0) return B == 0 ? PCG_OK : PCG_E_DIM;
   const Kernels& k = kernels(p->model_id);
-  const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5;
+  const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
   const int block = tb(lds_st);
   const size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
   IntKFn fn = k.integ[p->integrator_id][lds_st ? 1 : 0];

@@ -42,6 +42,7 @@ template <>
 struct Model<PCG_MODEL_CSTR> {
   static constexpr int NX = 2, NA = 1, NDM = 2, NRAW = 10;
   static constexpr bool DYNAMIC = false;
+  static constexpr bool FULL = true;  // all kernel specialisations
   struct KP {
     double qV, c1, c2, k0, nEAR;
   };
@@ -82,6 +83,7 @@ template <>
 struct Model<PCG_MODEL_FOUR_TANK> {
   static constexpr int NX = 4, NA = 2, NDM = 0, NRAW = 13;
   static constexpr bool DYNAMIC = false;
+  static constexpr bool FULL = true;  // all kernel specialisations
   struct KP {
     double g2;              // 2 g
     double o1, o2, o3, o4;  // a_i / A_i
@@ -140,6 +142,7 @@ template <>
 struct Model<PCG_MODEL_ME> {
   static constexpr int NX = 10, NA = 2, NDM = 2, NRAW = 7;
   static constexpr bool DYNAMIC = false;
+  static constexpr bool FULL = true;  // all kernel specialisations
   struct KP {
     double iVl, iVg, inv_m, KlaVl, e, sq;
   };
@@ -188,6 +191,7 @@ template <>
 struct Model<PCG_MODEL_ME_REACTIVE> {
   static constexpr int NX = 20, NA = 2, NDM = 0, NRAW = 10;
   static constexpr bool DYNAMIC = false;
+  static constexpr bool FULL = true;  // all kernel specialisations
   struct KP {
     double iVl, iVg, inv_m, KlaVl, kVg, e, sq, XA0, YA6, YB6, YC6;
   };
@@ -246,6 +250,7 @@ template <>
 struct Model<PCG_MODEL_CRYST> {
   static constexpr int NX = 7, NA = 1, NDM = 0, NRAW = 11;
   static constexpr bool DYNAMIC = false;
+  static constexpr bool FULL = true;  // all kernel specialisations
   struct KP {
     double ka, kb, kc2, kd2, kg, k1, k22, a, b, cc;  // kc2 = kc/2 ..., cc = -0.5*ro*alfa
   };
@@ -318,6 +323,7 @@ template <>
 struct Model<PCG_MODEL_AFFINE> {
   static constexpr int NX = 8, NA = 4, NDM = 0, NRAW = -1;
   static constexpr bool DYNAMIC = true;  // runtime nx<=8, na<=4
+  static constexpr bool FULL = true;
   struct KP {
     double A[8][8], Bm[8][4], c[8];
   };
@@ -358,6 +364,297 @@ struct Model<PCG_MODEL_AFFINE> {
       for (int j = 0; j < 8; ++j) s = s + k.A[i][j] * x[j];
       dx[i] = s;
     }
+  }
+};
+
+// ===========================================================================
+// "next" row f-2: further registry models of pcgym.py:128-148.  Same functor
+// template; FULL = false instantiates the general kernels only (no streaming / pipelined / LDS-stage
+// specialisations), which keeps the build time of the library bounded.
+// ===========================================================================
+
+// complex_cstr -- model_classes.py:65-125.  raw = q,V,rho,C,deltaHr1,EA1_over_R,k01,deltaHr2,EA2_over_R,k02,UA,Ti,Caf
+template <>
+struct Model<PCG_MODEL_COMPLEX_CSTR> {
+  static constexpr int NX = 4, NA = 1, NDM = 2, NRAW = 13;
+  static constexpr bool DYNAMIC = false, FULL = false;
+  struct KP {
+    double qV, k01, nEA1, k02, nEA2, h1, h2, c2;
+  };
+  using CKP = const PCG_CONSTANT KP;
+  template <class R>
+  struct HoldT {
+    R Tc, Ti, Caf;
+  };
+  using Hold = HoldT<double>;
+  static void prep(const double* r, int, int, double* kp_out, double* ddef) {
+    KP k;
+    k.qV = r[0] / r[1];
+    k.k01 = r[6];
+    k.nEA1 = -r[5];
+    k.k02 = r[9];
+    k.nEA2 = -r[8];
+    k.h1 = (-r[4]) / (r[2] * r[3]);
+    k.h2 = (-r[7]) / (r[2] * r[3]);
+    k.c2 = r[10] / (r[2] * r[3] * r[1]);
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+    ddef[0] = r[11];
+    ddef[1] = r[12];
+  }
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[0], u[1], u[2]};
+  }
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+    const R ca = x[0], cb = x[1], cc = x[2], T = x[3];
+    const R r1 = k.k01 * exp(k.nEA1 / T) * ca;
+    const R r2 = k.k02 * exp(k.nEA2 / T) * cb;
+    dx[0] = k.qV * (h.Caf - ca) - r1;
+    dx[1] = k.qV * (0.0 - cb) + 2.0 * r1 - r2;
+    dx[2] = k.qV * (0.0 - cc) + r2;
+    dx[3] = k.qV * (h.Ti - T) + (k.h1 * r1 + k.h2 * r2) + k.c2 * (h.Tc - T);
+  }
+};
+
+// disease_model (SIRS with vaccination) -- model_classes.py:156-183.  raw = beta, gamma
+template <>
+struct Model<PCG_MODEL_DISEASE> {
+  static constexpr int NX = 3, NA = 1, NDM = 0, NRAW = 2;
+  static constexpr bool DYNAMIC = false, FULL = false;
+  struct KP {
+    double beta, gamma;
+  };
+  using CKP = const PCG_CONSTANT KP;
+  template <class R>
+  struct HoldT {
+    R u;
+  };
+  using Hold = HoldT<double>;
+  static void prep(const double* r, int, int, double* kp_out, double*) {
+    KP k{r[0], r[1]};
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[0]};
+  }
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+    const R S = x[0], I = x[1];
+    const R inf = k.beta * S * I;
+    dx[0] = -inf - h.u * S;
+    dx[1] = inf - k.gamma * I;
+    dx[2] = k.gamma * I + h.u * S;
+  }
+};
+
+// batch (exothermic consecutive reactions) -- model_classes.py:222-265.
+// raw = k01,k02,EA1,EA2,R,dH1,dH2,rho,Cp,UA,V
+template <>
+struct Model<PCG_MODEL_BATCH> {
+  static constexpr int NX = 4, NA = 1, NDM = 0, NRAW = 11;
+  static constexpr bool DYNAMIC = false, FULL = false;
+  struct KP {
+    double k01, k02, nE1, nE2, g1, g2, c;
+  };
+  using CKP = const PCG_CONSTANT KP;
+  template <class R>
+  struct HoldT {
+    R Tc;
+  };
+  using Hold = HoldT<double>;
+  static void prep(const double* r, int, int, double* kp_out, double*) {
+    KP k;
+    k.k01 = r[0];
+    k.k02 = r[1];
+    k.nE1 = -r[2] / r[4];
+    k.nE2 = -r[3] / r[4];
+    k.g1 = r[5] / (r[7] * r[8]);
+    k.g2 = r[6] / (r[7] * r[8]);
+    k.c = r[9] / (r[7] * r[8] * r[10]);
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[0]};
+  }
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+    const R CA = x[0], CB = x[1], T = x[3];
+    const R r1 = k.k01 * exp(k.nE1 / T) * CA;
+    const R r2 = k.k02 * exp(k.nE2 / T) * CB;
+    dx[0] = -r1;
+    dx[1] = 2.0 * r1 - r2;
+    dx[2] = r2;
+    dx[3] = -(k.g1 * r1 + k.g2 * r2) + k.c * (h.Tc - T);
+  }
+};
+
+// photo_production ("photobioreactor") -- model_classes.py:433-506.
+// raw = u_m,u_d,Y_NX,k_m,k_d,k_sq,K_Nq,k_iq,k_s,k_i,k_N ; u = [I, F_N]
+// the light-dependent factors only depend on the held input: once per env step
+template <>
+struct Model<PCG_MODEL_PHOTO> {
+  static constexpr int NX = 3, NA = 2, NDM = 0, NRAW = 11;
+  static constexpr bool DYNAMIC = false, FULL = false;
+  struct KP {
+    double u_m, u_d, Y_NX, k_m, k_d, k_sq, K_Nq, k_iq, k_s, k_i, k_N;
+  };
+  using CKP = const PCG_CONSTANT KP;
+  template <class R>
+  struct HoldT {
+    R f1, f2, F_N;  // u_m I/(I+k_s+I^2/k_i),  k_m I/(I+k_sq+I^2/k_iq)
+  };
+  using Hold = HoldT<double>;
+  static void prep(const double* r, int, int, double* kp_out, double*) {
+    KP k{r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10]};
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP& k, const R (&u)[NA + NDM]) {
+    const R I = u[0];
+    HoldT<R> h;
+    h.f1 = k.u_m * I / (I + k.k_s + (I * I) / k.k_i);
+    h.f2 = k.k_m * I / (I + k.k_sq + (I * I) / k.k_iq);
+    h.F_N = u[1];
+    return h;
+  }
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+    const R c_x = x[0], c_N = x[1], c_q = x[2];
+    const R g = h.f1 * c_x * c_N / (c_N + k.k_N);
+    dx[0] = g - k.u_d * c_x;
+    dx[1] = -k.Y_NX * g + h.F_N;
+    dx[2] = h.f2 * c_x - (k.k_d * c_q) / (c_N + k.K_Nq);
+  }
+};
+
+// cstr_series_recycle -- model_classes.py:611-679.  raw = C_O,T_O,V1,V2,U1A1,U2A2,rho,cp,k,E,deltaH,R
+// u = [F, L, Tc1, Tc2]
+template <>
+struct Model<PCG_MODEL_CSTR_SERIES> {
+  static constexpr int NX = 4, NA = 4, NDM = 0, NRAW = 12;
+  static constexpr bool DYNAMIC = false, FULL = false;
+  struct KP {
+    double COV1, TOV1, iV1, iV2, c1, c2, k, nER, kh;  // c_i = U_iA_i/(V_i rho cp), kh = k(-dH)/(rho cp)
+  };
+  using CKP = const PCG_CONSTANT KP;
+  template <class R>
+  struct HoldT {
+    R F, L, Tc1, Tc2;
+  };
+  using Hold = HoldT<double>;
+  static void prep(const double* r, int, int, double* kp_out, double*) {
+    KP k;
+    k.COV1 = r[0] / r[2];
+    k.TOV1 = r[1] / r[2];
+    k.iV1 = 1 / r[2];
+    k.iV2 = 1 / r[3];
+    k.c1 = r[4] / (r[2] * r[6] * r[7]);
+    k.c2 = r[5] / (r[3] * r[6] * r[7]);
+    k.k = r[8];
+    k.nER = -r[9] / r[11];
+    k.kh = (r[8] * (-r[10])) / (r[6] * r[7]);
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[0], u[1], u[2], u[3]};
+  }
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+    const R C1 = x[0], T1 = x[1], C2 = x[2], T2 = x[3];
+    const R e1 = exp(k.nER / T1), e2 = exp(k.nER / T2);
+    const R FL = h.F + h.L;
+    dx[0] = k.COV1 * h.F + k.iV1 * h.L * C2 - k.iV1 * FL * C1 - k.k * C1 * e1;
+    dx[1] = k.TOV1 * h.F + k.iV1 * h.L * T2 - k.c1 * (T1 - h.Tc1) - k.iV1 * FL * T1 + k.kh * C1 * e1;
+    dx[2] = k.iV2 * FL * (C1 - C2) - k.k * C2 * e2;
+    dx[3] = k.iV2 * FL * (T1 - T2) - k.c2 * (T2 - h.Tc2) + k.kh * C2 * e2;
+  }
+};
+
+// distillation_column -- model_classes.py:682-760.  raw = D,q,alpha,X_feed,M0,Mb,M ; u = [R, F]
+// x = X0,X1,X2,X3,Xf,X4,X5,X6,Xb
+template <>
+struct Model<PCG_MODEL_DISTILLATION> {
+  static constexpr int NX = 9, NA = 2, NDM = 0, NRAW = 7;
+  static constexpr bool DYNAMIC = false, FULL = false;
+  struct KP {
+    double D, q, alpha, am1, X_feed, iM0, iMb, iM;
+  };
+  using CKP = const PCG_CONSTANT KP;
+  template <class R>
+  struct HoldT {
+    R L, V, Ld, Vd, W, FXf;
+  };
+  using Hold = HoldT<double>;
+  static void prep(const double* r, int, int, double* kp_out, double*) {
+    KP k{r[0], r[1], r[2], r[2] - 1, r[3], 1 / r[4], 1 / r[5], 1 / r[6]};
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP& k, const R (&u)[NA + NDM]) {
+    const R Rr = u[0], F = u[1];
+    HoldT<R> h;
+    h.L = Rr * k.D;
+    h.V = (Rr + 1.0) * k.D;
+    h.Ld = h.L + k.q * F;
+    h.Vd = h.V + (1 - k.q) * F;
+    h.W = F - k.D;
+    h.FXf = F * k.X_feed;
+    return h;
+  }
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+    R Y[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Y[i] = (k.alpha * x[i]) / (1.0 + k.am1 * x[i]);
+    // indices: 0 X0, 1 X1, 2 X2, 3 X3, 4 Xf, 5 X4, 6 X5, 7 X6, 8 Xb
+    dx[0] = k.iM0 * ((h.V * Y[1]) - (h.L + k.D) * x[0]);
+    dx[1] = k.iM * (h.L * (x[0] - x[1]) + h.V * (Y[2] - Y[1]));
+    dx[2] = k.iM * (h.L * (x[1] - x[2]) + h.V * (Y[3] - Y[2]));
+    dx[3] = k.iM * (h.L * (x[2] - x[3]) + h.V * (Y[4] - Y[3]));
+    dx[4] = k.iM * (h.L * x[3] - h.Ld * x[4] + h.Vd * Y[5] - h.V * Y[4] + h.FXf);
+    dx[5] = k.iM * (h.Ld * (x[4] - x[5]) + h.Vd * (Y[6] - Y[5]));
+    dx[6] = k.iM * (h.Ld * (x[5] - x[6]) + h.Vd * (Y[7] - Y[6]));
+    dx[7] = k.iM * (h.Ld * (x[6] - x[7]) + h.Vd * (Y[8] - Y[7]));
+    dx[8] = k.iMb * (h.Ld * x[7] - h.W * x[8] - h.Vd * Y[8]);
+  }
+};
+
+// polymerisation_reactor -- model_classes.py:1158-1229.
+// raw = Ap,Ad,At,Ep_over_R,Ed_over_R,Et_over_R,f,V,deltaHp,rho,cp ; x = T,M,I ; u = [F,Tf,Mf,If]
+template <>
+struct Model<PCG_MODEL_POLYMER> {
+  static constexpr int NX = 3, NA = 4, NDM = 0, NRAW = 11;
+  static constexpr bool DYNAMIC = false, FULL = false;
+  struct KP {
+    double Ap, Ad, At, nEp, nEd, nEt, f, hq, iV;  // hq = (-deltaHp)/(rho cp)
+  };
+  using CKP = const PCG_CONSTANT KP;
+  template <class R>
+  struct HoldT {
+    R FV, Tf, Mf, If;
+  };
+  using Hold = HoldT<double>;
+  static void prep(const double* r, int, int, double* kp_out, double*) {
+    KP k{r[0], r[1], r[2], -r[3], -r[4], -r[5], r[6], (-r[8]) / (r[9] * r[10]), 1 / r[7]};
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  template <class R>
+  PCG_DEV static HoldT<R> hold(CKP& k, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[0] * k.iV, u[1], u[2], u[3]};
+  }
+  template <class R>
+  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+    const R T = x[0], M = x[1], I = x[2];
+    const R kp = k.Ap * exp(k.nEp / T), kd = k.Ad * exp(k.nEd / T), kt = k.At * exp(k.nEt / T);
+    const R ri = 2.0 * k.f * kd * I;
+    const R rp = kp * sqrt((k.f * kd * I) / kt);
+    dx[0] = h.FV * (h.Tf - T) + k.hq * rp;
+    dx[1] = h.FV * (h.Mf - M) - rp;
+    dx[2] = h.FV * (h.If - I) - ri;
   }
 };
 

@@ -11,6 +11,7 @@ from collections import OrderedDict
 
 # ids must match enum pcg_model in include/pcgym_hip.h
 CSTR, FOUR_TANK, ME, ME_REACTIVE, CRYST, AFFINE = range(6)
+COMPLEX_CSTR, DISEASE, BATCH, PHOTO, CSTR_SERIES, DISTILLATION, POLYMER = range(6, 13)
 
 
 class ModelInfo:
@@ -18,7 +19,8 @@ class ModelInfo:
     ``info()`` -> {"parameters","states","inputs","disturbances"} and attribute
     access to parameters (pcgym.py:150-165, 226-238)."""
 
-    def __init__(self, name, model_id, states, inputs, disturbances, params):
+    def __init__(self, name, model_id, states, inputs, disturbances, params, affine_builder=None):
+        self.affine_builder = affine_builder  # registry models whose RHS is affine: params -> (A, B, c)
         self.name = name
         self.model_id = model_id
         self.states = list(states)
@@ -46,7 +48,7 @@ class ModelInfo:
 
     def copy(self):
         return ModelInfo(self.name, self.model_id, self.states, self.inputs, self.disturbances,
-                         self.parameters)
+                         self.parameters, self.affine_builder)
 
 
 def _registry():
@@ -84,6 +86,53 @@ def _registry():
         [("ka", 0.923714966), ("kb", -6754.878558), ("kc", 0.92229965554), ("kd", 1.341205945),
          ("kg", 48.07514464), ("k1", -4921.261419), ("k2", 1.871281405), ("a", 0.50523693),
          ("b", 7.271241375), ("alfa", 7.510905767), ("ro", 2.658)])
+    # ---- "next" row f-2: further registry models (general kernels) --------------------------------
+    # model_classes.py:65-96
+    R["complex_cstr"] = ModelInfo(
+        "complex_cstr", COMPLEX_CSTR, ["Ca", "Cb", "Cc", "T"], ["Tc"], ["Ti", "Caf"],
+        [("q", 100.0), ("V", 100.0), ("rho", 1000.0), ("C", 0.239), ("deltaHr1", -5e4), ("EA1_over_R", 8750.0),
+         ("k01", 7.2e10), ("deltaHr2", -3e4), ("EA2_over_R", 9000.0), ("k02", 1.0e10), ("UA", 5e4),
+         ("Ti", 350.0), ("Caf", 1.0)])
+    # model_classes.py:156-171 (registry key "disease", pcgym.py:146)
+    R["disease"] = ModelInfo("disease", DISEASE, ["S", "I", "R"], ["u"], [], [("beta", 0.3), ("gamma", 0.1)])
+    # model_classes.py:222-246
+    R["batch"] = ModelInfo(
+        "batch", BATCH, ["Ca", "Cb", "Cc", "T"], ["Tc"], [],
+        [("k01", 1.0), ("k02", 0.5), ("EA1", 5000.0), ("EA2", 6000.0), ("R", 8.314), ("dH1", -1000.0),
+         ("dH2", -1500.0), ("rho", 1000.0), ("Cp", 4.0), ("UA", 100.0), ("V", 1.0)])
+    # model_classes.py:443-453, 495-503 (registry key "photobioreactor", pcgym.py:141)
+    R["photobioreactor"] = ModelInfo(
+        "photobioreactor", PHOTO, ["c_x", "c_N", "c_q"], ["I", "F_N"], [],
+        [("u_m", 0.0572), ("u_d", 0.0), ("Y_NX", 504.5), ("k_m", 0.00016), ("k_d", 0.281), ("k_sq", 23.51),
+         ("K_Nq", 16.89), ("k_iq", 800.0), ("k_s", 178.9), ("k_i", 447.1), ("k_N", 393.1)])
+    # model_classes.py:619-630, 672-677
+    R["cstr_series_recycle"] = ModelInfo(
+        "cstr_series_recycle", CSTR_SERIES, ["C1", "T1", "C2", "T2"], ["F", "L", "Tc1", "Tc2"], [],
+        [("C_O", 97.35), ("T_O", 298.0), ("V1", 1e-3), ("V2", 2e-3), ("U1A1", 0.461), ("U2A2", 0.732),
+         ("rho", 1.05e3), ("cp", 3.766), ("k", 3.118e5), ("E", 46.14), ("deltaH", 58.41), ("R", 8.3145e-3)])
+    # model_classes.py:689-695, 753-758
+    R["distillation_column"] = ModelInfo(
+        "distillation_column", DISTILLATION, ["X0", "X1", "X2", "X3", "Xf", "X4", "X5", "X6", "Xb"], ["R", "F"], [],
+        [("D", 100.0), ("q", 1.0), ("alpha", 5.0), ("X_feed", 0.2), ("M0", 2000.0), ("Mb", 2000.0), ("M", 2000.0)])
+    # model_classes.py:1172-1182, 1222-1227
+    R["polymerisation_reactor"] = ModelInfo(
+        "polymerisation_reactor", POLYMER, ["T", "M", "I"], ["F", "Tf", "Mf", "If"], [],
+        [("Ap", 6e10), ("Ad", 4e10), ("At", 9e10), ("Ep_over_R", 7750.0), ("Ed_over_R", 8500.0),
+         ("Et_over_R", 8250.0), ("f", 0.5), ("V", 1.0), ("deltaHp", -3e4), ("rho", 1200.0), ("cp", 2.0)])
+    # registry models whose RHS is affine run on the affine kernel (matrices built here from the parameters)
+    # hydraulic_tank model_classes.py:128-153: dq1 = -D (q1-q2) + u, dq2 = D (q1-q2) - u
+    R["hydraulic_tank"] = ModelInfo(
+        "hydraulic_tank", AFFINE, ["q1", "q2"], ["u"], [], [("D", 1.0)],
+        affine_builder=lambda p: ([[-p["D"], p["D"]], [p["D"], -p["D"]]], [[1.0], [-1.0]], [0.0, 0.0]))
+    # first_order_system model_classes.py:296-343: dx = (K u - x) / tau   ("None" disturbance entry: quirk Q13)
+    R["first_order_system"] = ModelInfo(
+        "first_order_system", AFFINE, ["x"], ["u"], [], [("K", 1.0), ("tau", 0.5)],
+        affine_builder=lambda p: ([[-1.0 / p["tau"]]], [[p["K"] / p["tau"]]], [0.0]))
+    # nonsmooth_control model_classes.py:509-558
+    R["nonsmooth_control"] = ModelInfo(
+        "nonsmooth_control", AFFINE, ["X1", "X2"], ["U"], [],
+        [("a_11", 0.0), ("a_12", 1.0), ("a_21", -2.0), ("a_22", -3.0), ("b_1", 0.0), ("b_2", 1.0)],
+        affine_builder=lambda p: ([[p["a_11"], p["a_12"]], [p["a_21"], p["a_22"]]], [[p["b_1"]], [p["b_2"]]], [0.0, 0.0]))
     return R
 
 
@@ -92,10 +141,10 @@ _REGISTRY = _registry()
 # registry keys of the reference (pcgym.py:128-148) that are NOT built yet:
 # asking for them is an explicit error, never a silent CPU fallback.
 NOT_BUILT = [
-    "complex_cstr", "first_order_system", "nonsmooth_control", "cstr_series_recycle",
-    "distillation_column", "heat_exchanger", "biofilm_reactor", "polymerisation_reactor",
-    "photobioreactor", "invariant_batch", "batch", "coupled_oscillator", "disease",
-    "hydraulic_tank",
+    "heat_exchanger",      # 24 states  > PCG_MAX_NX
+    "biofilm_reactor",     # 5 inputs   > PCG_MAX_NA
+    "invariant_batch",     # no inputs
+    "coupled_oscillator",  # no inputs, 20 states
 ]
 
 

@@ -124,7 +124,7 @@ def tight_step(model, x, u, dt):
 
 
 # ---------------------------------------------------------------------------
-def gen_rhs_and_tight(M, out):
+def gen_rhs_and_tight(M, out, only_new=False):
     rng = np.random.default_rng(20260928)
 
     def cryst_x(n):
@@ -163,8 +163,43 @@ def gen_rhs_and_tight(M, out):
         "crystallization": (lambda: M.crystallization(int_method="casadi"),
                             cryst_x, lambda n: rng.uniform(10, 40, (n, 1)), 1.0),
     }
+    # ---- "next" row f-2 models (appended: the draws of the entries above are unchanged) ----
+    def col(*ranges):
+        return lambda n: np.column_stack([rng.uniform(a, b, n) for a, b in ranges])
+
+    def distill_x(n):
+        base = np.array([0.95, 0.9, 0.8, 0.65, 0.5, 0.35, 0.2, 0.1, 0.05])
+        return np.clip(base * (1 + 0.2 * rng.uniform(-1, 1, (n, 9))), 0.01, 0.99)
+
+    specs.update({
+        "complex_cstr": (lambda: M.complex_cstr(int_method="casadi"),
+                         col((0.5, 1.0), (0.0, 0.5), (0.0, 0.3), (310, 340)), col((295, 302)), 26.0 / 60.0),
+        "complex_cstr_d": (lambda: M.complex_cstr(int_method="casadi"),
+                           col((0.5, 1.0), (0.0, 0.5), (0.0, 0.3), (310, 335)),
+                           col((295, 302), (330, 355), (0.9, 1.1)), 26.0 / 60.0),
+        "disease": (lambda: M.disease_model(int_method="casadi"),
+                    col((0.3, 0.9), (0.01, 0.3), (0.0, 0.3)), col((0.0, 0.1)), 1.0),
+        "batch": (lambda: M.batch(int_method="casadi"),
+                  col((0.3, 1.0), (0.0, 0.5), (0.0, 0.3), (300, 400)), col((290, 350)), 0.5),
+        "photobioreactor": (lambda: M.photo_production(int_method="casadi"),
+                            col((0.5, 3.0), (50, 800), (0.0, 0.02)), col((120, 400), (0, 40)), 20.0),
+        "cstr_series_recycle": (lambda: M.cstr_series_recycle(int_method="casadi"),
+                                col((20, 90), (300, 340), (20, 90), (300, 340)),
+                                col((1e-5, 5e-5), (1e-5, 5e-5), (290, 310), (290, 310)), 5.0),
+        "distillation_column": (lambda: M.distillation_column(int_method="casadi"),
+                                distill_x, col((1.0, 5.0), (150, 400)), 1.0),
+        "polymerisation_reactor": (lambda: M.polymerisation_reactor(int_method="casadi"),
+                                   col((300, 345), (1.0, 8.0), (0.01, 0.5)),
+                                   col((0.001, 0.01), (290, 330), (4.0, 8.0), (0.2, 0.6)), 1.0),
+        "hydraulic_tank": (lambda: M.hydraulic_tank(int_method="casadi"), col((0, 2), (0, 2)), col((-1, 1)), 0.5),
+        "first_order_system": (lambda: M.first_order_system(int_method="casadi"), col((-2, 2)), col((-1, 1)), 0.5),
+        "nonsmooth_control": (lambda: M.nonsmooth_control(int_method="casadi"), col((-2, 2), (-2, 2)), col((-1, 1)), 0.5),
+    })
     n_rhs, n_tight = 64, 24
     for name, (ctor, xs, us, dt) in specs.items():
+        if only_new and os.path.exists(os.path.join(out, f"rhs_{name}.npz")):
+            rng_state = xs(n_rhs), us(n_rhs)  # keep the generator stream identical to a full run
+            continue
         X = xs(n_rhs)
         U = us(n_rhs)
         DX = np.stack([np.asarray(ctor()(X[i].copy(), U[i].copy()), dtype=np.float64) for i in range(n_rhs)])
@@ -218,12 +253,14 @@ def gen_paper(out):
         print(f"  paper {name}: x{x.shape} u{u.shape}")
 
 
-def gen_steps(P, out):
+def gen_steps(P, out, only_new=False):
     sys.path.insert(0, HERE)
     import scenarios as SC
 
     P.integration_engine = _TightEngine
     for name, sc in SC.scenarios().items():
+        if only_new and os.path.exists(os.path.join(out, f"step_{name}.npz")):
+            continue
         p = sc["env_params"]
         A = SC.actions_for(name, sc)
         np.random.seed(12345)  # only matters for action_space.sample() in _setup_constraints
@@ -255,9 +292,11 @@ def gen_steps(P, out):
 def main():
     P, M = _import_reference()
     out = HERE
-    print("RHS + tight steps"); gen_rhs_and_tight(M, out)
-    print("paper trajectories"); gen_paper(out)
-    print("full-step tuples"); gen_steps(P, out)
+    only_new = "--only-new" in sys.argv  # keep committed fixtures untouched, add the missing ones
+    print("RHS + tight steps"); gen_rhs_and_tight(M, out, only_new)
+    if not only_new:
+        print("paper trajectories"); gen_paper(out)
+    print("full-step tuples"); gen_steps(P, out, only_new)
     tot = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out) if f.endswith(".npz"))
     print(f"total fixture bytes: {tot}")
 

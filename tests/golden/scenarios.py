@@ -253,6 +253,33 @@ def scenarios():
     p.update(partial_observation=["Ca"])
     S["cstr_partial_obs"] = dict(env_params=p, steps=20, action_seed=14)
 
+    # ---- "next" row f-2 models ------------------------------------------------------------------
+    S["complex_cstr_sp"] = dict(env_params={
+        "N": 40, "tsim": 40 * 26.0 / 60.0, "SP": {"Cb": _halves(40, 0.3, 0.4)},
+        "o_space": {"low": np.array([0.0, 0.0, 0.0, 300.0, 0.0]), "high": np.array([1.0, 1.0, 1.0, 350.0, 1.0])},
+        "a_space": {"low": np.array([295.0]), "high": np.array([302.0])},
+        "x0": np.array([0.8, 0.1, 0.05, 325.0, 0.3]), "r_scale": {"Cb": 1e2}, "model": "complex_cstr"},
+        steps=39, action_seed=21)
+    S["photo_batch_reward"] = dict(env_params={   # terminal ("batch") reward, maximise the product c_q
+        "N": 12, "tsim": 240, "reward_states": ["c_q"], "maximise_reward": True,
+        "o_space": {"low": np.array([0.0, 0.0, 0.0]), "high": np.array([10.0, 1000.0, 0.05])},
+        "a_space": {"low": np.array([120.0, 0.0]), "high": np.array([400.0, 40.0])},
+        "x0": np.array([1.0, 150.0, 0.0]), "model": "photobioreactor"},
+        steps=11, action_seed=22)
+    S["distillation_sp"] = dict(env_params={
+        "N": 30, "tsim": 30.0, "SP": {"X0": _halves(30, 0.95, 0.9)},
+        "o_space": {"low": np.array([0.0] * 9 + [0.8]), "high": np.array([1.0] * 9 + [1.0])},
+        "a_space": {"low": np.array([1.0, 150.0]), "high": np.array([5.0, 400.0])},
+        "x0": np.array([0.95, 0.9, 0.8, 0.65, 0.5, 0.35, 0.2, 0.1, 0.05, 0.95]), "r_scale": {"X0": 1e2},
+        "model": "distillation_column"},
+        steps=29, action_seed=23)
+    S["first_order_sp"] = dict(env_params={
+        "N": 30, "tsim": 6.0, "SP": {"x": _halves(30, 0.5, -0.25)},
+        "o_space": {"low": np.array([-2.0, -2.0]), "high": np.array([2.0, 2.0])},
+        "a_space": {"low": np.array([-1.5]), "high": np.array([1.5])},
+        "x0": np.array([0.0, 0.5]), "model": "first_order_system"},
+        steps=29, action_seed=24)
+
     # the reference's own known-answer test (custom linear model)
     S["custom_linear_kat"] = dict(
         env_params={

@@ -42,6 +42,10 @@ TIGHT = {
     "multistage_extraction_reactive": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
     "crystallization": dict(integrator="rk4", substeps=512),
     None: dict(integrator="rk4", substeps=64),
+    "complex_cstr": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
+    "photobioreactor": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
+    "distillation_column": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
+    "first_order_system": dict(integrator="rk4", substeps=64),
 }
 
 

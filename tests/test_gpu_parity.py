@@ -45,7 +45,13 @@ RHS_CASES = [("cstr", "cstr"), ("cstr_d", "cstr"), ("four_tank", "four_tank"),
              ("multistage_extraction", "multistage_extraction"),
              ("multistage_extraction_d", "multistage_extraction"),
              ("multistage_extraction_reactive", "multistage_extraction_reactive"),
-             ("crystallization", "crystallization")]
+             ("crystallization", "crystallization"),
+             # "next" row f-2 models
+             ("complex_cstr", "complex_cstr"), ("complex_cstr_d", "complex_cstr"), ("disease", "disease"),
+             ("batch", "batch"), ("photobioreactor", "photobioreactor"),
+             ("cstr_series_recycle", "cstr_series_recycle"), ("distillation_column", "distillation_column"),
+             ("polymerisation_reactor", "polymerisation_reactor"), ("hydraulic_tank", "hydraulic_tank"),
+             ("first_order_system", "first_order_system"), ("nonsmooth_control", "nonsmooth_control")]
 
 
 def _plan_for(spec, torch):
@@ -76,8 +82,11 @@ def test_rhs_vs_reference_and_oracle(fix, model):
     torch.cuda.synchronize()
     got = dx.cpu().numpy().T
     lib.pcg_plan_destroy(plan)
-    want_ref = g["dx"]
-    want_orc = O.rhs(mi.model_id, mi.param_vector(), g["x"].T, g["u"].T).T
+    want_ref = g["dx"].reshape(g["x"].shape[0], -1)
+    from test_oracle_golden import _model_params
+
+    mid, pv = _model_params(model)
+    want_orc = O.rhs(mid, pv, g["x"].T, g["u"].T).T
     scale = np.maximum(np.abs(want_ref), 1e-3 * np.max(np.abs(want_ref), axis=0, keepdims=True))
     assert np.max(np.abs(got - want_orc) / scale) <= 1e-12
     assert np.max(np.abs(got - want_ref) / scale) <= 1e-12
@@ -97,6 +106,17 @@ INT_CASES = [
     ("multistage_extraction_reactive", "multistage_extraction_reactive", dict(integrator="rk4", substeps=64), 1e-12),
     ("crystallization", "crystallization", dict(integrator="rk4", substeps=32), 1e-11),
     ("crystallization", "crystallization", dict(integrator="dopri5"), 1e-9),
+    # "next" row f-2 models
+    ("complex_cstr", "complex_cstr", dict(integrator="rk4", substeps=8), 1e-12),
+    ("complex_cstr_d", "complex_cstr", dict(integrator="dopri5"), 1e-9),
+    ("disease", "disease", dict(integrator="rk4", substeps=4), 1e-12),
+    ("batch", "batch", dict(integrator="dopri5"), 1e-9),
+    ("photobioreactor", "photobioreactor", dict(integrator="rk4", substeps=16), 1e-12),
+    ("cstr_series_recycle", "cstr_series_recycle", dict(integrator="dopri5"), 1e-9),
+    ("distillation_column", "distillation_column", dict(integrator="rk4", substeps=8), 1e-12),
+    ("polymerisation_reactor", "polymerisation_reactor", dict(integrator="dopri5"), 1e-9),
+    ("hydraulic_tank", "hydraulic_tank", dict(integrator="rk4", substeps=8), 1e-12),
+    ("nonsmooth_control", "nonsmooth_control", dict(integrator="dopri5"), 1e-9),
 ]
 
 
@@ -118,6 +138,8 @@ def test_integrate_vs_oracle(fix, model, kw, tol, lds_stages):
     ok = np.ones(g["x"].shape[0], dtype=bool)
     if model == "cstr" and kw["integrator"] == "rk4":
         ok = g["xf"][:, 1] < 360.0  # ignition samples diverge under fixed-step RK4 on CPU and GPU alike
+    if model == "complex_cstr" and kw["integrator"] == "rk4":
+        ok = g["xf"][:, 3] < 360.0
     xs, us = g["x"][ok].T.copy(), g["u"][ok].T.copy()
     x = torch.tensor(xs, device="cuda")
     u = torch.tensor(us, device="cuda")

@@ -18,17 +18,33 @@ RHS_CASES = [
     ("cstr", "cstr"), ("cstr_d", "cstr"), ("four_tank", "four_tank"),
     ("multistage_extraction", "multistage_extraction"), ("multistage_extraction_d", "multistage_extraction"),
     ("multistage_extraction_reactive", "multistage_extraction_reactive"), ("crystallization", "crystallization"),
+    # "next" row f-2 models
+    ("complex_cstr", "complex_cstr"), ("complex_cstr_d", "complex_cstr"), ("disease", "disease"), ("batch", "batch"),
+    ("photobioreactor", "photobioreactor"), ("cstr_series_recycle", "cstr_series_recycle"),
+    ("distillation_column", "distillation_column"), ("polymerisation_reactor", "polymerisation_reactor"),
+    ("hydraulic_tank", "hydraulic_tank"), ("first_order_system", "first_order_system"),
+    ("nonsmooth_control", "nonsmooth_control"),
 ]
+
+
+def _model_params(model):
+    """(model_id, parameter vector) -- affine registry models carry host-built A|B|c"""
+    mi = M.get_model(model)
+    if mi.affine_builder is not None:
+        A, B, c = (np.asarray(v, dtype=np.float64) for v in mi.affine_builder(mi.parameters))
+        return mi.model_id, np.concatenate([np.atleast_2d(A).reshape(-1), np.atleast_2d(B).reshape(-1), c.reshape(-1)])
+    return mi.model_id, mi.param_vector()
 
 
 @pytest.mark.parametrize("fix,model", RHS_CASES)
 def test_rhs_matches_reference(fix, model):
     g = H.gold("rhs_" + fix)
-    mi = M.get_model(model)
-    dx = O.rhs(mi.model_id, mi.param_vector(), g["x"].T, g["u"].T).T
-    scale = np.max(np.abs(g["dx"]), axis=0, keepdims=True)
+    mid, pv = _model_params(model)
+    dx = O.rhs(mid, pv, g["x"].T, g["u"].T).T
+    gdx = g["dx"].reshape(g["x"].shape[0], -1)  # nonsmooth_control returns (2,1) in the reference (b*u with array u)
+    scale = np.max(np.abs(gdx), axis=0, keepdims=True)
     # same expression order as the reference: agreement to a few ulp (pow/exp of libm vs numpy)
-    assert np.all(np.abs(dx - g["dx"]) <= 2e-14 * np.maximum(np.abs(g["dx"]), 1e-3 * scale))
+    assert np.all(np.abs(dx - gdx) <= 2e-14 * np.maximum(np.abs(gdx), 1e-3 * scale))
 
 
 def _spec_for_integration(model, dt, nu, **kw):
@@ -56,6 +72,18 @@ TIGHT_CASES = [
     ("multistage_extraction_reactive", "multistage_extraction_reactive", 1e-6,
      dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
     ("crystallization", "crystallization", 1e-6, dict(integrator="rk4", substeps=512), 1e-9),
+    # "next" row f-2 models: adaptive by default
+    ("complex_cstr", "complex_cstr", 2e-6, dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
+    ("complex_cstr_d", "complex_cstr", 2e-6, dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
+    ("disease", "disease", 1e-6, dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
+    ("batch", "batch", 1e-6, dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
+    ("photobioreactor", "photobioreactor", 1e-6, dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
+    ("cstr_series_recycle", "cstr_series_recycle", 1e-6, dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
+    ("distillation_column", "distillation_column", 1e-6, dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
+    ("polymerisation_reactor", "polymerisation_reactor", 2e-6, dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
+    ("hydraulic_tank", "hydraulic_tank", 1e-6, dict(integrator="rk4", substeps=512), 1e-9),
+    ("first_order_system", "first_order_system", 1e-5, dict(integrator="rk4", substeps=512), 1e-9),
+    ("nonsmooth_control", "nonsmooth_control", 1e-5, dict(integrator="rk4", substeps=512), 1e-9),
 ]
 
 
