@@ -70,7 +70,10 @@ struct Model<PCG_MODEL_CSTR> {
   template <class R>
   PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const R ca = x[0], T = x[1];
-    const R rA = k.k0 * exp(k.nEAR / T) * ca;
+    // Arrhenius factor: the exponent -EA/(R T) lies in (-700, 0) for any T > 12.5 K, so the bounded
+    // exp and the Newton divide apply (quotient to ~0.5 ulp: the exponent is O(30), an ulp there is
+    // 3e-15 on rA, which the T balance amplifies ~100x by cancellation -- parity bar 1e-12)
+    const R rA = k.k0 * exp_bounded(div_fast(k.nEAR, T)) * ca;
     dx[0] = k.qV * (h.Caf - ca) - rA;
     dx[1] = k.qV * (h.Ti - T) + k.c1 * rA + k.c2 * (h.Tc - T);
   }
@@ -292,8 +295,8 @@ struct Model<PCG_MODEL_CRYST> {
     // reference's three pow() (model_classes.py:1299-1300) -- a third of the instructions; the exponent
     // is O(30), so the result is within ~1e-14 relative of the pow form (parity bar 1e-12).
     const R L1 = log(S2), L3 = log(mu3 * mu3);
-    const R B0 = h.eB * exp(k.kc2 * L1 + k.kd2 * L3);
-    const R Ginf = h.eG * exp(k.k22 * L1);
+    const R B0 = h.eB * exp_bounded(k.kc2 * L1 + k.kd2 * L3);
+    const R Ginf = h.eG * exp_bounded(k.k22 * L1);
     const R m12 = k.a * mu1 * 1e-4 + k.b * mu2 * 1e-8;
     const R m23 = k.a * mu2 * 1e-8 + k.b * mu3 * 1e-12;
     const R d0 = B0;
@@ -301,15 +304,16 @@ struct Model<PCG_MODEL_CRYST> {
     const R d2 = 2.0 * Ginf * m12 * 1e8;
     const R d3 = 3.0 * Ginf * m23 * 1e12;
     const R mu1sq = mu1 * mu1;
-    const R CV = sqrt(mu2 * mu0 / mu1sq - 1.0);
+    const R CV = sqrt(div_fast(mu2 * mu0, mu1sq) - 1.0);
     dx[0] = d0;
     dx[1] = d1;
     dx[2] = d2;
     dx[3] = d3;
     dx[4] = k.cc * Ginf * m23;
-    dx[5] = 1.0 / (2.0 * CV + 1e-10) * ((d2 * mu0 + mu2 * d0) * mu1sq - mu2 * mu0 * 2.0 * mu1 * d1) /
-            (mu1sq * mu1sq + 1e-10);
-    dx[6] = (d1 * mu0 - mu1 * d0) / (mu0 * mu0 + 1e-10);
+    // one divide for the two denominators of dCV/dt (model_classes.py:1314), Newton divides throughout
+    dx[5] = div_fast((d2 * mu0 + mu2 * d0) * mu1sq - mu2 * mu0 * 2.0 * mu1 * d1,
+                     (2.0 * CV + 1e-10) * (mu1sq * mu1sq + 1e-10));
+    dx[6] = div_fast(d1 * mu0 - mu1 * d0, mu0 * mu0 + 1e-10);
   }
 };
 
@@ -408,8 +412,8 @@ struct Model<PCG_MODEL_COMPLEX_CSTR> {
   template <class R>
   PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const R ca = x[0], cb = x[1], cc = x[2], T = x[3];
-    const R r1 = k.k01 * exp(k.nEA1 / T) * ca;
-    const R r2 = k.k02 * exp(k.nEA2 / T) * cb;
+    const R r1 = k.k01 * exp_bounded(div_fast(k.nEA1, T)) * ca;
+    const R r2 = k.k02 * exp_bounded(div_fast(k.nEA2, T)) * cb;
     dx[0] = k.qV * (h.Caf - ca) - r1;
     dx[1] = k.qV * (0.0 - cb) + 2.0 * r1 - r2;
     dx[2] = k.qV * (0.0 - cc) + r2;

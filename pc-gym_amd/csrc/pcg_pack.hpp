@@ -77,6 +77,75 @@ PCG_PACK_FN1(sqrt)
 PCG_PACK_FN1(fabs)
 #undef PCG_PACK_FN1
 
+// ---- fast fp64 helpers for arguments of known range (no special-case handling) -------------------
+// 1/x: hardware estimate + two Newton steps, ~1 ulp; x finite, normal, non-zero.  6 VALU instructions
+// against 11 for the IEEE divide sequence (div_scale x2, rcp, 5 fma, div_fmas, div_fixup).
+PCG_PK double rcp_fast(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+// a/b to ~0.5 ulp: Newton reciprocal, then one residual correction of the quotient (8 instructions)
+PCG_PK double div_fast(double a, double b) {
+  const double r = rcp_fast(b);
+  double q = a * r;
+  q = __builtin_fma(__builtin_fma(-b, q, a), r, q);
+  return q;
+}
+// exp(x) for x in [-745, 700] (clamped below): Cody-Waite reduction by ln2 and a degree-13 Taylor
+// polynomial on |r| <= ln2/2 (truncation 4e-18), ~1-2 ulp.  20 VALU instructions against ~30 for the
+// library exp(), whose extra work is overflow / underflow / NaN selection.
+PCG_PK double exp_bounded(double x) {
+  x = __builtin_fmax(x, -745.0);
+  const double n = __builtin_rint(x * 1.44269504088896338700e+00);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;             // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878681e-09);   // 1/12!
+  p = __builtin_fma(p, r, 2.505210838544172e-08);  // 1/11!
+  p = __builtin_fma(p, r, 2.755731922398589e-07);  // 1/10!
+  p = __builtin_fma(p, r, 2.7557319223985893e-06); // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873e-05);   // 1/8!
+  p = __builtin_fma(p, r, 1.984126984126984e-04);  // 1/7!
+  p = __builtin_fma(p, r, 1.388888888888889e-03);  // 1/6!
+  p = __builtin_fma(p, r, 8.333333333333333e-03);  // 1/5!
+  p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/4!
+  p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)n);
+}
+template <int W>
+PCG_PK Pack<W> rcp_fast(const Pack<W>& a) {
+  Pack<W> r;
+#pragma unroll
+  for (int i = 0; i < W; ++i) r.v[i] = rcp_fast(a.v[i]);
+  return r;
+}
+template <int W>
+PCG_PK Pack<W> div_fast(const Pack<W>& a, const Pack<W>& b) {
+  Pack<W> r;
+#pragma unroll
+  for (int i = 0; i < W; ++i) r.v[i] = div_fast(a.v[i], b.v[i]);
+  return r;
+}
+template <int W>
+PCG_PK Pack<W> div_fast(double a, const Pack<W>& b) {
+  Pack<W> r;
+#pragma unroll
+  for (int i = 0; i < W; ++i) r.v[i] = div_fast(a, b.v[i]);
+  return r;
+}
+template <int W>
+PCG_PK Pack<W> exp_bounded(const Pack<W>& a) {
+  Pack<W> r;
+#pragma unroll
+  for (int i = 0; i < W; ++i) r.v[i] = exp_bounded(a.v[i]);
+  return r;
+}
+
 template <int W>
 PCG_PK Pack<W> pow(const Pack<W>& a, double e) {
   Pack<W> r;
