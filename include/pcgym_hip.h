@@ -48,8 +48,9 @@ extern "C" {
 #define PCG_MAX_NDM 4     /* model disturbance inputs */
 #define PCG_MAX_NSP 4     /* set-point keys           */
 #define PCG_MAX_NCON 8    /* constraint rows          */
+#define PCG_MAX_NUNC 8    /* uncertain parameters     */
 #define PCG_MAX_PARAMS 128
-#define PCG_MAX_NOBS (PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM)
+#define PCG_MAX_NOBS (PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + PCG_MAX_NUNC)
 #define PCG_MAX_NU (PCG_MAX_NA + PCG_MAX_NDM)
 #define PCG_MAX_N 4096    /* episode length (schedule rows staged in LDS) */
 
@@ -108,7 +109,7 @@ enum pcg_integrator {
                                        re-"de-normalised" state/input, pcgym.py:597-608)       */
 #define PCG_F_GAUSS_DIST 0x0200u    /* extension: d = d_sched + d_sigma*z, z~N(0,1) Philox,
                                        clipped to [d_clip_lo,d_clip_hi] (BASELINE configs[4])  */
-#define PCG_F_X0_NORMAL 0x0400u     /* reset-time x0 uncertainty is normal (else uniform),
+#define PCG_F_X0_NORMAL 0x0400u     /* reset-time x0 / parameter uncertainty is normal (else uniform),
                                        pcgym.py:255-261                                        */
 
 /*
@@ -118,7 +119,11 @@ enum pcg_integrator {
  *
  * Layout of one env's "state"/observation vector, as in the reference
  * (pcgym.py:160-165,291-298,409-410,432-438):
- *      [ x(0..nx) | SP slot (nsp_obs) | configured disturbances (nd) ]  Nobs = nx+nsp_obs+nd
+ *      [ x(0..nx) | SP slot (nsp_obs) | configured disturbances (nd) | uncertain parameters (nunc) ]
+ *                                                                   Nobs = nx+nsp_obs+nd+nunc
+ *      (reset order of the reference, pcgym.py:291-316; with disturbances AND parameter uncertainty the
+ *      reference's step() writes the disturbance slots at a different offset -- quirk Q11 -- that
+ *      combination is rejected)
  * and of the model input vector (pcgym.py:371,386-404):
  *      uk = [ action (na) | model disturbance inputs (ndm) ]            Nu = na+ndm
  */
@@ -136,6 +141,7 @@ typedef struct pcg_env_cfg {
                              (pcgym.py:438 assigns into an empty slice), as in its own KAT      */
   int32_t ncon;           /* constraint rows (reference: n_con)                         */
   int32_t nrew;           /* batch reward: number of reward states                      */
+  int32_t nunc;           /* uncertain model parameters sampled per env at reset (pcgym.py:301-310) */
   int32_t N;              /* episode length (reference: N); done when t == N-1          */
   int32_t substeps;       /* RK4 sub-steps per env step (>=1)                           */
   int32_t max_steps;      /* DOPRI5: step budget per env step (accepted+rejected)       */
@@ -171,6 +177,8 @@ typedef struct pcg_env_cfg {
                              (pcgym.py:560-577, docs/guides/constraints.md:35-51)       */
   const double* con_b;    /* [ncon]                                                     */
   const double* noise_pct;/* [nx] per-state noise fraction (pcgym.py:454-466)           */
+  const int32_t* unc_index; /* [nunc] index of each uncertain parameter in `params`       */
+  const double* unc_pct;  /* [nunc] uncertainty fraction (uniform half-width / normal sigma, pcgym.py:255-261) */
 } pcg_env_cfg;
 
 /*
@@ -194,6 +202,8 @@ typedef struct pcg_buffers {
   double* g_pre;      /* [ncon][B]  out|NULL rows of the pre-step check the reference runs when
                                             t==0 (pcgym.py:416-420); untouched for other t      */
   int32_t* nsteps;    /* [2][B]     out|NULL DOPRI5 accepted / rejected step counts             */
+  double* p_unc;      /* [nunc][B]  in/out  per-env values of the uncertain parameters: written by
+                                            pcg_reset, read by pcg_step (required when nunc > 0)        */
 } pcg_buffers;
 
 typedef struct pcg_plan pcg_plan; /* opaque */

@@ -93,7 +93,8 @@ class OracleEnv:
         self.rew = np.zeros(B)
         self.done = np.zeros(B, dtype=np.uint8)
         self.viol = np.zeros(B, dtype=np.uint8)
-        self.slots = np.zeros((max(s.nsp + s.nd, 1), B))
+        self.slots = np.zeros((max(s.nsp + s.nd + s.nunc, 1), B))
+        self.p_unc = np.zeros((s.nunc, B)) if s.nunc else None
         self.a_save = np.zeros((s.na, B)) if s.a_delta else None
         self.g = np.zeros((s.ncon, B)) if s.ncon else None
         self.g_pre = np.zeros((s.ncon, B)) if s.ncon else None
@@ -104,6 +105,7 @@ class OracleEnv:
         b.x, b.obs, b.rew, b.done, b.viol = _p(self.x), _p(self.obs), _p(self.rew), _p(self.done), _p(self.viol)
         b.a_save, b.g, b.g_pre, b.t, b.nsteps = (_p(self.a_save), _p(self.g), _p(self.g_pre), _p(self.t_env),
                                                  _p(self.nsteps))
+        b.p_unc = _p(self.p_unc)
 
     def _seed(self):
         return (self.seed0 + self.episode) & 0xFFFFFFFFFFFFFFFF

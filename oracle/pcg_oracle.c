@@ -479,7 +479,7 @@ typedef struct {
   int32_t t;       /* in/out */
 } orc_env;
 
-static int cfg_nobs(const pcg_env_cfg* c) { return c->nx + c->nsp_obs + c->nd; }
+static int cfg_nobs(const pcg_env_cfg* c) { return c->nx + c->nsp_obs + c->nd + c->nunc; }
 static int cfg_nu(const pcg_env_cfg* c) { return c->na + c->ndm; }
 
 /* constraint_check + con_checker, pcgym.py:580-615, 560-577.
@@ -524,7 +524,7 @@ typedef struct {
 } orc_out;
 
 static void env_step(const pcg_env_cfg* c, orc_env* e, const double* action_in, const double* d_env,
-                     uint64_t seed, uint64_t env_id, orc_out* o) {
+                     uint64_t seed, uint64_t env_id, orc_out* o, const double* params) {
   int nx = c->nx, na = c->na, nsp = c->nsp, nd = c->nd, ndm = c->ndm;
   int nobs = cfg_nobs(c), nu = cfg_nu(c);
   double action[PCG_MAX_NA];
@@ -573,7 +573,7 @@ static void env_step(const pcg_env_cfg* c, orc_env* e, const double* action_in, 
     if (v && (c->flags & PCG_F_DONE_ON_CONS)) done = 1;
   }
   /* integrate :423-429 */
-  orc_model m = {c->model_id, nx, nu, c->params};
+  orc_model m = {c->model_id, nx, nu, params}; /* per-env parameters when uncertain (pcgym.py:301-310) */
   o->nacc = o->nrej = 0;
   if (c->integrator_id == PCG_INT_RK4) rk4(&m, e->state, uk, c->dt, c->substeps);
   else dopri5(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
@@ -636,6 +636,13 @@ static void env_reset(const pcg_env_cfg* c, orc_env* e, uint64_t seed, uint64_t 
         e->state[i] = c->x0[i] * (1 + pct * (2.0 * rng_uniform(seed, env_id, 0u, ORC_RNG_RESET, i) - 1.0));
     }
   for (int k = 0; k < nd; ++k) e->state[nx + nsp + k] = c->d_sched[(size_t)k * c->N + 0]; /* :291-298 (Q6: index 0) */
+  for (int j = 0; j < c->nunc; ++j) { /* :301-310, apply_uncertainties :255-261 */
+    double orig = c->params[c->unc_index[j]], pct = c->unc_pct[j], v;
+    int ri = nx + j;
+    if (c->flags & PCG_F_X0_NORMAL) v = orig + pct * orig * rng_normal(seed, env_id, 0u, ORC_RNG_RESET, ri);
+    else v = orig * (1 + pct * (2.0 * rng_uniform(seed, env_id, 0u, ORC_RNG_RESET, ri) - 1.0));
+    e->state[nx + nsp + nd + j] = v;
+  }
   if (c->flags & PCG_F_A_DELTA) /* :319-320 */
     for (int i = 0; i < c->na; ++i) e->a_save[i] = c->a_0[i];
   for (int i = 0; i < nobs; ++i) obs[i] = e->state[i];
@@ -694,7 +701,14 @@ ORC_EXPORT int orc_step(const pcg_env_cfg* c, const pcg_buffers* io, double* slo
     double state[PCG_MAX_NOBS], asave[PCG_MAX_NA], act[PCG_MAX_NA], denv[PCG_MAX_NDM];
     double obs[PCG_MAX_NOBS], g[PCG_MAX_NCON], gp[PCG_MAX_NCON];
     for (int i = 0; i < nx; ++i) state[i] = io->x[(size_t)i * B + b];
-    for (int i = 0; i < nsp + nd; ++i) state[nx + i] = slots ? slots[(size_t)i * B + b] : 0.0;
+    for (int i = 0; i < nsp + nd + c->nunc; ++i) state[nx + i] = slots ? slots[(size_t)i * B + b] : 0.0;
+    double params[PCG_MAX_PARAMS];
+    for (int i = 0; i < c->n_params; ++i) params[i] = c->params[i];
+    for (int j = 0; j < c->nunc; ++j) {
+      double v = io->p_unc[(size_t)j * B + b];
+      params[c->unc_index[j]] = v;
+      state[nx + nsp + nd + j] = v;
+    }
     for (int i = 0; i < na; ++i) act[i] = io->a[(size_t)i * B + b];
     if (io->a_save)
       for (int i = 0; i < na; ++i) asave[i] = io->a_save[(size_t)i * B + b];
@@ -706,10 +720,10 @@ ORC_EXPORT int orc_step(const pcg_env_cfg* c, const pcg_buffers* io, double* slo
     o.g = g;
     o.g_pre = gp;
     int t_old = e.t;
-    env_step(c, &e, act, io->d ? denv : NULL, seed, (uint64_t)(env_offset + b), &o);
+    env_step(c, &e, act, io->d ? denv : NULL, seed, (uint64_t)(env_offset + b), &o, params);
     for (int i = 0; i < nx; ++i) io->x[(size_t)i * B + b] = state[i];
     if (slots)
-      for (int i = 0; i < nsp + nd; ++i) slots[(size_t)i * B + b] = state[nx + i];
+      for (int i = 0; i < nsp + nd + c->nunc; ++i) slots[(size_t)i * B + b] = state[nx + i];
     if (io->a_save)
       for (int i = 0; i < na; ++i) io->a_save[(size_t)i * B + b] = asave[i];
     if (io->t) io->t[b] = e.t;
@@ -737,7 +751,8 @@ ORC_EXPORT int orc_reset(const pcg_env_cfg* c, const pcg_buffers* io, double* sl
     env_reset(c, &e, seed, (uint64_t)(env_offset + b), obs);
     for (int i = 0; i < nx; ++i) io->x[(size_t)i * B + b] = state[i];
     if (slots)
-      for (int i = 0; i < nsp + nd; ++i) slots[(size_t)i * B + b] = state[nx + i];
+      for (int i = 0; i < nsp + nd + c->nunc; ++i) slots[(size_t)i * B + b] = state[nx + i];
+    for (int j = 0; j < c->nunc; ++j) io->p_unc[(size_t)j * B + b] = state[nx + nsp + nd + j];
     if (io->a_save && (c->flags & PCG_F_A_DELTA))
       for (int i = 0; i < na; ++i) io->a_save[(size_t)i * B + b] = asave[i];
     if (io->t) io->t[b] = 0;

@@ -13,8 +13,9 @@ PCG_MAX_NA = 4
 PCG_MAX_NDM = 4
 PCG_MAX_NSP = 4
 PCG_MAX_NCON = 8
+PCG_MAX_NUNC = 8
 PCG_MAX_PARAMS = 128
-PCG_MAX_NOBS = PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM
+PCG_MAX_NOBS = PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + PCG_MAX_NUNC
 PCG_MAX_NU = PCG_MAX_NA + PCG_MAX_NDM
 PCG_MAX_N = 4096
 
@@ -66,6 +67,7 @@ class pcg_env_cfg(C.Structure):
         ("nsp_obs", C.c_int32),
         ("ncon", C.c_int32),
         ("nrew", C.c_int32),
+        ("nunc", C.c_int32),
         ("N", C.c_int32),
         ("substeps", C.c_int32),
         ("max_steps", C.c_int32),
@@ -98,6 +100,8 @@ class pcg_env_cfg(C.Structure):
         ("con_A", _pd),
         ("con_b", _pd),
         ("noise_pct", _pd),
+        ("unc_index", _pi),
+        ("unc_pct", _pd),
     ]
 
 
@@ -116,6 +120,7 @@ class pcg_buffers(C.Structure):
         ("g", C.c_void_p),
         ("g_pre", C.c_void_p),
         ("nsteps", C.c_void_p),
+        ("p_unc", C.c_void_p),
     ]
 
 

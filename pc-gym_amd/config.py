@@ -310,26 +310,59 @@ class EnvSpec:
             self.obs_mask = np.array([1 if s in self.partial_observation else 0 for s in info["states"]],
                                      dtype=np.uint8)
 
-        # --- uncertainty, pcgym.py:212-253 (x0 only in this build) ---------------------
+        # --- uncertainty, pcgym.py:212-253, 284-316 ---------------------------------------
+        # "x0": fractions per state (reset-time initial-state uncertainty); any other key names a model
+        # parameter sampled per env at reset and appended to the state/observation [x | SP | d | unc].
         self.x0_unc = None
         self.x0_normal = False
+        self.nunc = 0
+        self.unc_keys = []
+        self.unc_index = np.zeros(0, dtype=np.int32)
+        self.unc_pct = np.zeros(0)
         up = p.get("uncertainty_percentages")
         if p.get("empirical_distribution") is not None:
-            raise ValueError("empirical_distribution is not built yet (per-env parameter arrays, "
-                             "SURVEY.md section 8 row f-3)")
+            raise ValueError("empirical_distribution is not built yet (SURVEY.md section 8 row f-3); use "
+                             "uncertainty_percentages with distribution 'uniform' or 'normal'")
         if up is not None:
-            extra = [k for k in up if k != "x0"]
-            if extra:
-                raise ValueError(f"parameter uncertainty {extra} is not built yet (per-env parameter "
-                                 "arrays, SURVEY.md section 8 row f-3); only 'x0' is supported")
             dist = p.get("distribution", "uniform")
             if dist not in ("uniform", "normal"):
                 raise ValueError("distribution must be 'uniform' or 'normal'")
             self.x0_normal = dist == "normal"
-            xu = _arr(up["x0"])
-            self.x0_unc = np.zeros(self.nx)
-            n = min(self.nx, xu.shape[0])
-            self.x0_unc[:n] = xu[:n]
+            if "x0" in up:
+                xu = _arr(up["x0"])
+                self.x0_unc = np.zeros(self.nx)
+                n = min(self.nx, xu.shape[0])
+                self.x0_unc[:n] = xu[:n]
+            self.unc_keys = [k for k in up if k != "x0"]
+            if self.unc_keys:
+                if self.model.model_id == M.AFFINE:
+                    raise ValueError("parameter uncertainty is not available for affine / custom models")
+                names = list(self.model.parameters.keys())
+                for k in self.unc_keys:
+                    if k not in names:
+                        raise ValueError(f"uncertain parameter '{k}' is not a parameter of model "
+                                         f"'{self.model.name}' (available: {names})")
+                if self.nd:
+                    raise ValueError("disturbances together with parameter uncertainty are not supported: the "
+                                     "reference writes the disturbance slots at a different offset in step() than "
+                                     "in reset() (pcgym.py:298,310 vs 409-410)")
+                self.nunc = len(self.unc_keys)
+                if self.nunc > abi.PCG_MAX_NUNC:
+                    raise ValueError(f"at most {abi.PCG_MAX_NUNC} uncertain parameters are supported")
+                self.unc_index = np.array([names.index(k) for k in self.unc_keys], dtype=np.int32)
+                self.unc_pct = np.array([float(up[k]) for k in self.unc_keys], dtype=_f64)
+                ub = p["uncertainty_bounds"]
+                self.o_low = np.concatenate([self.o_low, _arr(ub["low"])])
+                self.o_high = np.concatenate([self.o_high, _arr(ub["high"])])
+                self.nobs += self.nunc
+                if self.o_low.shape[0] != self.nobs or self.o_high.shape[0] != self.nobs:
+                    raise ValueError(f"uncertainty_bounds must have {self.nunc} entries (one per uncertain parameter)")
+                if self.ncon:
+                    # constraint rows were probed before the observation grew: pad the uncertain-parameter columns
+                    A = self.con_A
+                    nst = self.nobs - self.nunc
+                    self.con_A = np.ascontiguousarray(np.concatenate(
+                        [A[:, :nst], np.zeros((A.shape[0], self.nunc)), A[:, nst:]], axis=1))
 
         # --- integrator selection (new keys) -------------------------------------------
         d_int = DEFAULT_INTEGRATOR[self.model.model_id]
@@ -356,8 +389,10 @@ class EnvSpec:
 
     # ------------------------------------------------------------------------------
     def x0_full(self):
-        """reference reset state [x0 | SP slots | d[:,0]] (pcgym.py:284-298)."""
-        return np.concatenate([self.x0, self.d_sched[:, 0] if self.nd else np.zeros(0)])
+        """reference reset state [x0 | SP slots | d[:,0] | nominal uncertain parameters] (pcgym.py:284-316)."""
+        unc = (np.array([self.model.param_vector()[i] for i in self.unc_index]) if getattr(self, "nunc", 0)
+               else np.zeros(0))
+        return np.concatenate([self.x0, self.d_sched[:, 0] if self.nd else np.zeros(0), unc])
 
     def _adopt_custom_model(self, m, p):
         """custom_model (pcgym.py:150-153).  Registry-shaped objects reuse the
@@ -444,6 +479,7 @@ class EnvSpec:
         cfg.nx, cfg.na, cfg.ndm, cfg.nd = self.nx, self.na, self.ndm, self.nd
         cfg.nsp, cfg.ncon, cfg.nrew, cfg.N = self.nsp, self.ncon, self.nrew, self.N
         cfg.nsp_obs = self.nsp_obs
+        cfg.nunc = self.nunc
         cfg.substeps, cfg.max_steps = self.substeps, self.max_steps
         cfg.flags = self.flags()
         cfg.n_params = params.shape[0]
@@ -469,4 +505,6 @@ class EnvSpec:
         cfg.con_A = pd(self.con_A)
         cfg.con_b = pd(self.con_b)
         cfg.noise_pct = pd(self.noise_pct)
+        cfg.unc_index = pi(self.unc_index)
+        cfg.unc_pct = pd(self.unc_pct)
         return cfg, keep

@@ -91,7 +91,7 @@ struct OMap {
 struct DevConst {
   double dt, h, rtol, atol;
   uint32_t flags;
-  int32_t nx, na, ndm, nd, nsp, nsp_obs, ncon, nrew, N, substeps, max_steps, nobs, has_x0_unc;
+  int32_t nx, na, ndm, nd, nsp, nsp_obs, ncon, nrew, N, substeps, max_steps, nobs, has_x0_unc, nunc;
   int32_t sp_index[PCG_MAX_NSP], d_slot[PCG_MAX_NDM];
   double kp[16];                      // model KP (pcg_models.hpp) of the five built-in models
   AMap amap[PCG_MAX_NA];
@@ -109,6 +109,10 @@ struct DevConst {
   double con_A[PCG_MAX_NCON][CON_W];
   double con_b[PCG_MAX_NCON];
   double kp_big[136];                 // KP of the affine custom model (A 8x8 | B 8x4 | c 8)
+  // per-env parameter uncertainty (pcgym.py:212-253, 301-310): raw parameter vector + which entries vary
+  double raw[32];
+  double unc_pct[PCG_MAX_NUNC];
+  int32_t unc_index[PCG_MAX_NUNC];
 };
 
 using CDevConst = const PCG_CONSTANT DevConst;
@@ -128,6 +132,7 @@ struct StepArgs {
   double* g;
   double* g_pre;
   int32_t* nsteps;
+  double* p_unc;        // [nunc][B] per-env uncertain parameters
   const uint8_t* mask;  // reset only
   int64_t B;
   int64_t env_offset;
@@ -210,9 +215,9 @@ PCG_DEV double pick(const double (&v)[N], int idx) {
   return r;
 }
 
-template <class M, class R = double>
+template <class M, class R = double, class K = typename M::CKP>
 struct RhsFn {
-  typename M::CKP& kp;
+  const K& kp;
   const typename M::template HoldT<R>& hold;
   PCG_DEV void operator()(const R (&x)[M::NX], R (&dx)[M::NX]) const { M::rhs(kp, hold, x, dx); }
 };
@@ -257,6 +262,7 @@ struct EnvOut {
   double ox[M::NX];          // observation rows of the physical states
   double osp[PCG_MAX_NSP];   // SP slots
   double od[PCG_MAX_NDM];    // disturbance slots
+  double ounc[PCG_MAX_NUNC]; // uncertain-parameter slots
   double rew;
   bool done, viol;
 };
@@ -267,7 +273,33 @@ struct EnvOut {
 // everything the hot path writes comes back in `out` (registers).  Only the rare
 // side outputs (a_save, constraint rows, DOPRI5 step counts) are stored here.
 // ---------------------------------------------------------------------------
-template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS>
+// integrate one env over [0,dt] with model constants `kp` of any storage class (scalar constants of the
+// plan, or a per-lane struct when parameters are uncertain)
+template <class M, int INTEG, bool LDS_STAGES, class K>
+PCG_DEV void integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const double (&u)[M::NA + M::NDM],
+                           double (&x)[M::NX], double* stage_l, int64_t e, int nx) {
+  constexpr int NX = M::NX;
+  const typename M::Hold hold = M::hold(kp, u);
+  const RhsFn<M, double, K> f{kp, hold};
+  if (INTEG == PCG_INT_RK4) {
+    rk4<NX>(f, x, c.h, c.substeps);
+  } else {
+    int nacc = 0, nrej = 0;
+    if (LDS_STAGES) {
+      LdsStages<NX, BLOCK_LDS> Kst{stage_l + threadIdx.x};
+      dopri5<NX>(f, Kst, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    } else {
+      RegStages<NX> Kst;
+      dopri5<NX>(f, Kst, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    }
+    if (A.nsteps) {
+      A.nsteps[e] = nacc;
+      A.nsteps[A.B + e] = nrej;
+    }
+  }
+}
+
+template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS, bool UNC = false>
 PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, double* stage_l, int64_t e,
                       int t, const double (&a_in)[M::NA], double (&x)[M::NX], EnvOut<M>& out) {
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
@@ -327,23 +359,30 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
     done = v && (flags & PCG_F_DONE_ON_CONS);
   }
   // ---- integrate over [0, dt], u held (pcgym.py:423-429, integrator.py:90-107,163-182) ----
-  const typename M::Hold hold = M::hold(kp, u);
-  const RhsFn<M> f{kp, hold};
-  if (INTEG == PCG_INT_RK4) {
-    rk4<NX>(f, x, c.h, c.substeps);
+  if constexpr (UNC && !M::DYNAMIC) {
+    // per-env uncertain parameters (sampled at reset, pcgym.py:301-310): rebuild the folded model constants
+    // for this lane from the raw parameter vector with the env's values substituted
+    constexpr int NR = M::NRAW;
+    double raw[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) raw[i] = c.raw[i];
+    for (int j = 0; j < c.nunc; ++j) {
+      const double v = A.p_unc[(size_t)j * B + e];
+      out.ounc[j] = v;
+      const int idx = c.unc_index[j];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) raw[i] = (i == idx) ? v : raw[i];
+    }
+    typename M::KP kpl;
+    double dd[PCG_MAX_NDM] = {0.0, 0.0, 0.0, 0.0};
+    M::prep(raw, NX, NA, reinterpret_cast<double*>(&kpl), dd);
+    if (c.ndm == 0) {  // unconfigured disturbance inputs take the (possibly uncertain) model parameters
+#pragma unroll
+      for (int j = 0; j < NDM; ++j) u[NA + j] = dd[j];
+    }
+    integrate_env<M, INTEG, LDS_STAGES>(A, c, kpl, u, x, stage_l, e, nx);
   } else {
-    int nacc = 0, nrej = 0;
-    if (LDS_STAGES) {
-      LdsStages<NX, BLOCK_LDS> K{stage_l + threadIdx.x};
-      dopri5<NX>(f, K, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
-    } else {
-      RegStages<NX> K;
-      dopri5<NX>(f, K, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
-    }
-    if (A.nsteps) {
-      A.nsteps[e] = nacc;
-      A.nsteps[B + e] = nrej;
-    }
+    integrate_env<M, INTEG, LDS_STAGES>(A, c, kp, u, x, stage_l, e, nx);
   }
   // ---- SP slot uses SP[t_old] (pcgym.py:432-438, quirk Q5); t += 1 ----
   double spv[PCG_MAX_NSP] = {0.0, 0.0, 0.0, 0.0};
@@ -408,10 +447,16 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
 #pragma unroll
   for (int k = 0; k < PCG_MAX_NDM; ++k)
     if (k < nd) out.od[k] = (dv[k] - c.omap[nx + nso + k].lo) * c.omap[nx + nso + k].sc + c.omap[nx + nso + k].off;
+  if constexpr (UNC) {
+    for (int j = 0; j < c.nunc; ++j) {
+      const int q = nx + nso + nd + j;
+      out.ounc[j] = (out.ounc[j] - c.omap[q].lo) * c.omap[q].sc + c.omap[q].off;
+    }
+  }
 }
 
 // scalar (8 B per lane) store of one env's outputs; obs_base = &obs[0][e] of the destination
-template <class M>
+template <class M, bool UNC = false>
 PCG_DEV void store_obs(const StepArgs& A, CDevConst& c, const EnvOut<M>& out, double* obs_base, int64_t B) {
   // B here is the component stride of the destination
   const int nx = M::DYNAMIC ? c.nx : M::NX;
@@ -425,9 +470,11 @@ PCG_DEV void store_obs(const StepArgs& A, CDevConst& c, const EnvOut<M>& out, do
 #pragma unroll
   for (int k = 0; k < PCG_MAX_NDM; ++k)
     if (k < nd) obs_base[(size_t)(nx + nso + k) * B] = out.od[k];
+  if constexpr (UNC)
+    for (int j = 0; j < c.nunc; ++j) obs_base[(size_t)(nx + nso + nd + j) * B] = out.ounc[j];
 }
 
-template <class M>
+template <class M, bool UNC = false>
 PCG_DEV void store_out(const StepArgs& A, CDevConst& c, int64_t e, const EnvOut<M>& out, double* obs_base) {
   const int64_t B = A.B;
   const int nx = M::DYNAMIC ? c.nx : M::NX;
@@ -441,6 +488,8 @@ PCG_DEV void store_out(const StepArgs& A, CDevConst& c, int64_t e, const EnvOut<
 #pragma unroll
   for (int k = 0; k < PCG_MAX_NDM; ++k)
     if (k < nd) obs_base[(size_t)(nx + nso + k) * B] = out.od[k];
+  if constexpr (UNC)
+    for (int j = 0; j < c.nunc; ++j) obs_base[(size_t)(nx + nso + nd + j) * B] = out.ounc[j];
   A.rew[e] = out.rew;
   A.done[e] = out.done ? 1 : 0;
   if (A.viol) A.viol[e] = out.viol ? 1 : 0;
@@ -455,7 +504,7 @@ PCG_DEV void stage_schedules(const StepArgs& A, CDevConst& c, double* sched_l) {
   }
 }
 
-template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS>
+template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS, bool UNC = false>
 __global__ __launch_bounds__(tb(LDS_STAGES), wpe(M::NX, INTEG, LDS_STAGES)) void step_kernel(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   CDevConst& c = *A.C;
@@ -479,12 +528,12 @@ __global__ __launch_bounds__(tb(LDS_STAGES), wpe(M::NX, INTEG, LDS_STAGES)) void
   for (int i = 0; i < NA; ++i) a[i] = (i < na) ? A.a[(size_t)i * B + e] : 0.0;
   PCG_TL_WAIT_STAMP(1);  // loads landed
   EnvOut<M> out;
-  env_step<M, INTEG, PER_ENV_T, LDS_STAGES, EXTRAS>(A, c, sched_l, stage_l, e, t, a, x, out);
+  env_step<M, INTEG, PER_ENV_T, LDS_STAGES, EXTRAS, UNC>(A, c, sched_l, stage_l, e, t, a, x, out);
   PCG_TL_STAMP(2);  // integration + epilogue arithmetic done
 #pragma unroll
   for (int i = 0; i < NX; ++i)
     if (i < nx) A.x[(size_t)i * B + e] = x[i];
-  store_out<M>(A, c, e, out, A.obs + e);
+  store_out<M, UNC>(A, c, e, out, A.obs + e);
   if (PER_ENV_T) A.t[e] = t + 1;
   PCG_TL_STAMP(3);       // stores issued
   PCG_TL_WAIT_STAMP(4);  // stores acknowledged
@@ -1013,6 +1062,24 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs A) {
     const int j = nx + nsp + k;
     A.obs[(size_t)j * B + e] = (A.sched[(size_t)(c.nsp + k) * c.N] - c.omap[j].lo) * c.omap[j].sc + c.omap[j].off;
   }
+  // uncertain model parameters (pcgym.py:301-310): sampled per env, appended to the observation
+  for (int j = 0; j < c.nunc; ++j) {
+    const double orig = c.raw[c.unc_index[j]], pct = c.unc_pct[j];
+    const int ri = nx + j;  // RNG index after the x0 draws
+    double v;
+    if (c.flags & PCG_F_X0_NORMAL) {
+      double z0, z1;
+      rng_normal2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), z0, z1);
+      v = orig + pct * orig * ((ri & 1) ? z1 : z0);
+    } else {
+      double u0, u1;
+      rng_uniform2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), u0, u1);
+      v = orig * (1 + pct * (2.0 * ((ri & 1) ? u1 : u0) - 1.0));
+    }
+    A.p_unc[(size_t)j * B + e] = v;
+    const int q = nx + nsp + nd + j;
+    A.obs[(size_t)q * B + e] = (v - c.omap[q].lo) * c.omap[q].sc + c.omap[q].off;
+  }
   if ((c.flags & PCG_F_A_DELTA) && A.a_save)
     for (int i = 0; i < c.na; ++i) A.a_save[(size_t)i * B + e] = c.a_0[i];
   if (A.t) A.t[e] = 0;
@@ -1094,6 +1161,7 @@ using IntKFn = void (*)(CDevConst*, int64_t, int, double*, const double*, int32_
 struct Kernels {
   StepFn step[PCG_INT_COUNT][2][2][2];  // [integrator][per_env_t][lds_stages][extras]
   StepFn stream[PCG_INT_COUNT][2][3];   // [integrator][EPL-1][log2 UNR]  (entries may be null)
+  StepFn step_unc[PCG_INT_COUNT][2]; // per-env parameter uncertainty [integrator][per_env_t] (null for affine)
   StepFn pipe[2];                    // RK4 software-pipelined lean kernel [EPL-1] (may be null)
   StepFn roll_lean[2];               // RK4 lean fused rollout [EPL-1] (may be null)
   StepFn rollout[PCG_INT_COUNT][2];  // [integrator][lds_stages]
@@ -1123,6 +1191,12 @@ Kernels make_kernels() {
   k.integ[PCG_INT_RK4][0] = integrate_kernel<M, PCG_INT_RK4, false>;
   k.integ[PCG_INT_DOPRI5][0] = integrate_kernel<M, PCG_INT_DOPRI5, false>;
   k.rhs = rhs_kernel<M>;
+  if constexpr (!M::DYNAMIC) {
+    k.step_unc[PCG_INT_RK4][0] = step_kernel<M, PCG_INT_RK4, false, false, true, true>;
+    k.step_unc[PCG_INT_RK4][1] = step_kernel<M, PCG_INT_RK4, true, false, true, true>;
+    k.step_unc[PCG_INT_DOPRI5][0] = step_kernel<M, PCG_INT_DOPRI5, false, false, true, true>;
+    k.step_unc[PCG_INT_DOPRI5][1] = step_kernel<M, PCG_INT_DOPRI5, true, false, true, true>;
+  }
   if constexpr (M::FULL) {
     // DOPRI5 with the stage vectors in LDS (PCG_OPT_LDS_STAGES)
     k.step[PCG_INT_DOPRI5][0][1][0] = step_kernel<M, PCG_INT_DOPRI5, false, true, false>;
@@ -1293,6 +1367,10 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   }
   if (nd < 0 || nd > ndm || nsp < 0 || nsp > PCG_MAX_NSP || ncon < 0 || ncon > PCG_MAX_NCON) return PCG_E_DIM;
   const int nso = c->nsp_obs;
+  const int nunc = c->nunc;
+  if (nunc < 0 || nunc > PCG_MAX_NUNC) return PCG_E_DIM;
+  if (nunc > 0 && (k.dynamic || !c->unc_index || !c->unc_pct)) return nunc > 0 && k.dynamic ? PCG_E_UNSUPPORTED : PCG_E_NULL;
+  if (nunc > 0 && nd > 0) return PCG_E_UNSUPPORTED;  // quirk Q11: the reference's slot layout is inconsistent there
   if (nso != 0 && nso != nsp) return PCG_E_DIM;
   if (nd > 0 && nso != nsp) return PCG_E_UNSUPPORTED;
   if (nrew < 0 || nrew > PCG_MAX_NX) return PCG_E_DIM;
@@ -1301,7 +1379,7 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   if (c->integrator_id == PCG_INT_RK4 && c->substeps < 0) return PCG_E_VALUE;  // 0 = no integration (I/O probe)
   if (c->integrator_id == PCG_INT_DOPRI5 && (!(c->rtol > 0) || !(c->atol >= 0) || c->max_steps < 1))
     return PCG_E_VALUE;
-  const int nobs = nx + nso + nd, cnu = na + ndm;
+  const int nobs = nx + nso + nd + nunc, cnu = na + ndm;
   if (!c->params || !c->x0 || !c->a_low || !c->a_high || !c->o_low || !c->o_high) return PCG_E_NULL;
   if (nsp && (!c->sp_index || !c->sp)) return PCG_E_NULL;
   if ((nsp || nrew) && !c->r_scale) return PCG_E_NULL;
@@ -1379,6 +1457,10 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
         b -= coef * (hs + c->o_low[i]);
         coef *= hs;
       }
+      if (i >= nx + nso + nd) {  // uncertain-parameter slots cannot enter constraint rows
+        if (coef != 0.0) return PCG_E_UNSUPPORTED;
+        continue;
+      }
       const int col = (i < nx) ? i : (i < nx + nso) ? PCG_MAX_NX + (i - nx) : PCG_MAX_NX + PCG_MAX_NSP + (i - nx - nso);
       d->con_A[r][col] = coef;
     }
@@ -1395,6 +1477,14 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
       d->con_A[r][col] = coef;
     }
     d->con_b[r] = b;
+  }
+  d->nunc = nunc;
+  if (!k.dynamic)
+    for (int i = 0; i < k.nraw && i < 32; ++i) d->raw[i] = c->params[i];
+  for (int j = 0; j < nunc; ++j) {
+    if (c->unc_index[j] < 0 || c->unc_index[j] >= k.nraw) return PCG_E_DIM;
+    d->unc_index[j] = c->unc_index[j];
+    d->unc_pct[j] = c->unc_pct[j];
   }
   d->dt = c->dt;
   d->h = c->dt / (c->substeps > 0 ? c->substeps : 1);
@@ -1501,6 +1591,7 @@ int64_t pcg_plan_bytes_per_env_step(const pcg_plan* p, const pcg_buffers* io) {
   if (io->t) A += 8;
   if ((c.flags & PCG_F_A_DELTA) && io->a_save) A += 16 * c.na;
   if (io->nsteps) A += 8;
+  A += 16 * c.nunc;  // per-env parameters read + their observation slots written
   return A;
 }
 
@@ -1513,6 +1604,7 @@ static int fill_args(const pcg_plan* p, const pcg_buffers* io, StepArgs* a) {
   a->x = io->x; a->a = io->a; a->d = io->d; a->t = io->t; a->a_save = io->a_save; a->obs = io->obs;
   a->rew = io->rew; a->done = io->done; a->viol = io->viol; a->g = io->g; a->g_pre = io->g_pre;
   a->nsteps = io->nsteps; a->B = io->B; a->env_offset = p->env_offset;
+  a->p_unc = io->p_unc;
   a->prio_mode = p->prio_mode;
   return PCG_OK;
 }
@@ -1540,6 +1632,21 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
       a.sched_in_lds = 1;
       shmem += sb;
     }
+  }
+  if (c.nunc > 0) {  // per-env uncertain parameters: dedicated general kernel
+    if (!io->p_unc) return PCG_E_NULL;
+    StepFn ufn = k.step_unc[p->integrator_id][per_env_t ? 1 : 0];
+    if (!ufn) return PCG_E_UNSUPPORTED;
+    size_t sh = 0;
+    if (per_env_t) {
+      const size_t sb = sizeof(double) * (size_t)(c.nsp + c.nd) * c.N;
+      if (sb > 0 && sb <= 64 * 1024) {
+        a.sched_in_lds = 1;
+        sh = sb;
+      }
+    }
+    hipLaunchKernelGGL(ufn, dim3(grid_for(io->B, BLOCK)), dim3(BLOCK), sh, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
   }
   // lean variant when no noise / Gaussian disturbance / constraint work is configured
   // (the lean kernels also compile out a_delta, the terminal "batch" reward and per-env disturbances)
@@ -1607,6 +1714,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   if (!io->x || !a_seq || !io->obs || !io->rew || !io->done) return PCG_E_NULL;
   const DevConst& c = p->hc;
   if ((c.flags & PCG_F_A_DELTA) && !io->a_save) return PCG_E_NULL;
+  if (c.nunc > 0) return PCG_E_UNSUPPORTED;  // parameter uncertainty: per-step kernel only
   a.t_scalar = t0;
   a.seed = seed;
   a.T = T;
@@ -1655,6 +1763,7 @@ int pcg_reset(pcg_plan* p, const pcg_buffers* io, const uint8_t* mask, uint64_t 
   if (rc != PCG_OK) return rc;
   if (io->B == 0) return PCG_OK;
   if (!io->x || !io->obs) return PCG_E_NULL;
+  if (p->hc.nunc > 0 && !io->p_unc) return PCG_E_NULL;
   a.mask = mask;
   a.seed = seed;
   hipLaunchKernelGGL(reset_kernel, dim3(grid_for(io->B)), dim3(BLOCK), 0, (hipStream_t)stream, a);

@@ -25,6 +25,7 @@ using ::pow;
 using ::sqrt;
 
 #define PCG_DEV __device__ __forceinline__
+#define PCG_HD __host__ __device__ inline
 // Plan constants are read through the CONSTANT address space (AMDGPU addrspace 4): a load with a
 // wave-uniform address then always becomes a scalar s_load (SGPR destination, scalar cache), even
 // after the kernel has issued vector stores -- with a plain global pointer the compiler must assume
@@ -52,7 +53,7 @@ struct Model<PCG_MODEL_CSTR> {
     R Tc, Ti, Caf;
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int /*nx*/, int /*nu*/, double* kp_out, double* ddef) {
+  PCG_HD static void prep(const double* r, int /*nx*/, int /*nu*/, double* kp_out, double* ddef) {
     KP k;
     k.qV = r[0] / r[1];
     k.c1 = (-r[4]) * (1.0 / (r[2] * r[3]));
@@ -63,12 +64,12 @@ struct Model<PCG_MODEL_CSTR> {
     ddef[0] = r[8];
     ddef[1] = r[9];
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K&, const R (&u)[NA + NDM]) {
     return HoldT<R>{u[0], u[1], u[2]};
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const R ca = x[0], T = x[1];
     // Arrhenius factor: the exponent -EA/(R T) lies in (-700, 0) for any T > 12.5 K, so the bounded
     // exp and the Newton divide apply (quotient to ~0.5 ulp: the exponent is O(30), an ulp there is
@@ -99,7 +100,7 @@ struct Model<PCG_MODEL_FOUR_TANK> {
     R q1, q2, q3, q4;  // pump inflow terms, constant over the step
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int, int, double* kp_out, double*) {
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
     KP k;
     k.g2 = 2 * r[0];
     k.o1 = r[5] / r[9];
@@ -114,12 +115,12 @@ struct Model<PCG_MODEL_FOUR_TANK> {
     k.p4 = ((1 - r[1]) * r[3]) / r[12];
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP& k, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K& k, const R (&u)[NA + NDM]) {
     return HoldT<R>{k.p1 * u[0], k.p2 * u[1], k.p3 * u[1], k.p4 * u[0]};
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const R s1 = sqrt(k.g2 * x[0]), s2 = sqrt(k.g2 * x[1]);
     const R s3 = sqrt(k.g2 * x[2]), s4 = sqrt(k.g2 * x[3]);
     dx[0] = -k.o1 * s1 + k.i31 * s3 + h.q1;
@@ -155,7 +156,7 @@ struct Model<PCG_MODEL_ME> {
     R L, G, X0, Y6;
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int, int, double* kp_out, double* ddef) {
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double* ddef) {
     KP k;
     k.iVl = 1 / r[0];
     k.iVg = 1 / r[1];
@@ -167,12 +168,12 @@ struct Model<PCG_MODEL_ME> {
     ddef[0] = r[5];
     ddef[1] = r[6];
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K&, const R (&u)[NA + NDM]) {
     return HoldT<R>{u[0], u[1], u[2], u[3]};
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const bool sq = k.sq != 0.0;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
@@ -204,7 +205,7 @@ struct Model<PCG_MODEL_ME_REACTIVE> {
     R L, G;
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int, int, double* kp_out, double*) {
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
     KP k;
     k.iVl = 1 / r[0];
     k.iVg = 1 / r[1];
@@ -219,12 +220,12 @@ struct Model<PCG_MODEL_ME_REACTIVE> {
     k.YC6 = r[9];
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K&, const R (&u)[NA + NDM]) {
     return HoldT<R>{u[0], u[1]};
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const bool sq = k.sq != 0.0;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
@@ -263,7 +264,7 @@ struct Model<PCG_MODEL_CRYST> {
     R Ceq, eB, eG;  // eB = ka*exp(kb/Tk), eG = kg*exp(k1/Tk)
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int, int, double* kp_out, double*) {
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
     KP k;
     k.ka = r[0];
     k.kb = r[1];
@@ -277,8 +278,8 @@ struct Model<PCG_MODEL_CRYST> {
     k.cc = -0.5 * r[10] * r[9];
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP& k, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K& k, const R (&u)[NA + NDM]) {
     const R Tk = u[0] + 273.15;
     HoldT<R> h;
     h.Ceq = -686.2686 + 3.579165 * Tk - 0.00292874 * (Tk * Tk);
@@ -286,8 +287,8 @@ struct Model<PCG_MODEL_CRYST> {
     h.eG = k.kg * exp(k.k1 / Tk);
     return h;
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const R mu0 = x[0], mu1 = x[1], mu2 = x[2], mu3 = x[3], conc = x[4];
     const R S = conc * 1e3 - h.Ceq;
     const R S2 = S * S;
@@ -337,7 +338,7 @@ struct Model<PCG_MODEL_AFFINE> {
     R f[8];  // B u + c
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int nx, int nu, double* kp_out, double*) {
+  PCG_HD static void prep(const double* r, int nx, int nu, double* kp_out, double*) {
     KP k;
     __builtin_memset(&k, 0, sizeof(k));
     for (int i = 0; i < nx; ++i) {
@@ -347,8 +348,8 @@ struct Model<PCG_MODEL_AFFINE> {
     }
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP& k, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K& k, const R (&u)[NA + NDM]) {
     HoldT<R> h;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -359,8 +360,8 @@ struct Model<PCG_MODEL_AFFINE> {
     }
     return h;
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       R s = h.f[i];
@@ -391,7 +392,7 @@ struct Model<PCG_MODEL_COMPLEX_CSTR> {
     R Tc, Ti, Caf;
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int, int, double* kp_out, double* ddef) {
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double* ddef) {
     KP k;
     k.qV = r[0] / r[1];
     k.k01 = r[6];
@@ -405,12 +406,12 @@ struct Model<PCG_MODEL_COMPLEX_CSTR> {
     ddef[0] = r[11];
     ddef[1] = r[12];
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K&, const R (&u)[NA + NDM]) {
     return HoldT<R>{u[0], u[1], u[2]};
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const R ca = x[0], cb = x[1], cc = x[2], T = x[3];
     const R r1 = k.k01 * exp_bounded(div_fast(k.nEA1, T)) * ca;
     const R r2 = k.k02 * exp_bounded(div_fast(k.nEA2, T)) * cb;
@@ -435,16 +436,16 @@ struct Model<PCG_MODEL_DISEASE> {
     R u;
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int, int, double* kp_out, double*) {
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
     KP k{r[0], r[1]};
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K&, const R (&u)[NA + NDM]) {
     return HoldT<R>{u[0]};
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const R S = x[0], I = x[1];
     const R inf = k.beta * S * I;
     dx[0] = -inf - h.u * S;
@@ -468,7 +469,7 @@ struct Model<PCG_MODEL_BATCH> {
     R Tc;
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int, int, double* kp_out, double*) {
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
     KP k;
     k.k01 = r[0];
     k.k02 = r[1];
@@ -479,12 +480,12 @@ struct Model<PCG_MODEL_BATCH> {
     k.c = r[9] / (r[7] * r[8] * r[10]);
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K&, const R (&u)[NA + NDM]) {
     return HoldT<R>{u[0]};
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const R CA = x[0], CB = x[1], T = x[3];
     const R r1 = k.k01 * exp(k.nE1 / T) * CA;
     const R r2 = k.k02 * exp(k.nE2 / T) * CB;
@@ -511,12 +512,12 @@ struct Model<PCG_MODEL_PHOTO> {
     R f1, f2, F_N;  // u_m I/(I+k_s+I^2/k_i),  k_m I/(I+k_sq+I^2/k_iq)
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int, int, double* kp_out, double*) {
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
     KP k{r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10]};
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP& k, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K& k, const R (&u)[NA + NDM]) {
     const R I = u[0];
     HoldT<R> h;
     h.f1 = k.u_m * I / (I + k.k_s + (I * I) / k.k_i);
@@ -524,8 +525,8 @@ struct Model<PCG_MODEL_PHOTO> {
     h.F_N = u[1];
     return h;
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const R c_x = x[0], c_N = x[1], c_q = x[2];
     const R g = h.f1 * c_x * c_N / (c_N + k.k_N);
     dx[0] = g - k.u_d * c_x;
@@ -549,7 +550,7 @@ struct Model<PCG_MODEL_CSTR_SERIES> {
     R F, L, Tc1, Tc2;
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int, int, double* kp_out, double*) {
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
     KP k;
     k.COV1 = r[0] / r[2];
     k.TOV1 = r[1] / r[2];
@@ -562,12 +563,12 @@ struct Model<PCG_MODEL_CSTR_SERIES> {
     k.kh = (r[8] * (-r[10])) / (r[6] * r[7]);
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP&, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K&, const R (&u)[NA + NDM]) {
     return HoldT<R>{u[0], u[1], u[2], u[3]};
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const R C1 = x[0], T1 = x[1], C2 = x[2], T2 = x[3];
     const R e1 = exp(k.nER / T1), e2 = exp(k.nER / T2);
     const R FL = h.F + h.L;
@@ -593,12 +594,12 @@ struct Model<PCG_MODEL_DISTILLATION> {
     R L, V, Ld, Vd, W, FXf;
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int, int, double* kp_out, double*) {
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
     KP k{r[0], r[1], r[2], r[2] - 1, r[3], 1 / r[4], 1 / r[5], 1 / r[6]};
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP& k, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K& k, const R (&u)[NA + NDM]) {
     const R Rr = u[0], F = u[1];
     HoldT<R> h;
     h.L = Rr * k.D;
@@ -609,8 +610,8 @@ struct Model<PCG_MODEL_DISTILLATION> {
     h.FXf = F * k.X_feed;
     return h;
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     R Y[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) Y[i] = (k.alpha * x[i]) / (1.0 + k.am1 * x[i]);
@@ -642,16 +643,16 @@ struct Model<PCG_MODEL_POLYMER> {
     R FV, Tf, Mf, If;
   };
   using Hold = HoldT<double>;
-  static void prep(const double* r, int, int, double* kp_out, double*) {
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
     KP k{r[0], r[1], r[2], -r[3], -r[4], -r[5], r[6], (-r[8]) / (r[9] * r[10]), 1 / r[7]};
     __builtin_memcpy(kp_out, &k, sizeof(k));
   }
-  template <class R>
-  PCG_DEV static HoldT<R> hold(CKP& k, const R (&u)[NA + NDM]) {
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K& k, const R (&u)[NA + NDM]) {
     return HoldT<R>{u[0] * k.iV, u[1], u[2], u[3]};
   }
-  template <class R>
-  PCG_DEV static void rhs(CKP& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
     const R T = x[0], M = x[1], I = x[2];
     const R kp = k.Ap * exp(k.nEp / T), kd = k.Ad * exp(k.nEd / T), kt = k.At * exp(k.nEt / T);
     const R ri = 2.0 * k.f * kd * I;

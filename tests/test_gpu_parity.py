@@ -662,3 +662,49 @@ def test_collect_rollouts_reference_axis_order(name):
         assert np.allclose(gg, ci[:, :T1], rtol=1e-7, atol=1e-8 * np.max(np.abs(ci)))
     env.close()
     env2.close()
+
+
+def test_parameter_uncertainty_vs_oracle():
+    """row f-3: per-env model parameters sampled at reset (pcgym.py:212-253, 301-316) -- same Philox stream on
+    both sides, parameters appended to the observation, dynamics use the per-env values."""
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    cases = []
+    p = {"model": "photobioreactor", "x0": np.array([0.1, 20.0, 0.0]), "tsim": 100, "N": 100,
+         "a_space": {"low": np.array([0.0, 0.0]), "high": np.array([1000.0, 100.0])},
+         "o_space": {"low": np.array([0.0, 0.0, 0.0]), "high": np.array([10.0, 100.0, 10.0])},
+         "uncertainty_percentages": {"k_s": 0.1, "k_i": 0.1, "k_N": 0.1}, "distribution": "normal",
+         "uncertainty_bounds": {"low": np.array([160.0, 400.0, 350.0]), "high": np.array([200.0, 500.0, 440.0])},
+         "reward_states": ["c_q"], "maximise_reward": True, "r_scale": {"c_q": 1.0},
+         "integrator": "rk4", "substeps": 16}
+    cases.append((p, 1e-11))
+    p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+    p.update(uncertainty_percentages={"UA": 0.1, "x0": [0.02, 0.01], "Caf": 0.05}, distribution="uniform",
+             uncertainty_bounds={"low": np.array([4e4, 0.9]), "high": np.array([6e4, 1.1])})
+    cases.append((p, 1e-12))
+    for p, tol in cases:
+        for per_env_t in (False, True):
+            B = 1500
+            env = VecEnv(p, n_envs=B, seed=21, per_env_t=per_env_t, env_offset=10**6)
+            orc = O.OracleEnv(env.spec, B, seed=21, per_env_t=per_env_t, env_offset=10**6)
+            og, _ = env.reset()
+            oc = orc.reset()
+            assert np.allclose(env.p_unc.cpu().numpy(), orc.p_unc, rtol=1e-14)
+            assert np.allclose(og.cpu().numpy().T, oc, rtol=1e-12, atol=1e-12)
+            pu = env.p_unc.cpu().numpy()
+            nom = np.array([env.spec.model.param_vector()[i] for i in env.spec.unc_index])
+            assert np.all(np.abs(pu.mean(axis=1) / nom - 1) < 0.02) and np.all(pu.std(axis=1) / nom > 0.02)
+            acts = _rand_actions(env.spec, 6, B, 2)
+            for i in range(6):
+                o, r, d, _, _ = env.step(torch.tensor(acts[i], device=env.device))
+                oc, rc, dc = orc.step(acts[i])
+                xs = np.maximum(np.abs(orc.x), 1e-9)
+                assert np.max(np.abs(env.x.cpu().numpy() - orc.x) / xs) <= tol, (i, per_env_t)
+                assert np.max(np.abs(o.cpu().numpy().T - oc) / np.maximum(1.0, np.abs(oc))) <= 1e-10
+            # the parameters really differ between envs and matter for the dynamics
+            assert np.std(env.x.cpu().numpy()[0]) > 0
+            env.close()
