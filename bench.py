@@ -180,9 +180,10 @@ def main():
     # kernel trace is the reference), so each pair brackets EV_GROUP consecutive step launches and the
     # average launch duration is the bracket / EV_GROUP.  That figure still contains the launch-to-launch
     # gaps, i.e. it is a slight OVER-estimate of the kernel time (an under-estimate of achieved GB/s).
-    EV_GROUP, EV_EVERY = 8, 32
+    EV_GROUP, EV_EVERY = min(8, max(1, K)), 32
+    t_start = W % (env.N - 1)  # step counter at the first timed launch (episodes are N-1 steps long)
     starts = [i for i in range(0, K - EV_GROUP + 1, EV_EVERY)
-              if (env.t + i) // (env.N - 1) == (env.t + i + EV_GROUP - 1) // (env.N - 1)]  # no reset inside
+              if (t_start + i) // (env.N - 1) == (t_start + i + EV_GROUP - 1) // (env.N - 1)]  # no reset inside
     ev_beg = {i: torch.cuda.Event(enable_timing=True) for i in starts}
     ev_end = {i + EV_GROUP - 1: torch.cuda.Event(enable_timing=True) for i in starts}
     plan, bufp, buf, sptr = env._plan, env._bufp, env._buf, stream.cuda_stream
@@ -223,7 +224,9 @@ def main():
     # sanity: results are finite (a fast kernel producing NaN is not a result)
     finite = bool(torch.isfinite(env.x).all().item() and torch.isfinite(env.rew).all().item())
     kern_ms = np.array([ev_beg[i].elapsed_time(ev_end[i + EV_GROUP - 1]) / EV_GROUP for i in starts])
-    kern_avg_s = float(kern_ms.mean()) * 1e-3
+    # (very short runs may contain no reset-free bracket: fall back to the wall time per step, which also
+    # contains the reset launches -- an over-estimate of the kernel time)
+    kern_avg_s = float(kern_ms.mean()) * 1e-3 if len(kern_ms) else elapsed / K
     total_env_steps = float(B) * K * world
     value = total_env_steps / elapsed
 
@@ -261,7 +264,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": "step_kernel_stream<Model<cstr>, RK4, 2 env/lane> (lean, lock-stepped)",
+            "kernel": "step_kernel_pipe<Model<cstr>, EPL=2> (RK4, lean, lock-stepped, software-pipelined)",
             "kernel_avg_us": kern_avg_s * 1e6,
             "algorithmic_bytes_per_env_step": int(bytes_per_env_step),
             "algorithmic_bytes_per_launch": alg_bytes,
