@@ -130,10 +130,13 @@ def cpu_baseline(spec, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=590)
-    ap.add_argument("--warmup", type=int, default=59)
+    ap.add_argument("--steps", type=int, default=5900)
+    ap.add_argument("--warmup", type=int, default=590)
     ap.add_argument("--batch", type=int, default=1 << 20, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay whole episodes as one HIP graph (pcg_graph_*) instead of eager launches; "
+                         "measured within 1 %% of eager once the GPU is warm, so eager stays the default")
     ap.add_argument("--substeps", type=int, default=1,
                     help="RK4 sub-steps per env step (1 = the headline workload; other values are probes)")
     args = ap.parse_args()
@@ -175,32 +178,40 @@ def main():
     torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream(dev)
-    # Kernel timing for the roofline object: hipEvent pairs on the launch stream inside the timed region.
-    # A pair around ONE 17 us launch reads ~3 us high (marker packets + timestamp latency; rocprofv3's
-    # kernel trace is the reference), so each pair brackets EV_GROUP consecutive step launches and the
-    # average launch duration is the bracket / EV_GROUP.  That figure still contains the launch-to-launch
-    # gaps, i.e. it is a slight OVER-estimate of the kernel time (an under-estimate of achieved GB/s).
-    EV_GROUP, EV_EVERY = min(8, max(1, K)), 32
-    t_start = W % (env.N - 1)  # step counter at the first timed launch (episodes are N-1 steps long)
-    starts = [i for i in range(0, K - EV_GROUP + 1, EV_EVERY)
-              if (t_start + i) // (env.N - 1) == (t_start + i + EV_GROUP - 1) // (env.N - 1)]  # no reset inside
-    ev_beg = {i: torch.cuda.Event(enable_timing=True) for i in starts}
-    ev_end = {i + EV_GROUP - 1: torch.cuda.Event(enable_timing=True) for i in starts}
     plan, bufp, buf, sptr = env._plan, env._bufp, env._buf, stream.cuda_stream
     step_fn, last_t = lib.pcg_step, env.N - 1
+    # One episode (N-1 = 59 dependent pcg_step launches) is recorded once as a HIP graph (pcg_graph_*) and
+    # replayed with one host call; the reset between episodes and any steps that do not fill a whole
+    # episode (arbitrary --steps / --warmup) are launched eagerly.  Same kernels, same buffers.
+    graph = env.capture_steps([acts[j % n_act] for j in range(last_t)]) if args.graph else None
+    # Kernel timing for the roofline object: hipEvent pairs on the launch stream inside the timed region,
+    # one pair around each run of consecutive step launches of an episode (a graph replay = 59 launches).
+    # A pair around ONE ~14 us launch reads ~3 us high (marker packets + timestamp latency; rocprofv3's
+    # kernel trace is the reference); a bracket / its launch count still contains the launch-to-launch
+    # gaps, i.e. it is a slight OVER-estimate of the kernel time (an under-estimate of achieved GB/s).
+    brackets = []
 
     def run(n, timed):
-        for i in range(n):
-            a = acts[i % n_act]
-            if timed and i in ev_beg:
-                ev_beg[i].record(stream)
-            buf.a = a.data_ptr()
-            rc = step_fn(plan, bufp, env.t, env._episode_seed(), sptr)
-            if rc:
-                _lib.check(rc, "pcg_step")
-            if timed and i in ev_end:
-                ev_end[i].record(stream)
-            env.t += 1
+        i = 0
+        while i < n:
+            m = min(last_t - env.t, n - i)
+            if timed:
+                eb = torch.cuda.Event(enable_timing=True)
+                ee = torch.cuda.Event(enable_timing=True)
+                eb.record(stream)
+            if graph is not None and env.t == 0 and m == last_t:
+                graph.replay()
+            else:
+                for j in range(m):
+                    buf.a = acts[(env.t) % n_act].data_ptr()
+                    rc = step_fn(plan, bufp, env.t, env._episode_seed(), sptr)
+                    if rc:
+                        _lib.check(rc, "pcg_step")
+                    env.t += 1
+            if timed:
+                ee.record(stream)
+                brackets.append((eb, ee, m))
+            i += m
             if env.t == last_t:
                 env.reset()
 
@@ -223,10 +234,8 @@ def main():
 
     # sanity: results are finite (a fast kernel producing NaN is not a result)
     finite = bool(torch.isfinite(env.x).all().item() and torch.isfinite(env.rew).all().item())
-    kern_ms = np.array([ev_beg[i].elapsed_time(ev_end[i + EV_GROUP - 1]) / EV_GROUP for i in starts])
-    # (very short runs may contain no reset-free bracket: fall back to the wall time per step, which also
-    # contains the reset launches -- an over-estimate of the kernel time)
-    kern_avg_s = float(kern_ms.mean()) * 1e-3 if len(kern_ms) else elapsed / K
+    # launch-weighted mean over all brackets of the timed region
+    kern_avg_s = sum(eb.elapsed_time(ee) for eb, ee, _ in brackets) * 1e-3 / sum(m for _, _, m in brackets)
     total_env_steps = float(B) * K * world
     value = total_env_steps / elapsed
 
@@ -251,6 +260,8 @@ def main():
             "integrator": "rk4, 1 step per dt=1s (1/60 model time unit)",
             "episode_len": spec.N - 1,
             "parallelism": f"env-shard x{world} (no collective on the hot path)",
+            "launch": ("eager pcg_step launches" if graph is None else
+                       f"HIP graph of one {last_t}-step episode (pcg_graph_*), eager pcg_reset between episodes"),
             "finite": finite,
         },
     }

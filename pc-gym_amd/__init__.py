@@ -5,7 +5,7 @@ Keeps pc-gym's ``make_env(env_params)`` / ``reset()`` / ``step()`` surface
 per-timestep hot path as HIP kernels behind the C ABI in include/pcgym_hip.h.
 """
 from .config import EnvSpec  # noqa: F401
-from .env import make_env, make_vec_env, VecEnv  # noqa: F401
+from .env import StepGraph, VecEnv, make_env, make_vec_env  # noqa: F401
 from .rollout import collect_rollouts, reproducibility_metric  # noqa: F401
 from .spaces import Box  # noqa: F401
 

@@ -142,6 +142,10 @@ EXPORTS = [
     "pcg_integrate",
     "pcg_rollout",
     "pcg_rollout_strided",
+    "pcg_graph_create",
+    "pcg_graph_launch",
+    "pcg_graph_set_seed",
+    "pcg_graph_destroy",
     "pcg_philox4x32_10",
 ]
 
@@ -183,6 +187,15 @@ def declare(lib):
     lib.pcg_rollout_strided.restype = C.c_int
     lib.pcg_rollout_strided.argtypes = [vp, C.POINTER(pcg_buffers), C.c_int32, C.c_int32, vp, C.c_int64, C.c_int64,
                                         vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_uint64, vp]
+    lib.pcg_graph_create.restype = C.c_int
+    lib.pcg_graph_create.argtypes = [C.POINTER(vp), vp, C.POINTER(pcg_buffers), C.POINTER(vp), C.POINTER(vp),
+                                     C.c_int32, C.c_int32, C.c_uint64, C.c_int]
+    lib.pcg_graph_launch.restype = C.c_int
+    lib.pcg_graph_launch.argtypes = [vp, vp]
+    lib.pcg_graph_set_seed.restype = C.c_int
+    lib.pcg_graph_set_seed.argtypes = [vp, C.c_uint64]
+    lib.pcg_graph_destroy.restype = C.c_int
+    lib.pcg_graph_destroy.argtypes = [vp]
     lib.pcg_philox4x32_10.restype = None
     lib.pcg_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/pcgym_hip.h"
 #include "pcg_integrators.hpp"
@@ -1611,6 +1612,44 @@ static int fill_args(const pcg_plan* p, const pcg_buffers* io, StepArgs* a) {
 
 static inline unsigned grid_for(int64_t B, int block = BLOCK) { return (unsigned)((B + block - 1) / block); }
 
+// Resident 256-thread workgroups per CU (= waves per SIMD) of a persistent kernel; < 0: -(hipError_t).
+// The occupancy API over-reports by one for some register counts on ROCm 7.2 (MI355X_MICROARCH.md
+// "Residency"), and a persistent grid with a non-resident workgroup serialises a whole extra round:
+// bound it by the VGPR allocation too.
+static int resident_blocks(StepFn fn) {
+  int nb = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, BLOCK, 0);
+  if (e != hipSuccess) return -(int)e;
+  hipFuncAttributes fa;
+  e = hipFuncGetAttributes(&fa, (const void*)fn);
+  if (e != hipSuccess) return -(int)e;
+  const int alloc = ((fa.numRegs + 7) / 8) * 8;
+  const int by_vgpr = alloc > 0 ? 512 / alloc : 8;
+  if (nb > by_vgpr) nb = by_vgpr;
+  if (nb > 8) nb = 8;
+  return nb > 0 ? nb : 1;
+}
+
+// Fill every lazily queried occupancy of the plan's candidate persistent kernels (done before a stream
+// capture so that no query runs while capturing).
+static int warm_occupancy(pcg_plan* p) {
+  const Kernels& k = kernels(p->model_id);
+  for (int e = 0; e < 2; ++e) {
+    if (p->integrator_id == PCG_INT_RK4 && k.pipe[e] && p->pipe_occ[e] == 0) {
+      const int q = resident_blocks(k.pipe[e]);
+      if (q < 0) return -q;
+      p->pipe_occ[e] = q;
+    }
+    for (int lu = 0; lu < 3; ++lu)
+      if (k.stream[p->integrator_id][e][lu] && p->stream_occ[e][lu] == 0) {
+        const int q = resident_blocks(k.stream[p->integrator_id][e][lu]);
+        if (q < 0) return -q;
+        p->stream_occ[e][lu] = q;
+      }
+  }
+  return PCG_OK;
+}
+
 int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void* stream) {
   StepArgs a;
   int rc = fill_args(p, io, &a);
@@ -1671,18 +1710,9 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
     }
     int& occ = piped ? p->pipe_occ[epl - 1] : p->stream_occ[epl - 1][lu];
     if (occ == 0) {
-      // resident 256-thread workgroups per CU = waves per SIMD.  The occupancy API over-reports by one for
-      // some register counts on ROCm 7.2 (MI355X_MICROARCH.md "Residency"), and a persistent grid with a
-      // non-resident workgroup serialises a whole extra round: bound it by the VGPR allocation too.
-      int nb = 0;
-      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)sfn, BLOCK, 0));
-      hipFuncAttributes fa;
-      HIP_TRY(hipFuncGetAttributes(&fa, (const void*)sfn));
-      const int alloc = ((fa.numRegs + 7) / 8) * 8;
-      const int by_vgpr = alloc > 0 ? 512 / alloc : 8;
-      if (nb > by_vgpr) nb = by_vgpr;
-      if (nb > 8) nb = 8;
-      occ = nb > 0 ? nb : 1;
+      const int q = resident_blocks(sfn);
+      if (q < 0) return -q;
+      occ = q;
     }
     const int64_t tile_envs = (int64_t)BLOCK * epl * (1 << lu);
     const int64_t ntile = (io->B + tile_envs - 1) / tile_envs;
@@ -1768,6 +1798,115 @@ int pcg_reset(pcg_plan* p, const pcg_buffers* io, const uint8_t* mask, uint64_t 
   a.seed = seed;
   hipLaunchKernelGGL(reset_kernel, dim3(grid_for(io->B)), dim3(BLOCK), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
+}
+
+// ---- step graph: T pcg_step launches recorded once, replayed with one host call ------------------------------
+struct pcg_graph {
+  uint32_t magic;
+  int device;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  int n_nodes;
+};
+static constexpr uint32_t GRAPH_MAGIC = 0x50434747u;  // 'PCGG'
+
+int pcg_graph_create(pcg_graph** out, pcg_plan* p, const pcg_buffers* io, const double* const* a_steps,
+                     const double* const* d_steps, int32_t t0, int32_t T, uint64_t seed, int with_reset) {
+  if (!out) return PCG_E_NULL;
+  *out = nullptr;
+  if (!plan_ok(p)) return PCG_E_PLAN;
+  if (!io || !a_steps) return PCG_E_NULL;
+  if (io->t) return PCG_E_UNSUPPORTED;
+  if (T <= 0 || t0 < 0 || io->B <= 0) return PCG_E_DIM;
+  for (int j = 0; j < T; ++j)
+    if (!a_steps[j] || (d_steps && !d_steps[j])) return PCG_E_NULL;
+  pcg_buffers b = *io;
+  {
+    const int wrc = warm_occupancy(p);  // launch geometry is queried lazily: do it outside the capture
+    if (wrc != PCG_OK) return wrc;
+  }
+  hipStream_t cs;
+  HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  int rc = PCG_OK;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    hipStreamDestroy(cs);
+    return (int)e;
+  }
+  if (with_reset) rc = pcg_reset(p, &b, nullptr, seed, cs);
+  for (int j = 0; j < T && rc == PCG_OK; ++j) {
+    b.a = a_steps[j];
+    b.d = d_steps ? d_steps[j] : nullptr;
+    rc = pcg_step(p, &b, t0 + j, seed, cs);
+  }
+  e = hipStreamEndCapture(cs, &g);
+  hipStreamDestroy(cs);
+  if (rc != PCG_OK) {
+    if (g) hipGraphDestroy(g);
+    return rc;
+  }
+  if (e != hipSuccess) return (int)e;
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    hipGraphDestroy(g);
+    return (int)e;
+  }
+  pcg_graph* q = new (std::nothrow) pcg_graph();
+  if (!q) {
+    hipGraphExecDestroy(ex);
+    hipGraphDestroy(g);
+    return PCG_E_VALUE;
+  }
+  q->magic = GRAPH_MAGIC;
+  q->device = p->device;
+  q->graph = g;
+  q->exec = ex;
+  q->n_nodes = T + (with_reset ? 1 : 0);
+  *out = q;
+  return PCG_OK;
+}
+
+int pcg_graph_launch(pcg_graph* q, void* stream) {
+  if (!q || q->magic != GRAPH_MAGIC) return PCG_E_PLAN;
+  return (int)hipGraphLaunch(q->exec, (hipStream_t)stream);
+}
+
+int pcg_graph_set_seed(pcg_graph* q, uint64_t seed) {
+  if (!q || q->magic != GRAPH_MAGIC) return PCG_E_PLAN;
+  size_t n = 0;
+  HIP_TRY(hipGraphGetNodes(q->graph, nullptr, &n));
+  std::vector<hipGraphNode_t> nodes(n);
+  HIP_TRY(hipGraphGetNodes(q->graph, nodes.data(), &n));
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType ty;
+    HIP_TRY(hipGraphNodeGetType(nodes[i], &ty));
+    if (ty != hipGraphNodeTypeKernel) continue;
+    hipKernelNodeParams kp;
+    HIP_TRY(hipGraphKernelNodeGetParams(nodes[i], &kp));
+    if (!kp.kernelParams || !kp.kernelParams[0]) return PCG_E_UNSUPPORTED;
+    // every kernel this library records takes one by-value StepArgs: re-key it in the graph and in the executable
+    StepArgs a;
+    std::memcpy(&a, kp.kernelParams[0], sizeof(a));
+    a.seed = seed;
+    void* argv[1] = {&a};
+    kp.kernelParams = argv;
+    kp.extra = nullptr;
+    HIP_TRY(hipGraphKernelNodeSetParams(nodes[i], &kp));
+    HIP_TRY(hipGraphExecKernelNodeSetParams(q->exec, nodes[i], &kp));
+  }
+  return PCG_OK;
+}
+
+int pcg_graph_destroy(pcg_graph* q) {
+  if (!q) return PCG_OK;
+  if (q->magic != GRAPH_MAGIC) return PCG_E_PLAN;
+  hipGraphExecDestroy(q->exec);
+  hipGraphDestroy(q->graph);
+  q->magic = 0;
+  delete q;
+  return PCG_OK;
 }
 
 int pcg_rhs(pcg_plan* p, int64_t B, const double* x, const double* u, double* dx, void* stream) {

@@ -250,6 +250,18 @@ class VecEnv:
         self.t += T
         return obs_seq, rew_seq
 
+    def capture_steps(self, actions, disturbances=None, with_reset=False):
+        """Record ``len(actions)`` consecutive step() launches (starting at the current ``t``, or at a
+        full reset if ``with_reset``) as one HIP graph over this env's buffers.
+
+        actions : sequence of (na,B) SoA tensors (kept alive by the returned object; entries may repeat).
+        Returns a :class:`StepGraph`; ``graph.replay()`` runs the recorded steps with one host call and
+        advances ``t`` -- same kernels and results as the step() loop, without the launch-to-launch gap.
+        """
+        if self.per_env_t:
+            raise ValueError("capture_steps() is lock-stepped only")
+        return StepGraph(self, actions, disturbances, with_reset)
+
     # state_dict for checkpoint/resume of the env batch
     def state_dict(self):
         d = {"x": self.x.clone(), "t": self.t, "episode": self.episode, "seed0": self.seed0}
@@ -266,6 +278,63 @@ class VecEnv:
             self.a_save_t.copy_(d["a_save"])
         if self.t_env is not None:
             self.t_env.copy_(d["t_env"])
+
+
+class StepGraph:
+    """T recorded step() launches of one VecEnv (pcg_graph_* in include/pcgym_hip.h)."""
+
+    def __init__(self, env, actions, disturbances=None, with_reset=False):
+        s = env.spec
+        self.env = env
+        self.T = T = len(actions)
+        self.with_reset = bool(with_reset)
+        self.t0 = 0 if with_reset else env.t
+        if T < 1 or self.t0 + T > env.N - 1:
+            raise ValueError(f"cannot record {T} steps from t={self.t0}: an episode has {env.N - 1} steps")
+        self._a = [env._as_soa(a, s.na, "action") for a in actions]
+        self._d = None
+        ap = (C.c_void_p * T)(*[a.data_ptr() for a in self._a])
+        dp = None
+        if disturbances is not None:
+            if len(disturbances) != T:
+                raise ValueError("one disturbance slab per recorded step")
+            self._d = [env._as_soa(d, s.nd, "disturbance") for d in disturbances]
+            dp = (C.c_void_p * T)(*[d.data_ptr() for d in self._d])
+        self._uses_rng = bool(s.noise or s.gauss or (with_reset and (s.nunc or s.x0_unc is not None)))
+        self._seed = (env.seed0 + env.episode + (1 if with_reset else 0)) & 0xFFFFFFFFFFFFFFFF
+        g = C.c_void_p()
+        with _torch().cuda.device(env.device):
+            _lib.check(env._lib.pcg_graph_create(C.byref(g), env._plan, env._bufp, ap, dp, self.t0, T, self._seed,
+                                                 int(self.with_reset)), "pcg_graph_create")
+        self._g = g
+
+    def replay(self):
+        """Run the recorded steps on the current stream; returns (obs, rew, done) of the last one."""
+        env = self.env
+        if self._g is None:
+            raise RuntimeError("StepGraph was destroyed")
+        if self.with_reset:
+            env.episode += 1
+        elif env.t != self.t0:
+            raise ValueError(f"graph was recorded at t={self.t0}, env is at t={env.t}")
+        seed = env._episode_seed()
+        if seed != self._seed and self._uses_rng:  # new episode: re-key the in-kernel RNG, no re-recording
+            _lib.check(env._lib.pcg_graph_set_seed(self._g, seed), "pcg_graph_set_seed")
+            self._seed = seed
+        _lib.check(env._lib.pcg_graph_launch(self._g, env._stream()), "pcg_graph_launch")
+        env.t = self.t0 + self.T
+        return env.obs, env.rew, env.done.view(_torch().bool)
+
+    def destroy(self):
+        if getattr(self, "_g", None) is not None:
+            self.env._lib.pcg_graph_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 def make_vec_env(env_params, n_envs, **kw):

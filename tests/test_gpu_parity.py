@@ -405,6 +405,65 @@ def test_rollout_equals_stepping():
         e2.close()
 
 
+def test_step_graph_equals_stepping():
+    """pcg_graph_*: the recorded launches are the same kernels on the same buffers -> bit-identical to the
+    step() loop, including a re-keyed RNG on the second episode (pcg_graph_set_seed)."""
+    torch = _torch()
+    import copy
+
+    from pcgym_amd import VecEnv
+
+    # (a) lean path (the headline kernel), steps only, recorded mid-episode
+    sc = SC.scenarios()["cstr_canonical"]
+    B, T = 4096, 12
+    e1 = VecEnv(copy.deepcopy(sc["env_params"]), n_envs=B)
+    e2 = VecEnv(copy.deepcopy(sc["env_params"]), n_envs=B)
+    acts = torch.tensor(_rand_actions(e1.spec, T + 3, B, 9), device=e1.device)
+    e1.reset()
+    e2.reset()
+    for i in range(3):
+        e1.step(acts[i])
+        e2.step(acts[i])
+    g = e2.capture_steps([acts[3 + i] for i in range(T)])
+    for i in range(T):
+        e1.step(acts[3 + i])
+    o, r, d = g.replay()
+    assert e2.t == e1.t == 3 + T
+    assert torch.equal(e1.x, e2.x) and torch.equal(e1.obs_soa, e2.obs_soa) and torch.equal(e1.rew, e2.rew)
+    assert torch.equal(e1.done, e2.done)
+    with pytest.raises(ValueError):
+        g.replay()  # env is no longer at the recorded t
+    g.destroy()
+    with pytest.raises(ValueError):
+        e2.capture_steps([acts[0]] * e2.N)  # longer than an episode
+    e1.close()
+    e2.close()
+
+    # (b) noisy path with reset inside the graph, two episodes: the second replay must use seed + 2
+    sc = SC.scenarios()["cstr_dist_Ti"]
+    p = copy.deepcopy(sc["env_params"])
+    p.update(noise=True, noise_percentage=0.01, gaussian_disturbances={"Ti": 2.0})
+    B = 1000
+    e1 = VecEnv(copy.deepcopy(p), n_envs=B, seed=5)
+    e2 = VecEnv(copy.deepcopy(p), n_envs=B, seed=5)
+    T = e1.N - 1
+    acts = torch.tensor(_rand_actions(e1.spec, T, B, 2), device=e1.device)
+    g = e2.capture_steps([acts[i] for i in range(T)], with_reset=True)
+    first = None
+    for ep in range(2):
+        e1.reset()
+        for i in range(T):
+            e1.step(acts[i])
+        g.replay()
+        assert e1.episode == e2.episode and e1.t == e2.t
+        assert torch.equal(e1.x, e2.x) and torch.equal(e1.obs_soa, e2.obs_soa) and torch.equal(e1.rew, e2.rew)
+        if first is None:
+            first = e2.obs_soa.clone()
+    assert not torch.equal(first, e2.obs_soa)  # fresh noise in episode 2
+    e1.close()
+    e2.close()
+
+
 # ------------------------------------------------ full-size property tests ---
 def test_full_size_cstr_properties():
     """BASELINE.json configs[1] size (B = 2^20): size-independent properties.

@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256) void k6(Args A) {
   if ((threadIdx.x & 63) == 0) ((unsigned long long*)A.done)[e >> 6] = m;  // bitmask variant (1 bit/env)
 }
 
-int main() {
+int main(int argc, char** argv) {
+  // launches per timed loop; the GPU needs ~50 ms of work to reach steady clocks: pass 3000 for the warm floor
+  const int n_timed = argc > 1 ? atoi(argv[1]) : 300;
   const int64_t B = 1 << 20;
   const int NA = 64;
   double *x, *a, *xo, *obs, *rew;
@@ -123,9 +125,9 @@ int main() {
   CK(hipEventCreate(&e1));
   const double bytes = 73.0 * B;
   auto run = [&](const char* name, auto launch) -> int {
-    for (int i = 0; i < 20; ++i) launch(i);
+    for (int i = 0; i < n_timed / 10 + 20; ++i) launch(i);
     CK(hipDeviceSynchronize());
-    const int n = 300;
+    const int n = n_timed;
     CK(hipEventRecord(e0));
     for (int i = 0; i < n; ++i) launch(i);
     CK(hipEventRecord(e1));

@@ -8,11 +8,13 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 118 --warmup 59 --no-cpu-baseline $*"
+# the default bench.py run (5900 timed + 590 warm-up launches: the GPU needs ~50 ms to reach steady clocks)
+ARGS="--no-cpu-baseline $*"
+PMC_ARGS="--steps 590 --warmup 590 --no-cpu-baseline $*"  # counters are clock-independent: shorter
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$name -o p -- python $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_$name.log
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$name -o p -- python $ROOT/bench.py $PMC_ARGS > /dev/null 2> $OUT/pmc_$name.log
 done
 python $ROOT/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
