@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=590)
     ap.add_argument("--batch", type=int, default=1 << 20, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preheat-ms", type=float, default=100.0,
+                    help="untimed GPU clock pre-heat before the warm-up steps (0 = off)")
     ap.add_argument("--graph", action="store_true",
                     help="replay whole episodes as one HIP graph (pcg_graph_*) instead of eager launches; "
                          "measured within 1 %% of eager once the GPU is warm, so eager stays the default")
@@ -215,6 +217,16 @@ def main():
             if env.t == last_t:
                 env.reset()
 
+    # Clock pre-heat (untimed, before the W warm-up steps): an idle MI355X needs ~50 ms of work to reach
+    # steady clocks -- with a short --warmup the first timed launches would otherwise run 10-15 % slow
+    # (profiles/README.md).  Same kernel, same buffers; reported as config.preheat_launches.
+    preheat = 0
+    if args.preheat_ms > 0:
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
+            run(last_t, False)
+            torch.cuda.synchronize()
+            preheat += last_t
     run(W, False)
     torch.cuda.synchronize()
     if dist is not None:
@@ -260,6 +272,7 @@ def main():
             "integrator": "rk4, 1 step per dt=1s (1/60 model time unit)",
             "episode_len": spec.N - 1,
             "parallelism": f"env-shard x{world} (no collective on the hot path)",
+            "preheat_launches": preheat,
             "launch": ("eager pcg_step launches" if graph is None else
                        f"HIP graph of one {last_t}-step episode (pcg_graph_*), eager pcg_reset between episodes"),
             "finite": finite,

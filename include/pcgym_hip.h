@@ -43,8 +43,8 @@ extern "C" {
 #endif
 
 /* capacity limits (compile-time; per-lane state lives in VGPRs) */
-#define PCG_MAX_NX 20     /* physical states          */
-#define PCG_MAX_NA 4      /* action dims              */
+#define PCG_MAX_NX 24     /* physical states          */
+#define PCG_MAX_NA 5      /* action dims              */
 #define PCG_MAX_NDM 4     /* model disturbance inputs */
 #define PCG_MAX_NSP 4     /* set-point keys           */
 #define PCG_MAX_NCON 8    /* constraint rows          */
@@ -83,7 +83,11 @@ enum pcg_model {
   PCG_MODEL_CSTR_SERIES = 10,  /* model_classes.py:611-679  nx=4 nu=4            */
   PCG_MODEL_DISTILLATION = 11, /* model_classes.py:682-760  nx=9 nu=2            */
   PCG_MODEL_POLYMER = 12,      /* model_classes.py:1158-1229 nx=3 nu=4           */
-  PCG_MODEL_COUNT = 13
+  PCG_MODEL_BIOFILM = 13,      /* model_classes.py:1046-1155 nx=16 nu=5          */
+  PCG_MODEL_HEAT_EX = 14,      /* model_classes.py:935-1044 nx=24 nu=4           */
+  PCG_MODEL_INV_BATCH = 15,    /* model_classes.py:268-293 nx=4, no inputs (one ignored dummy action) */
+  PCG_MODEL_OSCILLATORS = 16,  /* model_classes.py:186-216 nx=20 (N=10), no inputs (dummy action)     */
+  PCG_MODEL_COUNT = 17
 };
 
 /* integrators replacing integrator.py:90-107 (CVODES) / :65-88 (diffrax Tsit5) */

@@ -269,6 +269,76 @@ static void rhs_polymer(const double* p, const double* x, const double* u, int n
   dx[2] = (F / V) * (If - I) - ri;
 }
 
+/* model_classes.py:1076-1139.  p = V,Va,Kla,m,eq_exponent,O_air,vm_1,vm_2,K1,K2,KO_1,KO_2 ;
+ * x = S1_1,S2_1,S3_1,O_1, ..._2, ..._3, S1_A,S2_A,S3_A,O_A ; u = F,Fr,S1_F,S2_F,S3_F */
+static void rhs_biofilm(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu;
+  double V = p[0], Va = p[1], Kla = p[2], m = p[3], eq_exponent = p[4], O_air = p[5], vm_1 = p[6], vm_2 = p[7],
+         K1 = p[8], K2 = p[9], KO_1 = p[10], KO_2 = p[11];
+  double F = u[0], Fr = u[1], S1_F = u[2], S2_F = u[3], S3_F = u[4];
+  const double *A = x + 12;
+  for (int s = 0; s < 3; ++s) {
+    const double *c = x + 4 * s, *up = (s == 0) ? A : x + 4 * (s - 1);
+    double S1 = c[0], S2 = c[1], S3 = c[2], O = c[3];
+    double r1 = ((vm_1 * S1) / (K1 + S1)) * ((O) / (KO_1 + O));
+    double r2 = ((vm_2 * S2) / (K2 + S2)) * ((O) / (KO_2 + O));
+    double ro = -r1 * 3.5 - r2 * 1.1;
+    double rs1 = -r1, rs2 = +r1 - r2, rs3 = r2;
+    dx[4 * s + 0] = (Fr / V) * (up[0] - S1) - rs1;
+    dx[4 * s + 1] = (Fr / V) * (up[1] - S2) - rs2;
+    dx[4 * s + 2] = (Fr / V) * (up[2] - S3) - rs3;
+    dx[4 * s + 3] = (Fr / V) * (up[3] - O) - ro;
+  }
+  double O_Aeq = (pow(O_air, eq_exponent) / m);
+  dx[12] = (Fr / Va) * (x[8] - A[0]) + (F / Va) * (S1_F - A[0]);
+  dx[13] = (Fr / Va) * (x[9] - A[1]) + (F / Va) * (S2_F - A[1]);
+  dx[14] = (Fr / Va) * (x[10] - A[2]) + (F / Va) * (S3_F - A[2]);
+  dx[15] = (Fr / Va) * (x[11] - A[3]) + Kla * (O_Aeq - A[3]);
+}
+
+/* model_classes.py:963-1029.  p = Utm,Usm,L,Dt,Dm,Ds,cpt,cpm,cps,rhot,rhom,rhos ;
+ * x = Tt1,Tm1,Ts1,...,Tt8,Tm8,Ts8 ; u = Ft,Fs,Tt0,Ts9 */
+static void rhs_heat_exchanger(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu;
+  double Utm = p[0], Usm = p[1], L = p[2], Dt = p[3], Dm = p[4], Ds = p[5], cpt = p[6], cpm = p[7], cps = p[8],
+         rhot = p[9], rhom = p[10], rhos = p[11];
+  double Ft = u[0], Fs = u[1], Tt0 = u[2], Ts9 = u[3];
+  const double M_PI_ = 3.14159265358979323846; /* numpy.pi */
+  double Vt = L * M_PI_ * (Dt * Dt), At = L * M_PI_ * Dt, Vm = L * M_PI_ * (Dm * Dm - Dt * Dt), Am = L * M_PI_ * Dm;
+  double Vs = L * M_PI_ * (Ds * Ds - Dm * Dm);
+  for (int i = 0; i < 8; ++i) {
+    double Tt = x[3 * i], Tm = x[3 * i + 1], Ts = x[3 * i + 2];
+    double Qt = Utm * At * (Tt - Tm), Qm = Usm * Am * (Tm - Ts);
+    double Tt_in = (i == 0) ? Tt0 : x[3 * (i - 1)];
+    double Ts_in = (i == 7) ? Ts9 : x[3 * (i + 1) + 2];
+    dx[3 * i] = (1 / (cpt * rhot * Vt)) * (Ft * cpt * (Tt_in - Tt) - Qt);
+    dx[3 * i + 1] = (1 / (cpm * rhom * Vm)) * (Qt - Qm);
+    dx[3 * i + 2] = (1 / (cps * rhos * Vs)) * (Fs * cps * (Ts_in - Ts) + Qm);
+  }
+}
+
+/* model_classes.py:283-291.  p = k1f,k1r,k2f,k2r ; x = xA,xB,xC,xD ; the model has no inputs (u ignored) */
+static void rhs_invariant_batch(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu; (void)u;
+  double k1f = p[0], k1r = p[1], k2f = p[2], k2r = p[3], xA = x[0], xB = x[1], xC = x[2], xD = x[3];
+  dx[0] = -(k1f * xA * xB - k1r * xC) - (k2f * xA * xC - k2r * xD);
+  dx[1] = -(k1f * xA * xB - k1r * xC);
+  dx[2] = (k1f * xA * xB - k1r * xC) - (k2f * xA * xC - k2r * xD);
+  dx[3] = k2f * xA * xC - k2r * xD;
+}
+
+/* model_classes.py:201-216.  p = N,k,m (N = 10) ; x = positions[10], momenta[10] ; no inputs (u ignored) */
+static void rhs_oscillators(const double* p, const double* x, const double* u, int nu, double* dx) {
+  (void)nu; (void)u;
+  int N = 10;
+  double k = p[1], m = p[2];
+  for (int i = 0; i < N; ++i) {
+    double left = x[(i - 1 + N) % N], right = x[(i + 1) % N];
+    dx[i] = x[N + i] / m;
+    dx[N + i] = -k * (2 * x[i] - left - right);
+  }
+}
+
 typedef struct {
   int model_id, nx, nu;
   const double* p;
@@ -288,6 +358,10 @@ static void rhs(const orc_model* m, const double* x, const double* u, double* dx
     case PCG_MODEL_CSTR_SERIES: rhs_cstr_series(m->p, x, u, m->nu, dx); break;
     case PCG_MODEL_DISTILLATION: rhs_distillation(m->p, x, u, m->nu, dx); break;
     case PCG_MODEL_POLYMER: rhs_polymer(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_BIOFILM: rhs_biofilm(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_HEAT_EX: rhs_heat_exchanger(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_INV_BATCH: rhs_invariant_batch(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_OSCILLATORS: rhs_oscillators(m->p, x, u, m->nu, dx); break;
     default: rhs_affine(m->p, m->nx, x, u, m->nu, dx); break;
   }
 }

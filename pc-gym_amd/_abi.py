@@ -8,8 +8,8 @@ from __future__ import annotations
 import ctypes as C
 
 PCG_ABI_VERSION = 1
-PCG_MAX_NX = 20
-PCG_MAX_NA = 4
+PCG_MAX_NX = 24
+PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
 PCG_MAX_NSP = 4
 PCG_MAX_NCON = 8

@@ -31,6 +31,7 @@ from . import models as M
 DEFAULT_INTEGRATOR = {
     M.COMPLEX_CSTR: "dopri5", M.DISEASE: "dopri5", M.BATCH: "dopri5", M.PHOTO: "dopri5", M.CSTR_SERIES: "dopri5",
     M.DISTILLATION: "dopri5", M.POLYMER: "dopri5",   # no tuned fixed step yet: adaptive by default
+    M.BIOFILM: "dopri5", M.HEAT_EX: "dopri5", M.INV_BATCH: "dopri5", M.OSCILLATORS: "dopri5",
     M.CSTR: "rk4",
     M.FOUR_TANK: "rk4",
     M.ME: "dopri5",           # stiff at high L,G (|lambda| dt up to ~240): adaptive
@@ -49,7 +50,7 @@ DEFAULT_RK4_H = {M.CSTR: 26.0 / 60.0 / 4, M.FOUR_TANK: 1000.0 / 60.0 / 4, M.ME: 
 
 
 def default_substeps(model_id, dt):
-    h = DEFAULT_RK4_H[model_id]
+    h = DEFAULT_RK4_H.get(model_id)
     if h is None:
         return 8
     return max(1, int(np.ceil(dt / h - 1e-9)))
@@ -160,7 +161,15 @@ class EnvSpec:
         info = self.model.info()
         self.nx = len(info["states"])
         self.nu_inputs = len(info["inputs"])
-        if self.nu_inputs != self.na:
+        # Models without inputs (invariant_batch, coupled_oscillator; model_classes.py:200,282): the kernels carry
+        # one dummy action the RHS ignores.  An empty a_space (the literal reading of info()["inputs"] == [])
+        # and a 1-entry placeholder a_space (what runs through the reference unchanged) are both accepted.
+        self.na_user = self.na
+        if self.nu_inputs == 0 and self.na in (0, 1):
+            if self.na == 0:
+                self.a_low = self.a_high = np.zeros(1)
+                self.na = 1
+        elif self.nu_inputs != self.na:
             raise ValueError(f"a_space has {self.na} entries but the model has {self.nu_inputs} inputs")
 
         # --- SP ------------------------------------------------------------------

@@ -1251,7 +1251,9 @@ static const Kernels& kernels(int id) {
       make_kernels<PCG_MODEL_COMPLEX_CSTR>(), make_kernels<PCG_MODEL_DISEASE>(),
       make_kernels<PCG_MODEL_BATCH>(),       make_kernels<PCG_MODEL_PHOTO>(),
       make_kernels<PCG_MODEL_CSTR_SERIES>(), make_kernels<PCG_MODEL_DISTILLATION>(),
-      make_kernels<PCG_MODEL_POLYMER>()};
+      make_kernels<PCG_MODEL_POLYMER>(),     make_kernels<PCG_MODEL_BIOFILM>(),
+      make_kernels<PCG_MODEL_HEAT_EX>(),     make_kernels<PCG_MODEL_INV_BATCH>(),
+      make_kernels<PCG_MODEL_OSCILLATORS>()};
   return K[id];
 }
 
@@ -1270,9 +1272,15 @@ static const double DEF_PHOTO[] = {0.0572, 0.0, 504.5, 0.00016, 0.281, 23.51, 16
 static const double DEF_CSTR_SERIES[] = {97.35, 298, 1e-3, 2e-3, 0.461, 0.732, 1.05e3, 3.766, 3.118e5, 46.14, 58.41, 8.3145e-3};
 static const double DEF_DISTILLATION[] = {100.0, 1.0, 5.0, 0.2, 2000.0, 2000.0, 2000.0};
 static const double DEF_POLYMER[] = {6e10, 4e10, 9e10, 7750, 8500, 8250, 0.5, 1.0, -3e4, 1200.0, 2.0};
+// model_classes.py:1062-1073, 949-960, 269-272, 187-189
+static const double DEF_BIOFILM[] = {10.0, 15.0, 1.5, 0.5, 1.0, 300, 0.8, 1.0, 0.5, 0.1, 1.5, 0.5};
+static const double DEF_HEAT_EX[] = {1, 1, 1, 1, 2, 3, 1, 1, 1, 1, 1, 1};
+static const double DEF_INV_BATCH[] = {55.0, 1.0, 2.0, 1.0};
+static const double DEF_OSCILLATORS[] = {10, 1.0, 1.0};
 static const double* const DEFAULTS[] = {DEF_CSTR,        DEF_FOUR_TANK, DEF_ME,    DEF_ME_REACTIVE, DEF_CRYST,
                                          nullptr,         DEF_COMPLEX_CSTR, DEF_DISEASE, DEF_BATCH, DEF_PHOTO,
-                                         DEF_CSTR_SERIES, DEF_DISTILLATION, DEF_POLYMER};
+                                         DEF_CSTR_SERIES, DEF_DISTILLATION, DEF_POLYMER, DEF_BIOFILM,
+                                         DEF_HEAT_EX,     DEF_INV_BATCH,    DEF_OSCILLATORS};
 
 }  // namespace pcg
 
@@ -1365,6 +1373,8 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
     if (nx != k.nx || na != k.na) return PCG_E_DIM;
     if (ndm != 0 && ndm != k.ndm) return PCG_E_DIM;
     if (c->n_params != k.nraw) return PCG_E_DIM;
+    // coupled_oscillators: the ring size is a structural parameter, only the reference default N = 10 is compiled
+    if (c->model_id == PCG_MODEL_OSCILLATORS && (!c->params || c->params[0] != 10.0)) return PCG_E_UNSUPPORTED;
   }
   if (nd < 0 || nd > ndm || nsp < 0 || nsp > PCG_MAX_NSP || ncon < 0 || ncon > PCG_MAX_NCON) return PCG_E_DIM;
   const int nso = c->nsp_obs;

@@ -663,4 +663,158 @@ struct Model<PCG_MODEL_POLYMER> {
   }
 };
 
+// biofilm_reactor -- model_classes.py:1046-1155.
+// raw = V,Va,Kla,m,eq_exponent,O_air,vm_1,vm_2,K1,K2,KO_1,KO_2 ; u = [F,Fr,S1_F,S2_F,S3_F]
+// x = (S1,S2,S3,O) for reactor stages 1..3, then the absorber tank A
+template <>
+struct Model<PCG_MODEL_BIOFILM> {
+  static constexpr int NX = 16, NA = 5, NDM = 0, NRAW = 12;
+  static constexpr bool DYNAMIC = false, FULL = false;
+  struct KP {
+    double iV, iVa, Kla, OAeq, vm1, vm2, K1, K2, KO1, KO2;
+  };
+  using CKP = const PCG_CONSTANT KP;
+  template <class R>
+  struct HoldT {
+    R FrV, FrVa, FVa, S1F, S2F, S3F;
+  };
+  using Hold = HoldT<double>;
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
+    KP k{1 / r[0], 1 / r[1], r[2], pow(r[5], r[4]) / r[3], r[6], r[7], r[8], r[9], r[10], r[11]};
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K& k, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[1] * k.iV, u[1] * k.iVa, u[0] * k.iVa, u[2], u[3], u[4]};
+  }
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int c = 4 * s, pv = (s == 0) ? 12 : 4 * (s - 1);  // upstream: absorber for stage 1
+      const R S1 = x[c], S2 = x[c + 1], S3 = x[c + 2], O = x[c + 3];
+      const R r1 = ((k.vm1 * S1) / (k.K1 + S1)) * (O / (k.KO1 + O));
+      const R r2 = ((k.vm2 * S2) / (k.K2 + S2)) * (O / (k.KO2 + O));
+      // the reference subtracts rs1 = -r1, rs2 = r1 - r2, rs3 = r2, ro = -3.5 r1 - 1.1 r2 (signs kept as written there)
+      dx[c] = h.FrV * (x[pv] - S1) + r1;
+      dx[c + 1] = h.FrV * (x[pv + 1] - S2) - (r1 - r2);
+      dx[c + 2] = h.FrV * (x[pv + 2] - S3) - r2;
+      dx[c + 3] = h.FrV * (x[pv + 3] - O) - (-r1 * 3.5 - r2 * 1.1);
+    }
+    dx[12] = h.FrVa * (x[8] - x[12]) + h.FVa * (h.S1F - x[12]);
+    dx[13] = h.FrVa * (x[9] - x[13]) + h.FVa * (h.S2F - x[13]);
+    dx[14] = h.FrVa * (x[10] - x[14]) + h.FVa * (h.S3F - x[14]);
+    dx[15] = h.FrVa * (x[11] - x[15]) + k.Kla * (k.OAeq - x[15]);
+  }
+};
+
+// heat_exchanger -- model_classes.py:935-1044.  raw = Utm,Usm,L,Dt,Dm,Ds,cpt,cpm,cps,rhot,rhom,rhos
+// x = (Tt,Tm,Ts) for segments 1..8 ; u = [Ft,Fs,Tt0,Ts9]  (tube flows 1->8, shell flows 8->1)
+template <>
+struct Model<PCG_MODEL_HEAT_EX> {
+  static constexpr int NX = 24, NA = 4, NDM = 0, NRAW = 12;
+  static constexpr bool DYNAMIC = false, FULL = false;
+  struct KP {
+    double ct, cm, cs, UAt, UAm, cpt, cps;
+  };
+  using CKP = const PCG_CONSTANT KP;
+  template <class R>
+  struct HoldT {
+    R Ftc, Fsc, Tt0, Ts9;
+  };
+  using Hold = HoldT<double>;
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
+    const double pi = 3.141592653589793;
+    const double L = r[2], Dt = r[3], Dm = r[4], Ds = r[5];
+    const double Vt = L * pi * (Dt * Dt), At = L * pi * Dt, Vm = L * pi * (Dm * Dm - Dt * Dt), Am = L * pi * Dm;
+    const double Vs = L * pi * (Ds * Ds - Dm * Dm);
+    KP k{1 / (r[6] * r[9] * Vt), 1 / (r[7] * r[10] * Vm), 1 / (r[8] * r[11] * Vs), r[0] * At, r[1] * Am, r[6], r[8]};
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K& k, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[0] * k.cpt, u[1] * k.cps, u[2], u[3]};
+  }
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const R Tt = x[3 * i], Tm = x[3 * i + 1], Ts = x[3 * i + 2];
+      const R Qt = k.UAt * (Tt - Tm), Qm = k.UAm * (Tm - Ts);
+      const R Tt_up = (i == 0) ? h.Tt0 : x[3 * (i - 1)];
+      const R Ts_up = (i == 7) ? h.Ts9 : x[3 * (i + 1) + 2];
+      dx[3 * i] = k.ct * (h.Ftc * (Tt_up - Tt) - Qt);
+      dx[3 * i + 1] = k.cm * (Qt - Qm);
+      dx[3 * i + 2] = k.cs * (h.Fsc * (Ts_up - Ts) + Qm);
+    }
+  }
+};
+
+// invariant_batch -- model_classes.py:268-293.  raw = k1f,k1r,k2f,k2r ; x = xA,xB,xC,xD ; no inputs:
+// the kernels carry one dummy action that the RHS ignores (the host passes zeros).
+template <>
+struct Model<PCG_MODEL_INV_BATCH> {
+  static constexpr int NX = 4, NA = 1, NDM = 0, NRAW = 4;
+  static constexpr bool DYNAMIC = false, FULL = false;
+  struct KP {
+    double k1f, k1r, k2f, k2r;
+  };
+  using CKP = const PCG_CONSTANT KP;
+  template <class R>
+  struct HoldT {
+    R none;
+  };
+  using Hold = HoldT<double>;
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
+    KP k{r[0], r[1], r[2], r[3]};
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K&, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[0]};
+  }
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>&, const R (&x)[NX], R (&dx)[NX]) {
+    const R r1 = k.k1f * x[0] * x[1] - k.k1r * x[2];
+    const R r2 = k.k2f * x[0] * x[2] - k.k2r * x[3];
+    dx[0] = -r1 - r2;
+    dx[1] = -r1;
+    dx[2] = r1 - r2;
+    dx[3] = r2;
+  }
+};
+
+// coupled_oscillators -- model_classes.py:186-216, N = 10 (ring of masses).  raw = N,k,m ;
+// x = x1..x10, p1..p10 ; no inputs (dummy action as above).
+template <>
+struct Model<PCG_MODEL_OSCILLATORS> {
+  static constexpr int NX = 20, NA = 1, NDM = 0, NRAW = 3;
+  static constexpr bool DYNAMIC = false, FULL = false;
+  struct KP {
+    double k, m;
+  };
+  using CKP = const PCG_CONSTANT KP;
+  template <class R>
+  struct HoldT {
+    R none;
+  };
+  using Hold = HoldT<double>;
+  PCG_HD static void prep(const double* r, int, int, double* kp_out, double*) {
+    KP k{r[1], r[2]};
+    __builtin_memcpy(kp_out, &k, sizeof(k));
+  }
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K&, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[0]};
+  }
+  template <class R, class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<R>&, const R (&x)[NX], R (&dx)[NX]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      dx[i] = x[10 + i] / k.m;
+      dx[10 + i] = -k.k * (2.0 * x[i] - x[(i + 9) % 10] - x[(i + 1) % 10]);
+    }
+  }
+};
+
 }  // namespace pcg

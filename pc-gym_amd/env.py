@@ -86,9 +86,9 @@ class VecEnv:
         else:
             self.observation_space = self.observation_space_base
         if s.normalise_a:
-            self.action_space = Box(-np.ones(s.na), np.ones(s.na))
+            self.action_space = Box(-np.ones(s.na_user), np.ones(s.na_user))
         else:
-            self.action_space = Box(s.a_low, s.a_high)
+            self.action_space = Box(s.a_low[:s.na_user], s.a_high[:s.na_user])
 
         cfg, keep = s.to_cfg()
         plan = C.c_void_p()
@@ -138,6 +138,7 @@ class VecEnv:
         self._bufp = C.byref(b)
         self._a_hold = None
         self._d_hold = None
+        self._zero_a = None
 
     # ------------------------------------------------------------------
     def close(self):
@@ -183,6 +184,10 @@ class VecEnv:
 
     def _as_soa(self, v, rows, what):
         torch = _torch()
+        if what == "action" and self.spec.na_user == 0:  # model without inputs: the kernels' dummy action
+            if self._zero_a is None:
+                self._zero_a = torch.zeros((1, self.B), dtype=torch.float64, device=self.device)
+            return self._zero_a
         if not torch.is_tensor(v):
             v = torch.as_tensor(np.asarray(v, dtype=np.float64), device=self.device)
         v = v.to(device=self.device, dtype=torch.float64)

@@ -12,6 +12,7 @@ from collections import OrderedDict
 # ids must match enum pcg_model in include/pcgym_hip.h
 CSTR, FOUR_TANK, ME, ME_REACTIVE, CRYST, AFFINE = range(6)
 COMPLEX_CSTR, DISEASE, BATCH, PHOTO, CSTR_SERIES, DISTILLATION, POLYMER = range(6, 13)
+BIOFILM, HEAT_EX, INV_BATCH, OSCILLATORS = range(13, 17)
 
 
 class ModelInfo:
@@ -119,6 +120,30 @@ def _registry():
         "polymerisation_reactor", POLYMER, ["T", "M", "I"], ["F", "Tf", "Mf", "If"], [],
         [("Ap", 6e10), ("Ad", 4e10), ("At", 9e10), ("Ep_over_R", 7750.0), ("Ed_over_R", 8500.0),
          ("Et_over_R", 8250.0), ("f", 0.5), ("V", 1.0), ("deltaHp", -3e4), ("rho", 1200.0), ("cp", 2.0)])
+    # model_classes.py:1062-1073, 1148-1150
+    st = []
+    for s in ("1", "2", "3", "A"):
+        st += [f"S1_{s}", f"S2_{s}", f"S3_{s}", f"O_{s}"]
+    R["biofilm_reactor"] = ModelInfo(
+        "biofilm_reactor", BIOFILM, st, ["F", "Fr", "S1_F", "S2_F", "S3_F"], [],
+        [("V", 10.0), ("Va", 15.0), ("Kla", 1.5), ("m", 0.5), ("eq_exponent", 1.0), ("O_air", 300.0), ("vm_1", 0.8),
+         ("vm_2", 1.0), ("K1", 0.5), ("K2", 0.1), ("KO_1", 1.5), ("KO_2", 0.5)])
+    # model_classes.py:949-960, 1040-1041 (its info() has no "disturbances" key)
+    st = []
+    for s in range(1, 9):
+        st += [f"Tt{s}", f"Tm{s}", f"Ts{s}"]
+    R["heat_exchanger"] = ModelInfo(
+        "heat_exchanger", HEAT_EX, st, ["Ft", "Fs", "Tt0", "Ts9"], [],
+        [("Utm", 1.0), ("Usm", 1.0), ("L", 1.0), ("Dt", 1.0), ("Dm", 2.0), ("Ds", 3.0), ("cpt", 1.0), ("cpm", 1.0),
+         ("cps", 1.0), ("rhot", 1.0), ("rhom", 1.0), ("rhos", 1.0)])
+    # model_classes.py:268-293 (no inputs)
+    R["invariant_batch"] = ModelInfo(
+        "invariant_batch", INV_BATCH, ["xA", "xB", "xC", "xD"], [], [],
+        [("k1f", 55.0), ("k1r", 1.0), ("k2f", 2.0), ("k2r", 1.0)])
+    # model_classes.py:186-216 (no inputs; N is structural: only the default ring of 10 masses is compiled)
+    R["coupled_oscillator"] = ModelInfo(
+        "coupled_oscillator", OSCILLATORS, [f"x{i + 1}" for i in range(10)] + [f"p{i + 1}" for i in range(10)], [], [],
+        [("N", 10), ("k", 1.0), ("m", 1.0)])
     # registry models whose RHS is affine run on the affine kernel (matrices built here from the parameters)
     # hydraulic_tank model_classes.py:128-153: dq1 = -D (q1-q2) + u, dq2 = D (q1-q2) - u
     R["hydraulic_tank"] = ModelInfo(
@@ -138,20 +163,14 @@ def _registry():
 
 _REGISTRY = _registry()
 
-# registry keys of the reference (pcgym.py:128-148) that are NOT built yet:
-# asking for them is an explicit error, never a silent CPU fallback.
-NOT_BUILT = [
-    "heat_exchanger",      # 24 states  > PCG_MAX_NX
-    "biofilm_reactor",     # 5 inputs   > PCG_MAX_NA
-    "invariant_batch",     # no inputs
-    "coupled_oscillator",  # no inputs, 20 states
-]
+# every registry key of the reference (pcgym.py:128-148) is built; kept for the explicit-error path
+NOT_BUILT = []
 
 
 def get_model(name: str) -> ModelInfo:
     if name in _REGISTRY:
         return _REGISTRY[name].copy()
-    if name in NOT_BUILT:
+    if name in NOT_BUILT:  # pragma: no cover - empty since every registry model has a kernel
         raise ValueError(
             f"Model '{name}' exists in pc-gym but has no HIP kernel in this build "
             f"(built: {sorted(_REGISTRY)}).")

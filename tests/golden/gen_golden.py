@@ -195,6 +195,20 @@ def gen_rhs_and_tight(M, out, only_new=False):
         "first_order_system": (lambda: M.first_order_system(int_method="casadi"), col((-2, 2)), col((-1, 1)), 0.5),
         "nonsmooth_control": (lambda: M.nonsmooth_control(int_method="casadi"), col((-2, 2), (-2, 2)), col((-1, 1)), 0.5),
     })
+    # ---- the last four registry models (appended; earlier draws unchanged) ----
+    specs.update({
+        "biofilm_reactor": (lambda: M.biofilm_reactor(int_method="casadi"),
+                            col(*([(0.5, 5.0), (0.05, 3.0), (1.0, 12.0), (0.05, 20.0)] * 4)),
+                            col((0.0, 10.0), (1.0, 30.0), (0.05, 1.0), (0.05, 1.0), (0.05, 1.0)), 1.0),
+        "heat_exchanger": (lambda: M.heat_exchanger(int_method="casadi"),
+                           col(*([(280.0, 360.0)] * 24)),
+                           col((0.1, 5.0), (0.1, 5.0), (300.0, 400.0), (280.0, 320.0)), 1.0),
+        # no inputs: one dummy column (ignored by the reference RHS, u=None there)
+        "invariant_batch": (lambda: M.invariant_batch(int_method="casadi"),
+                            col(*([(0.0, 1.0)] * 4)), col((0.0, 0.0)), 0.1),
+        "coupled_oscillator": (lambda: M.coupled_oscillators(int_method="casadi"),
+                               col(*([(-1.0, 1.0)] * 20)), col((0.0, 0.0)), 0.5),
+    })
     n_rhs, n_tight = 64, 24
     for name, (ctor, xs, us, dt) in specs.items():
         if only_new and os.path.exists(os.path.join(out, f"rhs_{name}.npz")):

@@ -280,6 +280,23 @@ def scenarios():
         "x0": np.array([0.0, 0.5]), "model": "first_order_system"},
         steps=29, action_seed=24)
 
+    # biofilm_reactor: the layout of pc-gym_paper/train_policies/Biofilm/biofilm_train.py:45-72, but with x0 / action
+    # ranges that keep S2 > -K2 (with the paper's own x0 the reference RHS reaches its Monod pole K2 + S2 = 0 in
+    # the second step and returns NaN -- checked with the reference RHS + LSODA)
+    S["biofilm_sp"] = dict(env_params={
+        "N": 40, "tsim": 40, "SP": {"S2_A": _halves(40, 1.5, 2.0)},
+        "o_space": {"low": np.array([-10, 0, -10, 0] * 4 + [0.9], dtype=float),
+                    "high": np.array([10, 10, 10, 700] * 4 + [2.1], dtype=float)},
+        "a_space": {"low": np.array([5, 10, 0.05, 0.5, 0.05]), "high": np.array([10, 30, 0.2, 1, 1], dtype=float)},
+        "x0": np.array([0.3, 1.0, 5, 5] * 4 + [1.5], dtype=float), "model": "biofilm_reactor"},
+        steps=39, action_seed=25)
+    S["heat_exchanger_sp"] = dict(env_params={
+        "N": 30, "tsim": 15.0, "SP": {"Tt8": _halves(30, 330.0, 340.0)},
+        "o_space": {"low": np.array([250.0] * 24 + [300.0]), "high": np.array([420.0] * 24 + [360.0])},
+        "a_space": {"low": np.array([0.1, 0.1, 350.0, 290.0]), "high": np.array([5.0, 5.0, 400.0, 310.0])},
+        "x0": np.array([340.0, 320.0, 300.0] * 8 + [330.0]), "r_scale": {"Tt8": 1e-2}, "model": "heat_exchanger"},
+        steps=29, action_seed=26)
+
     # the reference's own known-answer test (custom linear model)
     S["custom_linear_kat"] = dict(
         env_params={

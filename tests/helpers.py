@@ -46,6 +46,8 @@ TIGHT = {
     "photobioreactor": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
     "distillation_column": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
     "first_order_system": dict(integrator="rk4", substeps=64),
+    "biofilm_reactor": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
+    "heat_exchanger": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
 }
 
 

@@ -71,7 +71,7 @@ def test_model_metadata_and_default_params_agree_with_host_registry():
             continue  # affine registry models share PCG_MODEL_AFFINE (matrices are built on the host)
         nx, nu, ndm, npar = (C.c_int32() for _ in range(4))
         assert lib.pcg_model_info(mi.model_id, nx, nu, ndm, npar) == 0
-        assert (nx.value, nu.value, ndm.value) == (len(mi.states), len(mi.inputs), len(mi.disturbances))
+        assert (nx.value, nu.value, ndm.value) == (len(mi.states), len(mi.inputs) or 1, len(mi.disturbances))
         buf = (C.c_double * npar.value)()
         assert lib.pcg_model_default_params(mi.model_id, buf, npar.value) == 0
         assert list(buf) == mi.param_vector()

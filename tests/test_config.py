@@ -24,9 +24,24 @@ def test_unknown_model_raises_like_reference():
     p["model"] = "nope"
     with pytest.raises(ValueError, match="not found in model_mapping"):  # pcgym.py:157
         EnvSpec(p)
-    p["model"] = "biofilm_reactor"
-    with pytest.raises(ValueError, match="no HIP kernel"):
+    p["model"] = "biofilm_reactor"  # every registry model is built: a mismatched a_space is the error now
+    with pytest.raises(ValueError, match="a_space has 1 entries but the model has 5 inputs"):
         EnvSpec(p)
+
+
+def test_models_without_inputs_accept_empty_or_placeholder_action_space():
+    """invariant_batch / coupled_oscillator have info()["inputs"] == [] (model_classes.py:200,282)"""
+    base = {"model": "invariant_batch", "N": 10, "tsim": 1.0, "x0": np.array([1.0, 1.0, 0.0, 0.0]),
+            "o_space": {"low": np.zeros(4), "high": np.ones(4) * 2}, "reward_states": ["xD"], "maximise_reward": True}
+    s0 = EnvSpec(dict(base, a_space={"low": np.zeros(0), "high": np.zeros(0)}))
+    assert (s0.na_user, s0.na) == (0, 1) and s0.to_cfg()[0].na == 1
+    s1 = EnvSpec(dict(base, a_space={"low": np.array([-1.0]), "high": np.array([1.0])}))
+    assert (s1.na_user, s1.na) == (1, 1)
+    with pytest.raises(ValueError, match="a_space has 2 entries"):
+        EnvSpec(dict(base, a_space={"low": np.zeros(2), "high": np.ones(2)}))
+    p = dict(base, model="coupled_oscillator", x0=np.zeros(20), reward_states=["x1"],
+             o_space={"low": -np.ones(20), "high": np.ones(20)}, a_space={"low": np.zeros(0), "high": np.zeros(0)})
+    assert EnvSpec(p).nx == 20
 
 
 def test_dimensions_follow_reference_bookkeeping():

@@ -51,7 +51,9 @@ RHS_CASES = [("cstr", "cstr"), ("cstr_d", "cstr"), ("four_tank", "four_tank"),
              ("batch", "batch"), ("photobioreactor", "photobioreactor"),
              ("cstr_series_recycle", "cstr_series_recycle"), ("distillation_column", "distillation_column"),
              ("polymerisation_reactor", "polymerisation_reactor"), ("hydraulic_tank", "hydraulic_tank"),
-             ("first_order_system", "first_order_system"), ("nonsmooth_control", "nonsmooth_control")]
+             ("first_order_system", "first_order_system"), ("nonsmooth_control", "nonsmooth_control"),
+             ("biofilm_reactor", "biofilm_reactor"), ("heat_exchanger", "heat_exchanger"),
+             ("invariant_batch", "invariant_batch"), ("coupled_oscillator", "coupled_oscillator")]
 
 
 def _plan_for(spec, torch):
@@ -117,6 +119,12 @@ INT_CASES = [
     ("polymerisation_reactor", "polymerisation_reactor", dict(integrator="dopri5"), 1e-9),
     ("hydraulic_tank", "hydraulic_tank", dict(integrator="rk4", substeps=8), 1e-12),
     ("nonsmooth_control", "nonsmooth_control", dict(integrator="dopri5"), 1e-9),
+    ("biofilm_reactor", "biofilm_reactor", dict(integrator="dopri5"), 1e-9),
+    ("biofilm_reactor", "biofilm_reactor", dict(integrator="rk4", substeps=128), 1e-10),  # growing modes amplify ulps
+    ("heat_exchanger", "heat_exchanger", dict(integrator="dopri5"), 1e-9),
+    ("heat_exchanger", "heat_exchanger", dict(integrator="rk4", substeps=8), 1e-12),
+    ("invariant_batch", "invariant_batch", dict(integrator="rk4", substeps=64), 1e-10),
+    ("coupled_oscillator", "coupled_oscillator", dict(integrator="dopri5"), 1e-9),
 ]
 
 
@@ -150,7 +158,8 @@ def test_integrate_vs_oracle(fix, model, kw, tol, lds_stages):
     got = x.cpu().numpy()
     want, ns_o = O.integrate(spec, xs, us)
     scale = np.maximum(np.abs(want), 1e-6 * np.max(np.abs(want), axis=1, keepdims=True))
-    assert np.max(np.abs(got - want) / scale) <= tol
+    err = np.max(np.abs(got - want) / scale)
+    assert err <= tol, err
     if kw["integrator"] == "dopri5":
         ns_g = ns.cpu().numpy()
         # same controller: accepted/rejected counts agree except for razor-edge decisions
@@ -462,6 +471,44 @@ def test_step_graph_equals_stepping():
     assert not torch.equal(first, e2.obs_soa)  # fresh noise in episode 2
     e1.close()
     e2.close()
+
+
+def test_models_without_inputs_step_with_empty_actions():
+    """invariant_batch / coupled_oscillator: info()["inputs"] == [] in the reference (model_classes.py:200,282)"""
+    torch = _torch()
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    cases = [
+        ("invariant_batch", np.array([1.0, 0.8, 0.0, 0.0]), ["xD"], 0.05),
+        ("coupled_oscillator", np.r_[np.linspace(-1, 1, 10), np.zeros(10)], ["x1"], 0.25),
+    ]
+    for model, x0, rs, dt in cases:
+        nx = x0.size
+        p = {"model": model, "N": 12, "tsim": 12 * dt, "x0": x0, "reward_states": rs, "maximise_reward": True,
+             "a_space": {"low": np.zeros(0), "high": np.zeros(0)},
+             "o_space": {"low": -2 * np.ones(nx), "high": 2 * np.ones(nx)}}
+        B = 300
+        env = VecEnv(p, n_envs=B, seed=3)
+        assert env.action_space.shape == (0,)
+        orc = O.OracleEnv(env.spec, B, seed=3)
+        env.reset()
+        orc.reset()
+        empty = torch.zeros((0, B), dtype=torch.float64, device=env.device)
+        for i in range(11):
+            og, rg, dg, _, _ = env.step(empty)
+            oc, rc, dc = orc.step(np.zeros((1, B)))
+            assert np.max(np.abs(og.cpu().numpy().T - oc)) <= 1e-9, (model, i)
+            assert np.allclose(rg.cpu().numpy(), rc, rtol=1e-9, atol=1e-12)
+            assert np.array_equal(dg.cpu().numpy().astype(np.uint8), dc)
+        assert bool(dg.all())
+        # the oscillator ring conserves total momentum (sum of p_i), a size-independent invariant
+        if model == "coupled_oscillator":
+            assert torch.allclose(env.x[10:].sum(0), torch.zeros(B, dtype=torch.float64, device=env.device), atol=1e-12)
+        else:  # invariant_batch: reaction invariant d(xB + xC + xD)/dt = -r1 + (r1 - r2) + r2 = 0
+            inv = env.x[1] + env.x[2] + env.x[3]
+            assert torch.allclose(inv, torch.full_like(inv, 0.8), rtol=1e-12)
+        env.close()
 
 
 # ------------------------------------------------ full-size property tests ---

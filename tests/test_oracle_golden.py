@@ -24,6 +24,8 @@ RHS_CASES = [
     ("distillation_column", "distillation_column"), ("polymerisation_reactor", "polymerisation_reactor"),
     ("hydraulic_tank", "hydraulic_tank"), ("first_order_system", "first_order_system"),
     ("nonsmooth_control", "nonsmooth_control"),
+    ("biofilm_reactor", "biofilm_reactor"), ("heat_exchanger", "heat_exchanger"),
+    ("invariant_batch", "invariant_batch"), ("coupled_oscillator", "coupled_oscillator"),
 ]
 
 
@@ -54,7 +56,7 @@ def _spec_for_integration(model, dt, nu, **kw):
     p = {"model": model, "N": 10, "tsim": 10 * dt, "x0": np.ones(nx), "normalise_a": False, "normalise_o": False,
          "a_space": {"low": -np.ones(len(mi.inputs)), "high": np.ones(len(mi.inputs))},
          "o_space": {"low": -np.ones(nx), "high": np.ones(nx)}, "reward_states": [], "maximise_reward": True}
-    if nu > len(mi.inputs):
+    if nu > (len(mi.inputs) or 1):  # models without inputs carry one dummy column
         p["disturbances"] = {k: np.zeros(10) for k in mi.disturbances}
         p["disturbance_bounds"] = {"low": -np.ones(len(mi.disturbances)), "high": np.ones(len(mi.disturbances))}
         p["o_space"] = {"low": -np.ones(nx), "high": np.ones(nx)}
@@ -84,6 +86,10 @@ TIGHT_CASES = [
     ("hydraulic_tank", "hydraulic_tank", 1e-6, dict(integrator="rk4", substeps=512), 1e-9),
     ("first_order_system", "first_order_system", 1e-5, dict(integrator="rk4", substeps=512), 1e-9),
     ("nonsmooth_control", "nonsmooth_control", 1e-5, dict(integrator="rk4", substeps=512), 1e-9),
+    ("biofilm_reactor", "biofilm_reactor", 2e-6, dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
+    ("heat_exchanger", "heat_exchanger", 1e-6, dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
+    ("invariant_batch", "invariant_batch", 1e-6, dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
+    ("coupled_oscillator", "coupled_oscillator", 1e-6, dict(integrator="dopri5", rtol=1e-12, atol=1e-14), 1e-9),
 ]
 
 
