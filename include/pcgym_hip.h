@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 1
+#define PCG_ABI_VERSION 2
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -115,6 +115,10 @@ enum pcg_integrator {
                                        clipped to [d_clip_lo,d_clip_hi] (BASELINE configs[4])  */
 #define PCG_F_X0_NORMAL 0x0400u     /* reset-time x0 / parameter uncertainty is normal (else uniform),
                                        pcgym.py:255-261                                        */
+#define PCG_F_UNC_EMPIRICAL 0x0800u /* uncertain parameters are drawn uniformly from per-parameter sample
+                                       tables (env_params["empirical_distribution"], pcgym.py:311-316:
+                                       np.random.choice) instead of value*(1 +- pct)           */
+#define PCG_MAX_EMP 65536           /* total empirical samples over all parameters            */
 
 /*
  * Environment configuration: the numeric content of the reference's
@@ -183,6 +187,9 @@ typedef struct pcg_env_cfg {
   const double* noise_pct;/* [nx] per-state noise fraction (pcgym.py:454-466)           */
   const int32_t* unc_index; /* [nunc] index of each uncertain parameter in `params`       */
   const double* unc_pct;  /* [nunc] uncertainty fraction (uniform half-width / normal sigma, pcgym.py:255-261) */
+  const double* unc_emp;  /* PCG_F_UNC_EMPIRICAL: concatenated sample tables, parameter j owns
+                             unc_emp[unc_emp_off[j] .. unc_emp_off[j+1])                   */
+  const int32_t* unc_emp_off; /* [nunc+1], unc_emp_off[0] = 0                              */
 } pcg_env_cfg;
 
 /*

@@ -713,7 +713,12 @@ static void env_reset(const pcg_env_cfg* c, orc_env* e, uint64_t seed, uint64_t 
   for (int j = 0; j < c->nunc; ++j) { /* :301-310, apply_uncertainties :255-261 */
     double orig = c->params[c->unc_index[j]], pct = c->unc_pct[j], v;
     int ri = nx + j;
-    if (c->flags & PCG_F_X0_NORMAL) v = orig + pct * orig * rng_normal(seed, env_id, 0u, ORC_RNG_RESET, ri);
+    if (c->flags & PCG_F_UNC_EMPIRICAL) { /* :311-316 np.random.choice(samples): uniform index */
+      int len = c->unc_emp_off[j + 1] - c->unc_emp_off[j];
+      int idx = (int)(rng_uniform(seed, env_id, 0u, ORC_RNG_RESET, ri) * (double)len);
+      if (idx > len - 1) idx = len - 1;
+      v = c->unc_emp[c->unc_emp_off[j] + idx];
+    } else if (c->flags & PCG_F_X0_NORMAL) v = orig + pct * orig * rng_normal(seed, env_id, 0u, ORC_RNG_RESET, ri);
     else v = orig * (1 + pct * (2.0 * rng_uniform(seed, env_id, 0u, ORC_RNG_RESET, ri) - 1.0));
     e->state[nx + nsp + nd + j] = v;
   }

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PCG_ABI_VERSION = 1
+PCG_ABI_VERSION = 2
 PCG_MAX_NX = 24
 PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
@@ -49,6 +49,8 @@ PCG_F_MAXIMISE = 0x0080
 PCG_F_REF_COMPAT = 0x0100
 PCG_F_GAUSS_DIST = 0x0200
 PCG_F_X0_NORMAL = 0x0400
+PCG_F_UNC_EMPIRICAL = 0x0800
+PCG_MAX_EMP = 65536
 
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)
@@ -102,6 +104,8 @@ class pcg_env_cfg(C.Structure):
         ("noise_pct", _pd),
         ("unc_index", _pi),
         ("unc_pct", _pd),
+        ("unc_emp", _pd),
+        ("unc_emp_off", _pi),
     ]
 
 

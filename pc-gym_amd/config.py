@@ -329,9 +329,15 @@ class EnvSpec:
         self.unc_index = np.zeros(0, dtype=np.int32)
         self.unc_pct = np.zeros(0)
         up = p.get("uncertainty_percentages")
-        if p.get("empirical_distribution") is not None:
-            raise ValueError("empirical_distribution is not built yet (SURVEY.md section 8 row f-3); use "
-                             "uncertainty_percentages with distribution 'uniform' or 'normal'")
+        emp = p.get("empirical_distribution") if up is None else None  # the reference's precedence (pcgym.py:218-229)
+        self.unc_emp = np.zeros(0)
+        self.unc_emp_off = np.zeros(1, dtype=np.int32)
+        self.unc_empirical = emp is not None
+        if emp is not None:
+            if "x0" in emp:
+                raise ValueError("empirical_distribution['x0'] is not supported (the reference would setattr the "
+                                 "sample onto the model object, pcgym.py:311-315); use uncertainty_percentages['x0']")
+            up = {k: 0.0 for k in emp}  # shares the bookkeeping below; the percentages are unused
         if up is not None:
             dist = p.get("distribution", "uniform")
             if dist not in ("uniform", "normal"):
@@ -360,6 +366,14 @@ class EnvSpec:
                     raise ValueError(f"at most {abi.PCG_MAX_NUNC} uncertain parameters are supported")
                 self.unc_index = np.array([names.index(k) for k in self.unc_keys], dtype=np.int32)
                 self.unc_pct = np.array([float(up[k]) for k in self.unc_keys], dtype=_f64)
+                if emp is not None:
+                    tabs = [_arr(emp[k]) for k in self.unc_keys]
+                    if any(t.size == 0 for t in tabs):
+                        raise ValueError("every empirical_distribution entry needs at least one sample")
+                    self.unc_emp = np.concatenate(tabs)
+                    self.unc_emp_off = np.concatenate([[0], np.cumsum([t.size for t in tabs])]).astype(np.int32)
+                    if self.unc_emp.size > abi.PCG_MAX_EMP:
+                        raise ValueError(f"at most {abi.PCG_MAX_EMP} empirical samples in total are supported")
                 ub = p["uncertainty_bounds"]
                 self.o_low = np.concatenate([self.o_low, _arr(ub["low"])])
                 self.o_high = np.concatenate([self.o_high, _arr(ub["high"])])
@@ -454,6 +468,7 @@ class EnvSpec:
         f |= abi.PCG_F_REF_COMPAT if self.reference_compat else 0
         f |= abi.PCG_F_GAUSS_DIST if self.gauss else 0
         f |= abi.PCG_F_X0_NORMAL if self.x0_normal else 0
+        f |= abi.PCG_F_UNC_EMPIRICAL if (self.unc_empirical and self.nunc) else 0
         return f
 
     def to_cfg(self):
@@ -516,4 +531,6 @@ class EnvSpec:
         cfg.noise_pct = pd(self.noise_pct)
         cfg.unc_index = pi(self.unc_index)
         cfg.unc_pct = pd(self.unc_pct)
+        cfg.unc_emp = pd(self.unc_emp)
+        cfg.unc_emp_off = pi(self.unc_emp_off)
         return cfg, keep

@@ -114,6 +114,7 @@ struct DevConst {
   double raw[32];
   double unc_pct[PCG_MAX_NUNC];
   int32_t unc_index[PCG_MAX_NUNC];
+  int32_t emp_off[PCG_MAX_NUNC + 1];  // PCG_F_UNC_EMPIRICAL: sample tables live behind the schedules in `sched`
 };
 
 using CDevConst = const PCG_CONSTANT DevConst;
@@ -1068,7 +1069,14 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs A) {
     const double orig = c.raw[c.unc_index[j]], pct = c.unc_pct[j];
     const int ri = nx + j;  // RNG index after the x0 draws
     double v;
-    if (c.flags & PCG_F_X0_NORMAL) {
+    if (c.flags & PCG_F_UNC_EMPIRICAL) {  // np.random.choice(samples), pcgym.py:311-316
+      double u0, u1;
+      rng_uniform2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), u0, u1);
+      const int len = c.emp_off[j + 1] - c.emp_off[j];
+      int idx = (int)(((ri & 1) ? u1 : u0) * (double)len);
+      idx = idx < len - 1 ? idx : len - 1;
+      v = A.sched[(size_t)(c.nsp + c.nd) * c.N + c.emp_off[j] + idx];
+    } else if (c.flags & PCG_F_X0_NORMAL) {
       double z0, z1;
       rng_normal2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), z0, z1);
       v = orig + pct * orig * ((ri & 1) ? z1 : z0);
@@ -1496,6 +1504,13 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
     if (c->unc_index[j] < 0 || c->unc_index[j] >= k.nraw) return PCG_E_DIM;
     d->unc_index[j] = c->unc_index[j];
     d->unc_pct[j] = c->unc_pct[j];
+    if (c->flags & PCG_F_UNC_EMPIRICAL) {
+      if (!c->unc_emp || !c->unc_emp_off) return PCG_E_NULL;
+      if (c->unc_emp_off[0] != 0 || c->unc_emp_off[j + 1] <= c->unc_emp_off[j] || c->unc_emp_off[j + 1] > PCG_MAX_EMP)
+        return PCG_E_DIM;
+      d->emp_off[j] = c->unc_emp_off[j];
+      d->emp_off[j + 1] = c->unc_emp_off[j + 1];
+    }
   }
   d->dt = c->dt;
   d->h = c->dt / (c->substeps > 0 ? c->substeps : 1);
@@ -1537,15 +1552,20 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   if (e == hipSuccess) e = hipDeviceGetAttribute(&p->num_cus, hipDeviceAttributeMultiprocessorCount, p->device);
   if (e != hipSuccess) { delete p; return (int)e; }
   const int rows = cfg->nsp + cfg->nd;
+  const bool emp = (cfg->flags & PCG_F_UNC_EMPIRICAL) && cfg->nunc > 0;
+  const size_t n_emp = emp ? (size_t)cfg->unc_emp_off[cfg->nunc] : 0;
   p->sched_bytes = sizeof(double) * (size_t)(rows > 0 ? rows : 1) * cfg->N;
+  const size_t sched_alloc = sizeof(double) * ((size_t)(rows > 0 ? rows : 1) * cfg->N + n_emp);
   e = hipMalloc((void**)&p->dC, sizeof(DevConst));
-  if (e == hipSuccess) e = hipMalloc((void**)&p->dsched, p->sched_bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->dsched, sched_alloc);
   if (e == hipSuccess) e = hipMemcpy(p->dC, &p->hc, sizeof(DevConst), hipMemcpyHostToDevice);
   if (e == hipSuccess && cfg->nsp)
     e = hipMemcpy(p->dsched, cfg->sp, sizeof(double) * (size_t)cfg->nsp * cfg->N, hipMemcpyHostToDevice);
   if (e == hipSuccess && cfg->nd)
     e = hipMemcpy(p->dsched + (size_t)cfg->nsp * cfg->N, cfg->d_sched, sizeof(double) * (size_t)cfg->nd * cfg->N,
                   hipMemcpyHostToDevice);
+  if (e == hipSuccess && n_emp)  // empirical sample tables behind the schedule rows
+    e = hipMemcpy(p->dsched + (size_t)rows * cfg->N, cfg->unc_emp, sizeof(double) * n_emp, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (p->dC) (void)hipFree(p->dC);
     if (p->dsched) (void)hipFree(p->dsched);

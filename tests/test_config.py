@@ -174,7 +174,7 @@ def test_shape_errors():
         EnvSpec(p)
     p = P("cstr_canonical")
     p["empirical_distribution"] = {"q": [90, 100, 110]}
-    with pytest.raises(ValueError, match="not built yet"):
+    with pytest.raises(KeyError, match="uncertainty_bounds"):  # required by the reference too (pcgym.py:234-235)
         EnvSpec(p)
 
 
@@ -223,3 +223,40 @@ def test_parameter_uncertainty_parsing():
     p3.update(uncertainty_percentages={"UA": 0.1}, uncertainty_bounds={"low": np.array([4e4]), "high": np.array([6e4])})
     with pytest.raises(ValueError, match="disturbances together with parameter uncertainty"):
         EnvSpec(p3)
+
+
+def test_empirical_distribution_parsing_and_oracle_sampling():
+    """env_params["empirical_distribution"] (pcgym.py:226-232, 311-316: np.random.choice over the listed samples)"""
+    from oracle import oracle as O
+    from pcgym_amd import _lib
+    import ctypes as C
+
+    p = P("cstr_canonical")
+    ua = np.array([4.5e4, 5.0e4, 5.5e4, 6.0e4])
+    caf = np.array([0.95, 1.05])
+    p.update(empirical_distribution={"UA": ua, "Caf": caf},
+             uncertainty_bounds={"low": np.array([4e4, 0.9]), "high": np.array([6.5e4, 1.1])})
+    s = EnvSpec(p)
+    assert s.nunc == 2 and s.unc_empirical and list(s.unc_emp_off) == [0, 4, 6] and s.nobs == 5
+    cfg, keep = s.to_cfg()
+    assert cfg.flags & abi.PCG_F_UNC_EMPIRICAL
+    assert _lib.load().pcg_cfg_validate(C.byref(cfg)) == 0
+    B = 4000
+    orc = O.OracleEnv(s, B, seed=9)
+    orc.reset()
+    assert set(np.unique(orc.p_unc[0])) == set(ua) and set(np.unique(orc.p_unc[1])) == set(caf)
+    # uniform choice: every sample is drawn about B/len times
+    for row, tab in ((orc.p_unc[0], ua), (orc.p_unc[1], caf)):
+        counts = np.array([(row == v).sum() for v in tab])
+        assert np.all(np.abs(counts / B - 1 / len(tab)) < 0.03)
+    # uncertainty_percentages wins when both are given (pcgym.py:218-229)
+    p["uncertainty_percentages"] = {"UA": 0.1, "Caf": 0.1}
+    assert not EnvSpec(p).unc_empirical
+    del p["uncertainty_percentages"]
+    p["empirical_distribution"] = {"UA": []}
+    p["uncertainty_bounds"] = {"low": np.array([4e4]), "high": np.array([6.5e4])}
+    with pytest.raises(ValueError, match="at least one sample"):
+        EnvSpec(p)
+    p["empirical_distribution"] = {"x0": [1.0]}
+    with pytest.raises(ValueError, match="not supported"):
+        EnvSpec(p)

@@ -29,8 +29,14 @@ def _loaded_native():
     from pcgym_amd import _lib
 
     lib = _lib.load()
-    assert lib.pcg_version() == 1
+    assert lib.pcg_version() == abi_version()
     return lib
+
+
+def abi_version():
+    from pcgym_amd import _abi as abi
+
+    return abi.PCG_ABI_VERSION
 
 
 def test_native_library_loaded():
@@ -792,6 +798,10 @@ def test_parameter_uncertainty_vs_oracle():
     p.update(uncertainty_percentages={"UA": 0.1, "x0": [0.02, 0.01], "Caf": 0.05}, distribution="uniform",
              uncertainty_bounds={"low": np.array([4e4, 0.9]), "high": np.array([6e4, 1.1])})
     cases.append((p, 1e-12))
+    p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])  # empirical_distribution (pcgym.py:311-316)
+    p.update(empirical_distribution={"UA": np.linspace(4.5e4, 5.5e4, 7), "Caf": np.array([0.95, 1.0, 1.05])},
+             uncertainty_bounds={"low": np.array([4e4, 0.9]), "high": np.array([6e4, 1.1])})
+    cases.append((p, 1e-10))  # UA down to 4.5e4 puts some envs close to ignition: rounding differences grow
     for p, tol in cases:
         for per_env_t in (False, True):
             B = 1500
@@ -804,6 +814,11 @@ def test_parameter_uncertainty_vs_oracle():
             pu = env.p_unc.cpu().numpy()
             nom = np.array([env.spec.model.param_vector()[i] for i in env.spec.unc_index])
             assert np.all(np.abs(pu.mean(axis=1) / nom - 1) < 0.02) and np.all(pu.std(axis=1) / nom > 0.02)
+            if env.spec.unc_empirical:  # table look-ups: bit-identical, and only listed samples occur
+                assert np.array_equal(pu, orc.p_unc)
+                for j in range(env.spec.nunc):
+                    tab = env.spec.unc_emp[env.spec.unc_emp_off[j]:env.spec.unc_emp_off[j + 1]]
+                    assert set(np.unique(pu[j])) == set(tab)
             acts = _rand_actions(env.spec, 6, B, 2)
             for i in range(6):
                 o, r, d, _, _ = env.step(torch.tensor(acts[i], device=env.device))
