@@ -1,5 +1,8 @@
-// pcg_kernels.hip -- fused environment-step kernels for gfx950 (MI355X) and the
-// C ABI of include/pcgym_hip.h.
+// pcg_kernels.hpp -- device code shared by every translation unit of libpcgym_hip.so: the fused
+// environment-step / rollout / test-hook kernel templates and make_kernels<ID>() (the table of
+// instantiations for one model).  pcg_inst_*.hip instantiate groups of models so that the library
+// builds in parallel; pcg_abi.hip holds the C ABI, the host dispatch and the reset kernel.
+//
 //
 // Execution model
 //   * one wavefront lane = one environment; 256-thread workgroups; grid = ceil(B/256)
@@ -20,6 +23,7 @@
 // Reference path restated: make_env.step / reset (src/pcgym/pcgym.py:263-500),
 // integration_engine (src/pcgym/integrator.py:65-107,163-182), model RHS
 // (src/pcgym/model_classes.py) -- see pcg_models.hpp for per-model line ranges.
+#pragma once
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -32,33 +36,6 @@
 #include "../../include/pcgym_hip.h"
 #include "pcg_integrators.hpp"
 #include "pcg_models.hpp"
-
-// Optional per-wave timeline instrumentation (tools/timeline.py builds a second .so with
-// -DPCG_TIMELINE): s_memtime stamps at kernel entry / loads landed / arithmetic done / stores issued
-// / stores acknowledged, written for lane 0 of every wave into the `nsteps` debug buffer
-// (8 x uint64 per wave).  Compiled out of the product library.
-#ifdef PCG_TIMELINE
-#define PCG_TL_DECL unsigned long long tl_[6] = {0, 0, 0, 0, 0, 0}
-#define PCG_TL_STAMP(i) tl_[i] = __builtin_amdgcn_s_memtime()
-#define PCG_TL_WAIT_STAMP(i)                      \
-  do {                                            \
-    __builtin_amdgcn_s_waitcnt(0);                \
-    tl_[i] = __builtin_amdgcn_s_memtime();        \
-  } while (0)
-#define PCG_TL_FLUSH(e)                                                                   \
-  do {                                                                                    \
-    if ((threadIdx.x & 63) == 0 && A.nsteps) {                                            \
-      unsigned long long* q = reinterpret_cast<unsigned long long*>(A.nsteps) + ((e) >> 6) * 8; \
-      for (int i_ = 0; i_ < 5; ++i_) q[i_] = tl_[i_];                                     \
-      q[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); /* HW_ID */     \
-    }                                                                                     \
-  } while (0)
-#else
-#define PCG_TL_DECL
-#define PCG_TL_STAMP(i)
-#define PCG_TL_WAIT_STAMP(i)
-#define PCG_TL_FLUSH(e)
-#endif
 
 #ifndef PCG_LEAN_WPE
 #define PCG_LEAN_WPE 1  // min waves per SIMD requested from the register allocator for the lean kernels
@@ -521,25 +498,18 @@ __global__ __launch_bounds__(tb(LDS_STAGES), wpe(M::NX, INTEG, LDS_STAGES)) void
   const int na = M::DYNAMIC ? c.na : NA;
   const int t = PER_ENV_T ? A.t[e] : A.t_scalar;
   stagger_priority(A.prio_mode);
-  PCG_TL_DECL;
-  PCG_TL_STAMP(0);
   double x[NX], a[NA];
 #pragma unroll
   for (int i = 0; i < NX; ++i) x[i] = (i < nx) ? A.x[(size_t)i * B + e] : 0.0;
 #pragma unroll
   for (int i = 0; i < NA; ++i) a[i] = (i < na) ? A.a[(size_t)i * B + e] : 0.0;
-  PCG_TL_WAIT_STAMP(1);  // loads landed
   EnvOut<M> out;
   env_step<M, INTEG, PER_ENV_T, LDS_STAGES, EXTRAS, UNC>(A, c, sched_l, stage_l, e, t, a, x, out);
-  PCG_TL_STAMP(2);  // integration + epilogue arithmetic done
 #pragma unroll
   for (int i = 0; i < NX; ++i)
     if (i < nx) A.x[(size_t)i * B + e] = x[i];
   store_out<M, UNC>(A, c, e, out, A.obs + e);
   if (PER_ENV_T) A.t[e] = t + 1;
-  PCG_TL_STAMP(3);       // stores issued
-  PCG_TL_WAIT_STAMP(4);  // stores acknowledged
-  PCG_TL_FLUSH(e);
 }
 
 // ---------------------------------------------------------------------------
@@ -1032,68 +1002,6 @@ __global__ __launch_bounds__(tb(LDS_STAGES)) void rollout_kernel(const StepArgs 
     if (i < nx) A.x[(size_t)i * B + e] = x[i];
 }
 
-// reset (pcgym.py:263-349)
-__global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs A) {
-  CDevConst& c = *A.C;
-  const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (e >= A.B) return;
-  if (A.mask && !A.mask[e]) return;
-  const int64_t B = A.B;
-  const int nx = c.nx, nsp = c.nsp_obs, nd = c.nd;
-  const uint64_t env_id = (uint64_t)(A.env_offset + e);
-  for (int i = 0; i < nx; ++i) {
-    double v = c.x0[i];
-    if (c.has_x0_unc && c.x0_unc[i] != 0.0) {  // apply_uncertainties, pcgym.py:255-261
-      const double pct = c.x0_unc[i];
-      if (c.flags & PCG_F_X0_NORMAL) {
-        double z0, z1;
-        rng_normal2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(i >> 1), z0, z1);
-        v = c.x0[i] + pct * c.x0[i] * ((i & 1) ? z1 : z0);
-      } else {
-        double u0, u1;
-        rng_uniform2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(i >> 1), u0, u1);
-        v = c.x0[i] * (1 + pct * (2.0 * ((i & 1) ? u1 : u0) - 1.0));
-      }
-    }
-    A.x[(size_t)i * B + e] = v;
-    A.obs[(size_t)i * B + e] = (v - c.omap[i].lo) * c.omap[i].sc + c.omap[i].off;
-  }
-  for (int k = 0; k < nsp; ++k)
-    A.obs[(size_t)(nx + k) * B + e] = (c.x0[nx + k] - c.omap[nx + k].lo) * c.omap[nx + k].sc + c.omap[nx + k].off;
-  for (int k = 0; k < nd; ++k) {  // disturbances[k][0] (pcgym.py:291-298, quirk Q6)
-    const int j = nx + nsp + k;
-    A.obs[(size_t)j * B + e] = (A.sched[(size_t)(c.nsp + k) * c.N] - c.omap[j].lo) * c.omap[j].sc + c.omap[j].off;
-  }
-  // uncertain model parameters (pcgym.py:301-310): sampled per env, appended to the observation
-  for (int j = 0; j < c.nunc; ++j) {
-    const double orig = c.raw[c.unc_index[j]], pct = c.unc_pct[j];
-    const int ri = nx + j;  // RNG index after the x0 draws
-    double v;
-    if (c.flags & PCG_F_UNC_EMPIRICAL) {  // np.random.choice(samples), pcgym.py:311-316
-      double u0, u1;
-      rng_uniform2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), u0, u1);
-      const int len = c.emp_off[j + 1] - c.emp_off[j];
-      int idx = (int)(((ri & 1) ? u1 : u0) * (double)len);
-      idx = idx < len - 1 ? idx : len - 1;
-      v = A.sched[(size_t)(c.nsp + c.nd) * c.N + c.emp_off[j] + idx];
-    } else if (c.flags & PCG_F_X0_NORMAL) {
-      double z0, z1;
-      rng_normal2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), z0, z1);
-      v = orig + pct * orig * ((ri & 1) ? z1 : z0);
-    } else {
-      double u0, u1;
-      rng_uniform2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), u0, u1);
-      v = orig * (1 + pct * (2.0 * ((ri & 1) ? u1 : u0) - 1.0));
-    }
-    A.p_unc[(size_t)j * B + e] = v;
-    const int q = nx + nsp + nd + j;
-    A.obs[(size_t)q * B + e] = (v - c.omap[q].lo) * c.omap[q].sc + c.omap[q].off;
-  }
-  if ((c.flags & PCG_F_A_DELTA) && A.a_save)
-    for (int i = 0; i < c.na; ++i) A.a_save[(size_t)i * B + e] = c.a_0[i];
-  if (A.t) A.t[e] = 0;
-}
-
 // test hooks ------------------------------------------------------------------
 template <class M>
 __global__ __launch_bounds__(BLOCK) void rhs_kernel(CDevConst* C, int64_t B, int nu_rows, const double* xg,
@@ -1251,727 +1159,4 @@ Kernels make_kernels() {
   return k;
 }
 
-static const Kernels& kernels(int id) {
-  static const Kernels K[PCG_MODEL_COUNT] = {
-      make_kernels<PCG_MODEL_CSTR>(),        make_kernels<PCG_MODEL_FOUR_TANK>(),
-      make_kernels<PCG_MODEL_ME>(),          make_kernels<PCG_MODEL_ME_REACTIVE>(),
-      make_kernels<PCG_MODEL_CRYST>(),       make_kernels<PCG_MODEL_AFFINE>(),
-      make_kernels<PCG_MODEL_COMPLEX_CSTR>(), make_kernels<PCG_MODEL_DISEASE>(),
-      make_kernels<PCG_MODEL_BATCH>(),       make_kernels<PCG_MODEL_PHOTO>(),
-      make_kernels<PCG_MODEL_CSTR_SERIES>(), make_kernels<PCG_MODEL_DISTILLATION>(),
-      make_kernels<PCG_MODEL_POLYMER>(),     make_kernels<PCG_MODEL_BIOFILM>(),
-      make_kernels<PCG_MODEL_HEAT_EX>(),     make_kernels<PCG_MODEL_INV_BATCH>(),
-      make_kernels<PCG_MODEL_OSCILLATORS>()};
-  return K[id];
-}
-
-// reference default parameters (model_classes.py:24-33, 877-889, 361-367, 777-786, 1260-1270)
-static const double DEF_CSTR[] = {100, 100, 1000, 0.239, -5e4, 8750, 7.2e10, 5e4, 350, 1};
-static const double DEF_FOUR_TANK[] = {9.81, 0.2, 0.2, 0.00085, 0.00095, 0.0035, 0.0030, 0.0020, 0.0025, 1, 1, 1, 1};
-static const double DEF_ME[] = {5, 5, 1, 5, 2, 0.6, 0.05};
-static const double DEF_ME_REACTIVE[] = {5.0, 5.0, 1.0, 0.01, 0.1, 2.0, 2.00, 0.00, 2.00, 0.00};
-static const double DEF_CRYST[] = {0.923714966, -6754.878558, 0.92229965554, 1.341205945, 48.07514464, -4921.261419,
-                                   1.871281405, 0.50523693,   7.271241375,   7.510905767, 2.658};
-// model_classes.py:65-87, 156-158, 222-233, 443-453, 619-630, 689-695, 1172-1182
-static const double DEF_COMPLEX_CSTR[] = {100, 100, 1000, 0.239, -5e4, 8750, 7.2e10, -3e4, 9000, 1.0e10, 5e4, 350, 1};
-static const double DEF_DISEASE[] = {0.3, 0.1};
-static const double DEF_BATCH[] = {1.0, 0.5, 5000, 6000, 8.314, -1000, -1500, 1000, 4.0, 100, 1.0};
-static const double DEF_PHOTO[] = {0.0572, 0.0, 504.5, 0.00016, 0.281, 23.51, 16.89, 800.0, 178.9, 447.1, 393.1};
-static const double DEF_CSTR_SERIES[] = {97.35, 298, 1e-3, 2e-3, 0.461, 0.732, 1.05e3, 3.766, 3.118e5, 46.14, 58.41, 8.3145e-3};
-static const double DEF_DISTILLATION[] = {100.0, 1.0, 5.0, 0.2, 2000.0, 2000.0, 2000.0};
-static const double DEF_POLYMER[] = {6e10, 4e10, 9e10, 7750, 8500, 8250, 0.5, 1.0, -3e4, 1200.0, 2.0};
-// model_classes.py:1062-1073, 949-960, 269-272, 187-189
-static const double DEF_BIOFILM[] = {10.0, 15.0, 1.5, 0.5, 1.0, 300, 0.8, 1.0, 0.5, 0.1, 1.5, 0.5};
-static const double DEF_HEAT_EX[] = {1, 1, 1, 1, 2, 3, 1, 1, 1, 1, 1, 1};
-static const double DEF_INV_BATCH[] = {55.0, 1.0, 2.0, 1.0};
-static const double DEF_OSCILLATORS[] = {10, 1.0, 1.0};
-static const double* const DEFAULTS[] = {DEF_CSTR,        DEF_FOUR_TANK, DEF_ME,    DEF_ME_REACTIVE, DEF_CRYST,
-                                         nullptr,         DEF_COMPLEX_CSTR, DEF_DISEASE, DEF_BATCH, DEF_PHOTO,
-                                         DEF_CSTR_SERIES, DEF_DISTILLATION, DEF_POLYMER, DEF_BIOFILM,
-                                         DEF_HEAT_EX,     DEF_INV_BATCH,    DEF_OSCILLATORS};
-
 }  // namespace pcg
-
-using namespace pcg;
-
-struct pcg_plan {
-  uint32_t magic;
-  int device;
-  int model_id, integrator_id;
-  int lds_stages;
-  int variant;       // PCG_OPT_VARIANT: 0 auto, 1 classic, 2 stream EPL=1, 3 stream EPL=2
-  int stream_bpc;    // PCG_OPT_STREAM_BLOCKS_PER_CU: 0 = occupancy query
-  int nt_stores;     // PCG_OPT_NT_STORES
-  int prio_mode;     // PCG_OPT_PRIO_STAGGER
-  int num_cus;
-  int stream_occ[2][3]; // resident workgroups per CU of the stream kernels (0 = not queried yet)
-  int stream_unr;    // PCG_OPT_STREAM_UNROLL: log2(sub-tiles per workgroup)
-  int pipe_occ[2];
-  int64_t env_offset;
-  DevConst hc;       // host copy
-  DevConst* dC;      // device copy
-  double* dsched;    // [nsp+nd][N]
-  size_t sched_bytes;
-  int cfg_nu;        // na + ndm as the caller counts them
-};
-static constexpr uint32_t PLAN_MAGIC = 0x50434731u;  // 'PCG1'
-
-#define HIP_TRY(expr)                          \
-  do {                                         \
-    hipError_t _e = (expr);                    \
-    if (_e != hipSuccess) return (int)_e;      \
-  } while (0)
-
-extern "C" {
-
-int pcg_version(void) { return PCG_ABI_VERSION; }
-
-const char* pcg_strerror(int status) {
-  switch (status) {
-    case PCG_OK: return "ok";
-    case PCG_E_NULL: return "required pointer is NULL";
-    case PCG_E_MODEL: return "unknown model or integrator id";
-    case PCG_E_DIM: return "dimension out of range or inconsistent";
-    case PCG_E_VALUE: return "invalid scalar value";
-    case PCG_E_PLAN: return "invalid plan handle or wrong device";
-    case PCG_E_UNSUPPORTED: return "combination not supported by this build";
-    default: break;
-  }
-  if (status > 0) return hipGetErrorString((hipError_t)status);
-  return "unknown status";
-}
-
-int pcg_model_info(int model_id, int32_t* nx, int32_t* nu, int32_t* ndm, int32_t* n_params) {
-  if (model_id < 0 || model_id >= PCG_MODEL_COUNT) return PCG_E_MODEL;
-  const Kernels& k = kernels(model_id);
-  if (nx) *nx = k.nx;
-  if (nu) *nu = k.na;
-  if (ndm) *ndm = k.ndm;
-  if (n_params) *n_params = k.nraw;
-  return PCG_OK;
-}
-
-int pcg_model_default_params(int model_id, double* out, int32_t n_out) {
-  if (model_id < 0 || model_id >= PCG_MODEL_COUNT) return PCG_E_MODEL;
-  if (!out) return PCG_E_NULL;
-  const Kernels& k = kernels(model_id);
-  if (k.nraw < 0 || !DEFAULTS[model_id]) return PCG_E_UNSUPPORTED;
-  if (n_out < k.nraw) return PCG_E_DIM;
-  for (int i = 0; i < k.nraw; ++i) out[i] = DEFAULTS[model_id][i];
-  return PCG_OK;
-}
-
-void pcg_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
-  uint32_t o[4];
-  philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], o);
-  for (int i = 0; i < 4; ++i) out[i] = o[i];
-}
-
-// Validates cfg and fills the host DevConst.  No HIP calls: unit-testable without a GPU.
-static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
-  if (!c || !d) return PCG_E_NULL;
-  if (c->model_id < 0 || c->model_id >= PCG_MODEL_COUNT) return PCG_E_MODEL;
-  if (c->integrator_id < 0 || c->integrator_id >= PCG_INT_COUNT) return PCG_E_MODEL;
-  const Kernels& k = kernels(c->model_id);
-  const int nx = c->nx, na = c->na, ndm = c->ndm, nd = c->nd, nsp = c->nsp, ncon = c->ncon, nrew = c->nrew;
-  if (k.dynamic) {
-    if (nx < 1 || nx > k.nx || na < 1 || na > k.na || ndm != 0) return PCG_E_DIM;
-    if (c->n_params != nx * nx + nx * na + nx) return PCG_E_DIM;
-  } else {
-    if (nx != k.nx || na != k.na) return PCG_E_DIM;
-    if (ndm != 0 && ndm != k.ndm) return PCG_E_DIM;
-    if (c->n_params != k.nraw) return PCG_E_DIM;
-    // coupled_oscillators: the ring size is a structural parameter, only the reference default N = 10 is compiled
-    if (c->model_id == PCG_MODEL_OSCILLATORS && (!c->params || c->params[0] != 10.0)) return PCG_E_UNSUPPORTED;
-  }
-  if (nd < 0 || nd > ndm || nsp < 0 || nsp > PCG_MAX_NSP || ncon < 0 || ncon > PCG_MAX_NCON) return PCG_E_DIM;
-  const int nso = c->nsp_obs;
-  const int nunc = c->nunc;
-  if (nunc < 0 || nunc > PCG_MAX_NUNC) return PCG_E_DIM;
-  if (nunc > 0 && (k.dynamic || !c->unc_index || !c->unc_pct)) return nunc > 0 && k.dynamic ? PCG_E_UNSUPPORTED : PCG_E_NULL;
-  if (nunc > 0 && nd > 0) return PCG_E_UNSUPPORTED;  // quirk Q11: the reference's slot layout is inconsistent there
-  if (nso != 0 && nso != nsp) return PCG_E_DIM;
-  if (nd > 0 && nso != nsp) return PCG_E_UNSUPPORTED;
-  if (nrew < 0 || nrew > PCG_MAX_NX) return PCG_E_DIM;
-  if (c->N < 2 || c->N > PCG_MAX_N) return PCG_E_DIM;
-  if (!(c->dt > 0.0) || !std::isfinite(c->dt)) return PCG_E_VALUE;
-  if (c->integrator_id == PCG_INT_RK4 && c->substeps < 0) return PCG_E_VALUE;  // 0 = no integration (I/O probe)
-  if (c->integrator_id == PCG_INT_DOPRI5 && (!(c->rtol > 0) || !(c->atol >= 0) || c->max_steps < 1))
-    return PCG_E_VALUE;
-  const int nobs = nx + nso + nd + nunc, cnu = na + ndm;
-  if (!c->params || !c->x0 || !c->a_low || !c->a_high || !c->o_low || !c->o_high) return PCG_E_NULL;
-  if (nsp && (!c->sp_index || !c->sp)) return PCG_E_NULL;
-  if ((nsp || nrew) && !c->r_scale) return PCG_E_NULL;
-  if (nrew && !c->rew_index) return PCG_E_NULL;
-  if (nd && (!c->d_slot || !c->d_sched)) return PCG_E_NULL;
-  if (ndm && !c->d_default) return PCG_E_NULL;
-  if (ncon && (!c->con_A || !c->con_b)) return PCG_E_NULL;
-  if ((c->flags & PCG_F_A_DELTA) && (!c->a_act_low || !c->a_act_high || !c->a_0)) return PCG_E_NULL;
-  if ((c->flags & PCG_F_NOISE) && !c->noise_pct) return PCG_E_NULL;
-  if ((c->flags & PCG_F_GAUSS_DIST) && nd && (!c->d_sigma || !c->d_clip_lo || !c->d_clip_hi)) return PCG_E_NULL;
-
-  std::memset(d, 0, sizeof(*d));
-  double ddef[PCG_MAX_NDM] = {0, 0, 0, 0};
-  k.prep(c->params, nx, na, k.dynamic ? d->kp_big : d->kp, ddef);
-  for (int j = 0; j < k.ndm; ++j) d->d_default[j] = ndm ? c->d_default[j] : ddef[j];
-  const bool norm_a = c->flags & PCG_F_NORMALISE_A, norm_o = c->flags & PCG_F_NORMALISE_O;
-  const bool compat = c->flags & PCG_F_REF_COMPAT;
-  for (int i = 0; i < na; ++i) {
-    const double lo = c->a_low[i], hs = (c->a_high[i] - c->a_low[i]) / 2;
-    if (!norm_a) {
-      d->amap[i] = AMap{0, 1, 0};
-    } else if ((c->flags & PCG_F_A_DELTA) && compat) {
-      // Q1 (pcgym.py:372-379): f(f(a)), f(a) = (a+1)*hs + lo
-      d->amap[i] = AMap{1, hs * hs, (lo + 1) * hs + lo};
-    } else {
-      d->amap[i] = AMap{1, hs, lo};
-    }
-    if (c->flags & PCG_F_A_DELTA) {
-      d->a_act_lo[i] = c->a_act_low[i]; d->a_act_hi[i] = c->a_act_high[i]; d->a_0[i] = c->a_0[i];
-    }
-  }
-  for (int i = 0; i < nobs; ++i) {
-    const bool masked = (i < nx) && c->obs_mask && !c->obs_mask[i];
-    if (masked) {
-      d->omap[i] = OMap{0, 0, 0};
-    } else if (norm_o) {
-      if (!(c->o_high[i] > c->o_low[i])) return PCG_E_VALUE;
-      d->omap[i] = OMap{c->o_low[i], 2.0 / (c->o_high[i] - c->o_low[i]), -1.0};
-    } else {
-      d->omap[i] = OMap{0, 1, 0};
-    }
-  }
-  for (int i = 0; i < nsp; ++i) {
-    if (c->sp_index[i] < 0 || c->sp_index[i] >= nx) return PCG_E_DIM;
-    d->sp_index[i] = c->sp_index[i];
-  }
-  for (int i = 0; i < nrew; ++i) {
-    if (c->rew_index[i] < 0 || c->rew_index[i] >= nx) return PCG_E_DIM;
-    d->rew_index[i] = c->rew_index[i];
-  }
-  const int nrs = (c->flags & PCG_F_REWARD_BATCH) ? nrew : nsp;
-  for (int i = 0; i < nrs; ++i) d->r_scale[i] = c->r_scale[i];
-  if (c->flags & PCG_F_NOISE)
-    for (int i = 0; i < nx; ++i) d->noise_pct[i] = c->noise_pct[i];
-  for (int i = 0; i < nx + nso; ++i) d->x0[i] = c->x0[i];
-  d->has_x0_unc = c->x0_unc ? 1 : 0;
-  if (c->x0_unc)
-    for (int i = 0; i < nx; ++i) d->x0_unc[i] = c->x0_unc[i];
-  for (int i = 0; i < nd; ++i) {
-    if (c->d_slot[i] < 0 || c->d_slot[i] >= ndm) return PCG_E_DIM;
-    d->d_slot[i] = c->d_slot[i];
-    if (c->flags & PCG_F_GAUSS_DIST) {
-      d->d_sigma[i] = c->d_sigma[i]; d->d_lo[i] = c->d_clip_lo[i]; d->d_hi[i] = c->d_clip_hi[i];
-    }
-  }
-  // constraint rows: cfg layout [state(nobs) | uk(cnu)] -> padded kernel layout; compat Q3 folded:
-  //   state' = (s+1)*hs + lo = s*hs + (hs+lo)   (pcgym.py:601-608), input' likewise with a_space (:597-600)
-  for (int r = 0; r < ncon; ++r) {
-    const double* row = c->con_A + (size_t)r * (nobs + cnu);
-    double b = c->con_b[r];
-    for (int i = 0; i < nobs; ++i) {
-      double coef = row[i];
-      if (compat && norm_o) {
-        const double hs = (c->o_high[i] - c->o_low[i]) / 2;
-        b -= coef * (hs + c->o_low[i]);
-        coef *= hs;
-      }
-      if (i >= nx + nso + nd) {  // uncertain-parameter slots cannot enter constraint rows
-        if (coef != 0.0) return PCG_E_UNSUPPORTED;
-        continue;
-      }
-      const int col = (i < nx) ? i : (i < nx + nso) ? PCG_MAX_NX + (i - nx) : PCG_MAX_NX + PCG_MAX_NSP + (i - nx - nso);
-      d->con_A[r][col] = coef;
-    }
-    for (int j = 0; j < cnu; ++j) {
-      double coef = row[nobs + j];
-      if (compat && norm_a) {
-        if (cnu != na && na != 1) return PCG_E_UNSUPPORTED;  // the reference itself raises (broadcast error)
-        const int q = (na == 1) ? 0 : j;
-        const double hs = (c->a_high[q] - c->a_low[q]) / 2;
-        b -= coef * (hs + c->a_low[q]);
-        coef *= hs;
-      }
-      const int col = PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + ((j < na) ? j : PCG_MAX_NA + (j - na));
-      d->con_A[r][col] = coef;
-    }
-    d->con_b[r] = b;
-  }
-  d->nunc = nunc;
-  if (!k.dynamic)
-    for (int i = 0; i < k.nraw && i < 32; ++i) d->raw[i] = c->params[i];
-  for (int j = 0; j < nunc; ++j) {
-    if (c->unc_index[j] < 0 || c->unc_index[j] >= k.nraw) return PCG_E_DIM;
-    d->unc_index[j] = c->unc_index[j];
-    d->unc_pct[j] = c->unc_pct[j];
-    if (c->flags & PCG_F_UNC_EMPIRICAL) {
-      if (!c->unc_emp || !c->unc_emp_off) return PCG_E_NULL;
-      if (c->unc_emp_off[0] != 0 || c->unc_emp_off[j + 1] <= c->unc_emp_off[j] || c->unc_emp_off[j + 1] > PCG_MAX_EMP)
-        return PCG_E_DIM;
-      d->emp_off[j] = c->unc_emp_off[j];
-      d->emp_off[j + 1] = c->unc_emp_off[j + 1];
-    }
-  }
-  d->dt = c->dt;
-  d->h = c->dt / (c->substeps > 0 ? c->substeps : 1);
-  d->rtol = c->rtol;
-  d->atol = c->atol;
-  d->nx = nx; d->na = na; d->ndm = ndm; d->nd = nd; d->nsp = nsp; d->nsp_obs = nso; d->ncon = ncon; d->nrew = nrew;
-  d->N = c->N; d->substeps = c->substeps; d->max_steps = c->max_steps; d->nobs = nobs;
-  d->flags = c->flags;
-  if (cfg_nu_out) *cfg_nu_out = cnu;
-  return PCG_OK;
-}
-
-int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
-  if (!out || !cfg) return PCG_E_NULL;
-  *out = nullptr;
-  pcg_plan* p = new (std::nothrow) pcg_plan();
-  if (!p) return (int)hipErrorOutOfMemory;
-  int rc = build_devconst(cfg, &p->hc, &p->cfg_nu);
-  if (rc != PCG_OK) {
-    delete p;
-    return rc;
-  }
-  p->magic = PLAN_MAGIC;
-  p->model_id = cfg->model_id;
-  p->integrator_id = cfg->integrator_id;
-  p->lds_stages = 0;
-  p->variant = 0;
-  p->stream_bpc = 0;
-  p->nt_stores = 1;  // measured: 20.3 -> 18.7 us per launch on the cstr workload (profiles/)
-  p->prio_mode = 0;
-  p->num_cus = 0;
-  for (auto& r : p->stream_occ) for (int& v : r) v = 0;
-  p->stream_unr = 0;
-  p->pipe_occ[0] = p->pipe_occ[1] = 0;
-  p->env_offset = 0;
-  p->dC = nullptr;
-  p->dsched = nullptr;
-  hipError_t e = hipGetDevice(&p->device);
-  if (e == hipSuccess) e = hipDeviceGetAttribute(&p->num_cus, hipDeviceAttributeMultiprocessorCount, p->device);
-  if (e != hipSuccess) { delete p; return (int)e; }
-  const int rows = cfg->nsp + cfg->nd;
-  const bool emp = (cfg->flags & PCG_F_UNC_EMPIRICAL) && cfg->nunc > 0;
-  const size_t n_emp = emp ? (size_t)cfg->unc_emp_off[cfg->nunc] : 0;
-  p->sched_bytes = sizeof(double) * (size_t)(rows > 0 ? rows : 1) * cfg->N;
-  const size_t sched_alloc = sizeof(double) * ((size_t)(rows > 0 ? rows : 1) * cfg->N + n_emp);
-  e = hipMalloc((void**)&p->dC, sizeof(DevConst));
-  if (e == hipSuccess) e = hipMalloc((void**)&p->dsched, sched_alloc);
-  if (e == hipSuccess) e = hipMemcpy(p->dC, &p->hc, sizeof(DevConst), hipMemcpyHostToDevice);
-  if (e == hipSuccess && cfg->nsp)
-    e = hipMemcpy(p->dsched, cfg->sp, sizeof(double) * (size_t)cfg->nsp * cfg->N, hipMemcpyHostToDevice);
-  if (e == hipSuccess && cfg->nd)
-    e = hipMemcpy(p->dsched + (size_t)cfg->nsp * cfg->N, cfg->d_sched, sizeof(double) * (size_t)cfg->nd * cfg->N,
-                  hipMemcpyHostToDevice);
-  if (e == hipSuccess && n_emp)  // empirical sample tables behind the schedule rows
-    e = hipMemcpy(p->dsched + (size_t)rows * cfg->N, cfg->unc_emp, sizeof(double) * n_emp, hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    if (p->dC) (void)hipFree(p->dC);
-    if (p->dsched) (void)hipFree(p->dsched);
-    delete p;
-    return (int)e;
-  }
-  *out = p;
-  return PCG_OK;
-}
-
-static bool plan_ok(const pcg_plan* p) { return p && p->magic == PLAN_MAGIC; }
-
-int pcg_plan_destroy(pcg_plan* p) {
-  if (!plan_ok(p)) return PCG_E_PLAN;
-  p->magic = 0;
-  hipError_t e1 = hipFree(p->dC), e2 = hipFree(p->dsched);
-  delete p;
-  if (e1 != hipSuccess) return (int)e1;
-  if (e2 != hipSuccess) return (int)e2;
-  return PCG_OK;
-}
-
-int pcg_plan_set_env_offset(pcg_plan* p, int64_t env_offset) {
-  if (!plan_ok(p)) return PCG_E_PLAN;
-  p->env_offset = env_offset;
-  return PCG_OK;
-}
-
-int pcg_plan_set_option(pcg_plan* p, int option, int64_t value) {
-  if (!plan_ok(p)) return PCG_E_PLAN;
-  switch (option) {
-    case PCG_OPT_ENV_OFFSET: p->env_offset = value; return PCG_OK;
-    case PCG_OPT_LDS_STAGES: p->lds_stages = value ? 1 : 0; return PCG_OK;
-    case PCG_OPT_STREAM_BLOCKS_PER_CU: p->stream_bpc = (int)value; return PCG_OK;
-    case PCG_OPT_NT_STORES: p->nt_stores = value ? 1 : 0; return PCG_OK;
-    case PCG_OPT_STREAM_UNROLL: p->stream_unr = (int)value; return PCG_OK;
-    case PCG_OPT_PRIO_STAGGER: p->prio_mode = (int)value; return PCG_OK;
-    case PCG_OPT_VARIANT:
-      if (value < 0 || value > 4) return PCG_E_VALUE;
-      p->variant = (int)value;
-      return PCG_OK;
-    default: return PCG_E_VALUE;
-  }
-}
-
-int64_t pcg_plan_bytes_per_env_step(const pcg_plan* p, const pcg_buffers* io) {
-  if (!plan_ok(p) || !io) return PCG_E_PLAN;
-  const DevConst& c = p->hc;
-  // read x, read a, write x', write obs, write reward, done (+viol)
-  int64_t A = 8 * (int64_t)(c.nx + c.na + c.nx + c.nobs + 1) + 1;
-  if (io->viol) A += 1;
-  if (io->d) A += 8 * c.nd;
-  if (io->g) A += 8 * c.ncon;
-  if (io->t) A += 8;
-  if ((c.flags & PCG_F_A_DELTA) && io->a_save) A += 16 * c.na;
-  if (io->nsteps) A += 8;
-  A += 16 * c.nunc;  // per-env parameters read + their observation slots written
-  return A;
-}
-
-static int fill_args(const pcg_plan* p, const pcg_buffers* io, StepArgs* a) {
-  if (!plan_ok(p)) return PCG_E_PLAN;
-  if (!io) return PCG_E_NULL;
-  if (io->B < 0) return PCG_E_DIM;
-  std::memset(a, 0, sizeof(*a));
-  a->C = (CDevConst*)p->dC; a->sched = (const PCG_CONSTANT double*)p->dsched;
-  a->x = io->x; a->a = io->a; a->d = io->d; a->t = io->t; a->a_save = io->a_save; a->obs = io->obs;
-  a->rew = io->rew; a->done = io->done; a->viol = io->viol; a->g = io->g; a->g_pre = io->g_pre;
-  a->nsteps = io->nsteps; a->B = io->B; a->env_offset = p->env_offset;
-  a->p_unc = io->p_unc;
-  a->prio_mode = p->prio_mode;
-  return PCG_OK;
-}
-
-static inline unsigned grid_for(int64_t B, int block = BLOCK) { return (unsigned)((B + block - 1) / block); }
-
-// Resident 256-thread workgroups per CU (= waves per SIMD) of a persistent kernel; < 0: -(hipError_t).
-// The occupancy API over-reports by one for some register counts on ROCm 7.2 (MI355X_MICROARCH.md
-// "Residency"), and a persistent grid with a non-resident workgroup serialises a whole extra round:
-// bound it by the VGPR allocation too.
-static int resident_blocks(StepFn fn) {
-  int nb = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, BLOCK, 0);
-  if (e != hipSuccess) return -(int)e;
-  hipFuncAttributes fa;
-  e = hipFuncGetAttributes(&fa, (const void*)fn);
-  if (e != hipSuccess) return -(int)e;
-  const int alloc = ((fa.numRegs + 7) / 8) * 8;
-  const int by_vgpr = alloc > 0 ? 512 / alloc : 8;
-  if (nb > by_vgpr) nb = by_vgpr;
-  if (nb > 8) nb = 8;
-  return nb > 0 ? nb : 1;
-}
-
-// Fill every lazily queried occupancy of the plan's candidate persistent kernels (done before a stream
-// capture so that no query runs while capturing).
-static int warm_occupancy(pcg_plan* p) {
-  const Kernels& k = kernels(p->model_id);
-  for (int e = 0; e < 2; ++e) {
-    if (p->integrator_id == PCG_INT_RK4 && k.pipe[e] && p->pipe_occ[e] == 0) {
-      const int q = resident_blocks(k.pipe[e]);
-      if (q < 0) return -q;
-      p->pipe_occ[e] = q;
-    }
-    for (int lu = 0; lu < 3; ++lu)
-      if (k.stream[p->integrator_id][e][lu] && p->stream_occ[e][lu] == 0) {
-        const int q = resident_blocks(k.stream[p->integrator_id][e][lu]);
-        if (q < 0) return -q;
-        p->stream_occ[e][lu] = q;
-      }
-  }
-  return PCG_OK;
-}
-
-int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void* stream) {
-  StepArgs a;
-  int rc = fill_args(p, io, &a);
-  if (rc != PCG_OK) return rc;
-  if (io->B == 0) return PCG_OK;  // empty batch: nothing to do (zero-size buffers may be NULL)
-  if (!io->x || !io->a || !io->obs || !io->rew || !io->done) return PCG_E_NULL;
-  const DevConst& c = p->hc;
-  if ((c.flags & PCG_F_A_DELTA) && !io->a_save) return PCG_E_NULL;
-  a.t_scalar = t;
-  a.seed = seed;
-  const bool per_env_t = io->t != nullptr;
-  const Kernels& k = kernels(p->model_id);
-  const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
-  const int block = tb(lds_st);
-  size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
-  if (per_env_t) {
-    const size_t sb = sizeof(double) * (size_t)(c.nsp + c.nd) * c.N;
-    if (sb > 0 && shmem + sb <= 64 * 1024) {
-      a.sched_in_lds = 1;
-      shmem += sb;
-    }
-  }
-  if (c.nunc > 0) {  // per-env uncertain parameters: dedicated general kernel
-    if (!io->p_unc) return PCG_E_NULL;
-    StepFn ufn = k.step_unc[p->integrator_id][per_env_t ? 1 : 0];
-    if (!ufn) return PCG_E_UNSUPPORTED;
-    size_t sh = 0;
-    if (per_env_t) {
-      const size_t sb = sizeof(double) * (size_t)(c.nsp + c.nd) * c.N;
-      if (sb > 0 && sb <= 64 * 1024) {
-        a.sched_in_lds = 1;
-        sh = sb;
-      }
-    }
-    hipLaunchKernelGGL(ufn, dim3(grid_for(io->B, BLOCK)), dim3(BLOCK), sh, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
-  }
-  // lean variant when no noise / Gaussian disturbance / constraint work is configured
-  // (the lean kernels also compile out a_delta, the terminal "batch" reward and per-env disturbances)
-  const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH)) ||
-                      c.ncon > 0 || io->d != nullptr;
-  // streaming (persistent, prefetching, 16 B/lane) kernel for the lean lock-stepped path
-  if (!per_env_t && !extras && !lds_st && !io->viol && p->variant != 1 && k.stream[p->integrator_id][0][0]) {
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    const bool epl2_ok = k.stream[p->integrator_id][1][0] && (io->B % 2 == 0) && al16(io->x) && al16(io->a) &&
-                         al16(io->obs) && al16(io->rew) && (reinterpret_cast<uintptr_t>(io->done) & 1u) == 0;
-    int epl = (p->variant == 2) ? 1 : (epl2_ok ? 2 : 1);
-    if (p->variant == 3 && !epl2_ok) return PCG_E_UNSUPPORTED;
-    int lu = p->stream_unr;  // log2(sub-tiles per workgroup)
-    if (lu < 0 || lu > 2 || !k.stream[p->integrator_id][epl - 1][lu]) lu = 0;
-    StepFn sfn = k.stream[p->integrator_id][epl - 1][lu];
-    // auto (0): the software-pipelined kernel where it exists (measured best on the cstr workload:
-    // 14.9 us vs 15.0 two-sub-tile streaming vs 16.9 plain streaming vs 21 classic, profiles/r1)
-    const bool piped = (p->variant == 4 || p->variant == 0) && p->integrator_id == PCG_INT_RK4 && k.pipe[epl - 1];
-    if (piped) {
-      sfn = k.pipe[epl - 1];
-      lu = 0;
-    }
-    int& occ = piped ? p->pipe_occ[epl - 1] : p->stream_occ[epl - 1][lu];
-    if (occ == 0) {
-      const int q = resident_blocks(sfn);
-      if (q < 0) return -q;
-      occ = q;
-    }
-    const int64_t tile_envs = (int64_t)BLOCK * epl * (1 << lu);
-    const int64_t ntile = (io->B + tile_envs - 1) / tile_envs;
-    int bpc = occ;
-    if (p->stream_bpc > 0 && p->stream_bpc < bpc) bpc = p->stream_bpc;
-    int64_t grid = (int64_t)p->num_cus * bpc;
-    if (grid > ntile) grid = ntile;
-    a.nt_stores = p->nt_stores;
-    hipLaunchKernelGGL(sfn, dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
-  }
-  StepFn fn = k.step[p->integrator_id][per_env_t ? 1 : 0][lds_st ? 1 : 0][extras ? 1 : 0];
-  if (shmem > 48 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(fn, dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
-}
-
-int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t T, const double* a_seq,
-                        int64_t a_step_stride, int64_t a_comp_stride, double* obs_seq, int64_t obs_step_stride,
-                        int64_t obs_comp_stride, double* rew_seq, int64_t rew_step_stride, uint64_t seed,
-                        void* stream) {
-  StepArgs a;
-  int rc = fill_args(p, io, &a);
-  if (rc != PCG_OK) return rc;
-  if (io->t) return PCG_E_UNSUPPORTED;  // lock-stepped only
-  if (T < 1) return PCG_E_VALUE;
-  if (io->B == 0) return PCG_OK;
-  if (!io->x || !a_seq || !io->obs || !io->rew || !io->done) return PCG_E_NULL;
-  const DevConst& c = p->hc;
-  if ((c.flags & PCG_F_A_DELTA) && !io->a_save) return PCG_E_NULL;
-  if (c.nunc > 0) return PCG_E_UNSUPPORTED;  // parameter uncertainty: per-step kernel only
-  a.t_scalar = t0;
-  a.seed = seed;
-  a.T = T;
-  a.a_seq = a_seq;
-  a.obs_seq = obs_seq;
-  a.rew_seq = rew_seq;
-  a.a_ss = a_step_stride; a.a_cs = a_comp_stride;
-  a.o_ss = obs_step_stride; a.o_cs = obs_comp_stride;
-  a.r_ss = rew_step_stride;
-  if (a.a_cs < io->B || (obs_seq && a.o_cs < io->B)) return PCG_E_DIM;
-  const Kernels& k = kernels(p->model_id);
-  const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
-  const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH)) ||
-                      c.ncon > 0 || io->d != nullptr;
-  if (!extras && p->integrator_id == PCG_INT_RK4 && !io->viol && p->variant != 1 && k.roll_lean[0]) {
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    const bool ev = ((a.a_ss | a.a_cs | a.o_ss | a.o_cs | a.r_ss) & 1) == 0;  // 16-byte rows stay 16-byte aligned
-    const bool e2 = ev && k.roll_lean[1] && (io->B % 2 == 0) && al16(io->x) && al16(a_seq) && al16(io->obs) &&
-                    al16(io->rew) && (!obs_seq || al16(obs_seq)) && (!rew_seq || al16(rew_seq)) &&
-                    (reinterpret_cast<uintptr_t>(io->done) & 1u) == 0;
-    const int epl = e2 ? 2 : 1;
-    hipLaunchKernelGGL(k.roll_lean[epl - 1], dim3(grid_for(io->B, BLOCK * epl)), dim3(BLOCK), 0, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
-  }
-  const int block = tb(lds_st);
-  const size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
-  StepFn fn = k.rollout[p->integrator_id][lds_st ? 1 : 0];
-  if (shmem > 48 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(fn, dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
-}
-
-int pcg_rollout(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t T, const double* a_seq, double* obs_seq,
-                double* rew_seq, uint64_t seed, void* stream) {
-  if (!plan_ok(p)) return PCG_E_PLAN;
-  if (!io) return PCG_E_NULL;
-  const int64_t B = io->B;
-  return pcg_rollout_strided(p, io, t0, T, a_seq, (int64_t)p->hc.na * B, B, obs_seq, (int64_t)p->hc.nobs * B, B, rew_seq,
-                             B, seed, stream);
-}
-
-int pcg_reset(pcg_plan* p, const pcg_buffers* io, const uint8_t* mask, uint64_t seed, void* stream) {
-  StepArgs a;
-  int rc = fill_args(p, io, &a);
-  if (rc != PCG_OK) return rc;
-  if (io->B == 0) return PCG_OK;
-  if (!io->x || !io->obs) return PCG_E_NULL;
-  if (p->hc.nunc > 0 && !io->p_unc) return PCG_E_NULL;
-  a.mask = mask;
-  a.seed = seed;
-  hipLaunchKernelGGL(reset_kernel, dim3(grid_for(io->B)), dim3(BLOCK), 0, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
-}
-
-// ---- step graph: T pcg_step launches recorded once, replayed with one host call ------------------------------
-struct pcg_graph {
-  uint32_t magic;
-  int device;
-  hipGraph_t graph;
-  hipGraphExec_t exec;
-  int n_nodes;
-};
-static constexpr uint32_t GRAPH_MAGIC = 0x50434747u;  // 'PCGG'
-
-int pcg_graph_create(pcg_graph** out, pcg_plan* p, const pcg_buffers* io, const double* const* a_steps,
-                     const double* const* d_steps, int32_t t0, int32_t T, uint64_t seed, int with_reset) {
-  if (!out) return PCG_E_NULL;
-  *out = nullptr;
-  if (!plan_ok(p)) return PCG_E_PLAN;
-  if (!io || !a_steps) return PCG_E_NULL;
-  if (io->t) return PCG_E_UNSUPPORTED;
-  if (T <= 0 || t0 < 0 || io->B <= 0) return PCG_E_DIM;
-  for (int j = 0; j < T; ++j)
-    if (!a_steps[j] || (d_steps && !d_steps[j])) return PCG_E_NULL;
-  pcg_buffers b = *io;
-  {
-    const int wrc = warm_occupancy(p);  // launch geometry is queried lazily: do it outside the capture
-    if (wrc != PCG_OK) return wrc;
-  }
-  hipStream_t cs;
-  HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-  int rc = PCG_OK;
-  hipGraph_t g = nullptr;
-  hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) {
-    hipStreamDestroy(cs);
-    return (int)e;
-  }
-  if (with_reset) rc = pcg_reset(p, &b, nullptr, seed, cs);
-  for (int j = 0; j < T && rc == PCG_OK; ++j) {
-    b.a = a_steps[j];
-    b.d = d_steps ? d_steps[j] : nullptr;
-    rc = pcg_step(p, &b, t0 + j, seed, cs);
-  }
-  e = hipStreamEndCapture(cs, &g);
-  hipStreamDestroy(cs);
-  if (rc != PCG_OK) {
-    if (g) hipGraphDestroy(g);
-    return rc;
-  }
-  if (e != hipSuccess) return (int)e;
-  hipGraphExec_t ex = nullptr;
-  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-  if (e != hipSuccess) {
-    hipGraphDestroy(g);
-    return (int)e;
-  }
-  pcg_graph* q = new (std::nothrow) pcg_graph();
-  if (!q) {
-    hipGraphExecDestroy(ex);
-    hipGraphDestroy(g);
-    return PCG_E_VALUE;
-  }
-  q->magic = GRAPH_MAGIC;
-  q->device = p->device;
-  q->graph = g;
-  q->exec = ex;
-  q->n_nodes = T + (with_reset ? 1 : 0);
-  *out = q;
-  return PCG_OK;
-}
-
-int pcg_graph_launch(pcg_graph* q, void* stream) {
-  if (!q || q->magic != GRAPH_MAGIC) return PCG_E_PLAN;
-  return (int)hipGraphLaunch(q->exec, (hipStream_t)stream);
-}
-
-int pcg_graph_set_seed(pcg_graph* q, uint64_t seed) {
-  if (!q || q->magic != GRAPH_MAGIC) return PCG_E_PLAN;
-  size_t n = 0;
-  HIP_TRY(hipGraphGetNodes(q->graph, nullptr, &n));
-  std::vector<hipGraphNode_t> nodes(n);
-  HIP_TRY(hipGraphGetNodes(q->graph, nodes.data(), &n));
-  for (size_t i = 0; i < n; ++i) {
-    hipGraphNodeType ty;
-    HIP_TRY(hipGraphNodeGetType(nodes[i], &ty));
-    if (ty != hipGraphNodeTypeKernel) continue;
-    hipKernelNodeParams kp;
-    HIP_TRY(hipGraphKernelNodeGetParams(nodes[i], &kp));
-    if (!kp.kernelParams || !kp.kernelParams[0]) return PCG_E_UNSUPPORTED;
-    // every kernel this library records takes one by-value StepArgs: re-key it in the graph and in the executable
-    StepArgs a;
-    std::memcpy(&a, kp.kernelParams[0], sizeof(a));
-    a.seed = seed;
-    void* argv[1] = {&a};
-    kp.kernelParams = argv;
-    kp.extra = nullptr;
-    HIP_TRY(hipGraphKernelNodeSetParams(nodes[i], &kp));
-    HIP_TRY(hipGraphExecKernelNodeSetParams(q->exec, nodes[i], &kp));
-  }
-  return PCG_OK;
-}
-
-int pcg_graph_destroy(pcg_graph* q) {
-  if (!q) return PCG_OK;
-  if (q->magic != GRAPH_MAGIC) return PCG_E_PLAN;
-  hipGraphExecDestroy(q->exec);
-  hipGraphDestroy(q->graph);
-  q->magic = 0;
-  delete q;
-  return PCG_OK;
-}
-
-int pcg_rhs(pcg_plan* p, int64_t B, const double* x, const double* u, double* dx, void* stream) {
-  if (!plan_ok(p)) return PCG_E_PLAN;
-  if (!x || !u || !dx) return PCG_E_NULL;
-  if (B <= 0) return B == 0 ? PCG_OK : PCG_E_DIM;
-  const Kernels& k = kernels(p->model_id);
-  hipLaunchKernelGGL(k.rhs, dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, (CDevConst*)p->dC, B, p->cfg_nu, x, u, dx);
-  return (int)hipGetLastError();
-}
-
-int pcg_integrate(pcg_plan* p, int64_t B, double* x, const double* u, int32_t* nsteps, void* stream) {
-  if (!plan_ok(p)) return PCG_E_PLAN;
-  if (!x || !u) return PCG_E_NULL;
-  if (B <= 0) return B == 0 ? PCG_OK : PCG_E_DIM;
-  const Kernels& k = kernels(p->model_id);
-  const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
-  const int block = tb(lds_st);
-  const size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
-  IntKFn fn = k.integ[p->integrator_id][lds_st ? 1 : 0];
-  if (shmem > 48 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(fn, dim3(grid_for(B, block)), dim3(block), shmem, (hipStream_t)stream, (CDevConst*)p->dC, B, p->cfg_nu, x,
-                     u, nsteps);
-  return (int)hipGetLastError();
-}
-
-// Host-only validation of a cfg (what pcg_plan_create would return before touching the
-// device): lets the host logic be tested on machines without a GPU.
-int pcg_cfg_validate(const pcg_env_cfg* cfg) {
-  DevConst* d = new (std::nothrow) DevConst();
-  if (!d) return (int)hipErrorOutOfMemory;
-  int rc = build_devconst(cfg, d, nullptr);
-  delete d;
-  return rc;
-}
-
-}  // extern "C"
