@@ -517,6 +517,73 @@ def test_models_without_inputs_step_with_empty_actions():
         env.close()
 
 
+def test_maximum_episode_length_schedules():
+    """N = PCG_MAX_N = 4096 with three schedule rows (SP + two disturbances): 96 KiB of tables -- beyond the
+    64 KiB LDS staging budget of the per-env-t kernels (global-load fall-back) -- and one 32 KiB row that is
+    staged; every step of the longest episode is compared with the oracle at the end points and in between."""
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv, _abi as abi
+
+    N = abi.PCG_MAX_N
+    rng = np.random.default_rng(4096)
+    base = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+    base.update(N=N, tsim=N / 60.0, SP={"Ca": (0.85 + 0.05 * rng.uniform(-1, 1, N)).tolist()})
+    big = copy.deepcopy(base)
+    big.update(disturbances={"Ti": 350.0 + 3.0 * rng.uniform(-1, 1, N), "Caf": 1.0 + 0.05 * rng.uniform(-1, 1, N)},
+               disturbance_bounds={"low": np.array([320.0, 0.9]), "high": np.array([360.0, 1.1])})
+    for p in (base, big):
+        for per_env_t in (False, True):
+            B = 130
+            env = VecEnv(copy.deepcopy(p), n_envs=B, seed=1, per_env_t=per_env_t)
+            orc = O.OracleEnv(env.spec, B, seed=1, per_env_t=per_env_t)
+            env.reset()
+            orc.reset()
+            acts = _rand_actions(env.spec, 16, B, 5) * 0.2  # mild actions: stay away from ignition for 4095 steps
+            ag = [torch.tensor(a, device=env.device) for a in acts]
+            for i in range(N - 1):
+                og, rg, dg, _, _ = env.step(ag[i % 16])
+                oc, rc, dc = orc.step(acts[i % 16])
+                if i % 500 == 0 or i >= N - 3:
+                    assert np.max(np.abs(og.cpu().numpy().T - oc)) <= 1e-9, (i, per_env_t)
+                    assert np.allclose(rg.cpu().numpy(), rc, rtol=1e-9, atol=1e-12), (i, per_env_t)
+                    assert np.array_equal(dg.cpu().numpy().astype(np.uint8), dc)
+            assert bool(dg.all()) and env.t == N - 1
+            env.close()
+    with pytest.raises(ValueError, match="N must be in"):
+        VecEnv(dict(base, N=N + 1, SP={"Ca": [0.85] * (N + 1)}), n_envs=1)
+
+
+def test_sixteen_million_envs_tail_window_vs_oracle():
+    """B = 2^24 + 6 envs (64-bit indexing, ragged last tile, 1.2 GB of state/obs): the LAST 4096 envs are compared
+    with the oracle, which reproduces exactly that window through env_offset (RNG streams are keyed by the
+    global env index), plus whole-batch invariants."""
+    torch = _torch()
+    import bench as BN
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    B, W = (1 << 24) + 6, 4096
+    env = VecEnv(BN.workload_params(B), n_envs=B, seed=11)
+    orc = O.OracleEnv(env.spec, W, seed=11, env_offset=B - W)
+    env.reset()
+    orc.reset()
+    assert np.allclose(env.x[:, B - W:].cpu().numpy(), orc.x, rtol=4e-16, atol=0)  # FMA contraction: <= 2 ulp
+    gen = torch.Generator(device=env.device).manual_seed(3)
+    for i in range(4):
+        a = 2 * torch.rand((1, B), generator=gen, device=env.device, dtype=torch.float64) - 1
+        og, rg, dg, _, _ = env.step(a)
+        oc, rc, dc = orc.step(a[:, B - W:].cpu().numpy())
+        assert np.max(np.abs(env.x[:, B - W:].cpu().numpy() - orc.x) / np.abs(orc.x)) <= 1e-12
+        assert np.max(np.abs(env.obs_soa[:, B - W:].cpu().numpy() - oc)) <= 1e-11
+        assert np.allclose(rg[B - W:].cpu().numpy(), rc, rtol=1e-10, atol=1e-12)
+    assert bool(torch.isfinite(env.x).all()) and bool(torch.isfinite(env.rew).all())
+    assert float(env.x[0].min()) > 0.0 and not bool(env.done.any())
+    env.close()
+
+
 # ------------------------------------------------ full-size property tests ---
 def test_full_size_cstr_properties():
     """BASELINE.json configs[1] size (B = 2^20): size-independent properties.
