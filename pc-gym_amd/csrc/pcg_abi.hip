@@ -510,7 +510,7 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   const bool per_env_t = io->t != nullptr;
   const Kernels& k = kernels(p->model_id);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
-  const int block = tb(lds_st);
+  const int block = tb(lds_st, p->integrator_id);
   size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
   if (per_env_t) {
     const size_t sb = sizeof(double) * (size_t)(c.nsp + c.nd) * c.N;
@@ -531,7 +531,8 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
         sh = sb;
       }
     }
-    hipLaunchKernelGGL(ufn, dim3(grid_for(io->B, BLOCK)), dim3(BLOCK), sh, (hipStream_t)stream, a);
+    const int ub = tb(false, p->integrator_id);
+    hipLaunchKernelGGL(ufn, dim3(grid_for(io->B, ub)), dim3(ub), sh, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
   // lean variant when no noise / Gaussian disturbance / constraint work is configured
@@ -539,7 +540,11 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH)) ||
                       c.ncon > 0 || io->d != nullptr;
   // streaming (persistent, prefetching, 16 B/lane) kernel for the lean lock-stepped path
-  if (!per_env_t && !extras && !lds_st && !io->viol && p->variant != 1 && k.stream[p->integrator_id][0][0]) {
+  // Adaptive stepping is left to the one-wave-per-workgroup classic kernel unless a streaming variant is forced:
+  // lanes take different numbers of steps, and a persistent grid fixes each wave's share of the batch up front,
+  // whereas the dispatcher hands single-wave workgroups to whichever SIMD slot frees first.
+  const bool stream_ok = p->integrator_id == PCG_INT_RK4 || p->variant == 2 || p->variant == 3;
+  if (!per_env_t && !extras && !lds_st && !io->viol && p->variant != 1 && stream_ok && k.stream[p->integrator_id][0][0]) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool epl2_ok = k.stream[p->integrator_id][1][0] && (io->B % 2 == 0) && al16(io->x) && al16(io->a) &&
                          al16(io->obs) && al16(io->rew) && (reinterpret_cast<uintptr_t>(io->done) & 1u) == 0;
@@ -616,7 +621,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
     hipLaunchKernelGGL(k.roll_lean[epl - 1], dim3(grid_for(io->B, BLOCK * epl)), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
-  const int block = tb(lds_st);
+  const int block = tb(lds_st, p->integrator_id);
   const size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
   StepFn fn = k.rollout[p->integrator_id][lds_st ? 1 : 0];
   if (shmem > 48 * 1024)
@@ -771,7 +776,7 @@ int pcg_integrate(pcg_plan* p, int64_t B, double* x, const double* u, int32_t* n
   if (B <= 0) return B == 0 ? PCG_OK : PCG_E_DIM;
   const Kernels& k = kernels(p->model_id);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
-  const int block = tb(lds_st);
+  const int block = tb(lds_st, p->integrator_id);
   const size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
   IntKFn fn = k.integ[p->integrator_id][lds_st ? 1 : 0];
   if (shmem > 48 * 1024)

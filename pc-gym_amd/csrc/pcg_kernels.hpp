@@ -45,7 +45,9 @@ namespace pcg {
 
 constexpr int BLOCK = 256;      // threads per workgroup (4 waves, one per SIMD)
 constexpr int BLOCK_LDS = 64;   // LDS-staged DOPRI5: 6*NX*8 B of stage storage per lane
-constexpr int tb(bool lds_stages) { return lds_stages ? BLOCK_LDS : BLOCK; }
+// Adaptive (DOPRI5) kernels run one wave per workgroup: lanes take different numbers of steps, a 4-wave workgroup
+// holds its CU slots until its slowest wave ends, and single-wave workgroups let the dispatcher refill per wave.
+constexpr int tb(bool lds_stages, int integ) { return (lds_stages || integ == PCG_INT_DOPRI5) ? BLOCK_LDS : BLOCK; }
 // Minimum waves per SIMD asked of the register allocator.  DOPRI5 with <= 10 states needs ~280 registers
 // when left alone (1 wave/SIMD, latency-bound: measured 14k cycles per attempted step against ~3.6k of
 // issue); capping it at 256 costs a few spills and doubles the resident waves.
@@ -484,14 +486,14 @@ PCG_DEV void stage_schedules(const StepArgs& A, CDevConst& c, double* sched_l) {
 }
 
 template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS, bool UNC = false>
-__global__ __launch_bounds__(tb(LDS_STAGES), wpe(M::NX, INTEG, LDS_STAGES)) void step_kernel(const StepArgs A) {
+__global__ __launch_bounds__(tb(LDS_STAGES, INTEG), wpe(M::NX, INTEG, LDS_STAGES)) void step_kernel(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA;
   double* stage_l = lds;
   double* sched_l = lds + (LDS_STAGES ? 6 * NX * BLOCK_LDS : 0);
   if (PER_ENV_T) stage_schedules(A, c, sched_l);
-  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES) + threadIdx.x;
+  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES, INTEG) + threadIdx.x;
   if (e >= A.B) return;
   const int64_t B = A.B;
   const int nx = M::DYNAMIC ? c.nx : NX;
@@ -973,11 +975,11 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel_lean(const StepArgs A) {
 
 // Open-loop fused rollout: T env steps with x in registers ("next" row f-1).
 template <class M, int INTEG, bool LDS_STAGES>
-__global__ __launch_bounds__(tb(LDS_STAGES)) void rollout_kernel(const StepArgs A) {
+__global__ __launch_bounds__(tb(LDS_STAGES, INTEG)) void rollout_kernel(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA;
-  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES) + threadIdx.x;
+  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES, INTEG) + threadIdx.x;
   if (e >= A.B) return;
   const int64_t B = A.B;
   const int nx = M::DYNAMIC ? c.nx : NX;
@@ -1028,12 +1030,12 @@ __global__ __launch_bounds__(BLOCK) void rhs_kernel(CDevConst* C, int64_t B, int
 }
 
 template <class M, int INTEG, bool LDS_STAGES>
-__global__ __launch_bounds__(tb(LDS_STAGES)) void integrate_kernel(CDevConst* C, int64_t B, int nu_rows,
+__global__ __launch_bounds__(tb(LDS_STAGES, INTEG)) void integrate_kernel(CDevConst* C, int64_t B, int nu_rows,
                                                                    double* xg, const double* ug, int32_t* nsteps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   CDevConst& c = *C;
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
-  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES) + threadIdx.x;
+  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES, INTEG) + threadIdx.x;
   if (e >= B) return;
   const int nx = M::DYNAMIC ? c.nx : NX;
   const int na = M::DYNAMIC ? c.na : NA;

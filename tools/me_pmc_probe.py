@@ -1,0 +1,17 @@
+import os, sys
+ROOT = "/root/repo"
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import torch
+import scenarios as SC
+from pcgym_amd import VecEnv
+name = sys.argv[1]
+B = 262144
+p = dict(SC.scenarios()[name]["env_params"]); p.update(integrator="dopri5", rtol=1e-8, atol=1e-8)
+env = VecEnv(p, n_envs=B, seed=3); env.reset()
+gen = torch.Generator(device=env.device).manual_seed(7)
+for i in range(6):
+    a = 2 * torch.rand((env.spec.na, B), generator=gen, device=env.device, dtype=torch.float64) - 1
+    env.step(a)
+torch.cuda.synchronize()
+ns = env.nsteps.double()
+print("attempted mean", (ns[0] + ns[1]).mean().item())
