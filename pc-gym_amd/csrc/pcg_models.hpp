@@ -294,8 +294,9 @@ struct Model<PCG_MODEL_CRYST> {
     const R S2 = S * S;
     // (S^2)^(kc/2) (mu3^2)^(kd/2) and (S^2)^(k2/2) share log(S^2): two logs + two exps instead of the
     // reference's three pow() (model_classes.py:1299-1300) -- a third of the instructions; the exponent
-    // is O(30), so the result is within ~1e-14 relative of the pow form (parity bar 1e-12).
-    const R L1 = log(S2), L3 = log(mu3 * mu3);
+    // is O(30), so the result is within ~1e-14 relative of the pow form (parity bar 1e-12).  log_pos / exp_bounded:
+    // range-restricted forms (pcg_pack.hpp), S^2 and mu3^2 are positive and far from the denormal range.
+    const R L1 = log_pos(S2), L3 = log_pos(mu3 * mu3);
     const R B0 = h.eB * exp_bounded(k.kc2 * L1 + k.kd2 * L3);
     const R Ginf = h.eG * exp_bounded(k.k22 * L1);
     const R m12 = k.a * mu1 * 1e-4 + k.b * mu2 * 1e-8;

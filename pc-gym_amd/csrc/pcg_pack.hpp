@@ -117,6 +117,40 @@ PCG_PK double exp_bounded(double x) {
   p = __builtin_fma(p, r, 1.0);
   return __builtin_ldexp(p, (int)n);
 }
+// log(x) for finite, normal x > 0 (clamped below at DBL_MIN): x = m 2^e with m in [sqrt(1/2), sqrt(2)),
+// log m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716, odd Taylor series to s^21 (truncation 2e-17 relative),
+// then e ln2 in two pieces.  ~1-2 ulp; ~40 VALU instructions against ~150 for the library log(), which carries
+// the result in double-double and selects among zero / negative / inf / NaN / denormal inputs.
+PCG_PK double log_pos(double x) {
+  x = __builtin_fmax(x, 2.2250738585072014e-308);
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double s = div_fast(m - 1.0, m + 1.0);
+  const double z = s * s;
+  double p = 2.0 / 21.0;
+  p = __builtin_fma(p, z, 2.0 / 19.0);
+  p = __builtin_fma(p, z, 2.0 / 17.0);
+  p = __builtin_fma(p, z, 2.0 / 15.0);
+  p = __builtin_fma(p, z, 2.0 / 13.0);
+  p = __builtin_fma(p, z, 2.0 / 11.0);
+  p = __builtin_fma(p, z, 2.0 / 9.0);
+  p = __builtin_fma(p, z, 2.0 / 7.0);
+  p = __builtin_fma(p, z, 2.0 / 5.0);
+  p = __builtin_fma(p, z, 2.0 / 3.0);
+  const double lm = __builtin_fma(s * z, p, s + s);
+  const double de = (double)e;
+  return __builtin_fma(de, 6.93147180369123816490e-01, __builtin_fma(de, 1.90821492927058770002e-10, lm));
+}
+template <int W>
+PCG_PK Pack<W> log_pos(const Pack<W>& a) {
+  Pack<W> r;
+#pragma unroll
+  for (int i = 0; i < W; ++i) r.v[i] = log_pos(a.v[i]);
+  return r;
+}
 template <int W>
 PCG_PK Pack<W> rcp_fast(const Pack<W>& a) {
   Pack<W> r;
