@@ -121,8 +121,9 @@ struct Model<PCG_MODEL_FOUR_TANK> {
   }
   template <class R, class K>
   PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
-    const R s1 = sqrt(k.g2 * x[0]), s2 = sqrt(k.g2 * x[1]);
-    const R s3 = sqrt(k.g2 * x[2]), s4 = sqrt(k.g2 * x[3]);
+    // tank levels are O(0.01..1) m: the range-restricted square root (pcg_pack.hpp) applies
+    const R s1 = sqrt_pos(k.g2 * x[0]), s2 = sqrt_pos(k.g2 * x[1]);
+    const R s3 = sqrt_pos(k.g2 * x[2]), s4 = sqrt_pos(k.g2 * x[3]);
     dx[0] = -k.o1 * s1 + k.i31 * s3 + h.q1;
     dx[1] = -k.o2 * s2 + k.i42 * s4 + h.q2;
     dx[2] = -k.o3 * s3 + h.q3;
@@ -306,7 +307,7 @@ struct Model<PCG_MODEL_CRYST> {
     const R d2 = 2.0 * Ginf * m12 * 1e8;
     const R d3 = 3.0 * Ginf * m23 * 1e12;
     const R mu1sq = mu1 * mu1;
-    const R CV = sqrt(div_fast(mu2 * mu0, mu1sq) - 1.0);
+    const R CV = sqrt_pos(div_fast(mu2 * mu0, mu1sq) - 1.0);
     dx[0] = d0;
     dx[1] = d1;
     dx[2] = d2;

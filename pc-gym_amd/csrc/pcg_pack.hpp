@@ -151,6 +151,26 @@ PCG_PK Pack<W> log_pos(const Pack<W>& a) {
   for (int i = 0; i < W; ++i) r.v[i] = log_pos(a.v[i]);
   return r;
 }
+// sqrt(x) for x >= 0 in the normal range (exact 0 handled; negative -> NaN like the library): hardware
+// reciprocal-square-root estimate, one coupled Goldschmidt step, two residual corrections.  ~13 VALU instructions
+// against ~25 for the library sqrt(), whose extra work is the 2^+-256 rescaling for huge / denormal arguments.
+PCG_PK double sqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  return x == 0.0 ? 0.0 : g;
+}
+template <int W>
+PCG_PK Pack<W> sqrt_pos(const Pack<W>& a) {
+  Pack<W> r;
+#pragma unroll
+  for (int i = 0; i < W; ++i) r.v[i] = sqrt_pos(a.v[i]);
+  return r;
+}
 template <int W>
 PCG_PK Pack<W> rcp_fast(const Pack<W>& a) {
   Pack<W> r;
