@@ -270,8 +270,6 @@ PCG_API int pcg_plan_set_env_offset(pcg_plan* plan, int64_t env_offset);
                                  (16 B per lane accesses); non-auto values are for A/B measurement      */
 #define PCG_OPT_STREAM_BLOCKS_PER_CU 4 /* streaming kernel: resident workgroups per CU (0 = occupancy query) */
 #define PCG_OPT_NT_STORES 5   /* streaming kernel: non-temporal stores for obs / reward (not re-read by the step) */
-#define PCG_OPT_STREAM_UNROLL 6 /* streaming kernel: log2(sub-tiles per workgroup), 0..2 */
-#define PCG_OPT_PRIO_STAGGER 7 /* static wave-priority staggering by workgroup index (0 off, 1, 2) */
 PCG_API int pcg_plan_set_option(pcg_plan* plan, int option, int64_t value);
 
 /* Host-only validation of a cfg: the status pcg_plan_create() would return before it

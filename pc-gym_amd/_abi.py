@@ -32,8 +32,6 @@ PCG_OPT_LDS_STAGES = 2
 PCG_OPT_VARIANT = 3
 PCG_OPT_STREAM_BLOCKS_PER_CU = 4
 PCG_OPT_NT_STORES = 5
-PCG_OPT_STREAM_UNROLL = 6
-PCG_OPT_PRIO_STAGGER = 7
 
 PCG_INT_RK4 = 0
 PCG_INT_DOPRI5 = 1

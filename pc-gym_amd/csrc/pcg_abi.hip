@@ -119,10 +119,8 @@ struct pcg_plan {
   int variant;       // PCG_OPT_VARIANT: 0 auto, 1 classic, 2 stream EPL=1, 3 stream EPL=2
   int stream_bpc;    // PCG_OPT_STREAM_BLOCKS_PER_CU: 0 = occupancy query
   int nt_stores;     // PCG_OPT_NT_STORES
-  int prio_mode;     // PCG_OPT_PRIO_STAGGER
   int num_cus;
-  int stream_occ[2][3]; // resident workgroups per CU of the stream kernels (0 = not queried yet)
-  int stream_unr;    // PCG_OPT_STREAM_UNROLL: log2(sub-tiles per workgroup)
+  int stream_occ[2]; // resident workgroups per CU of the stream kernels [EPL-1] (0 = not queried yet)
   int pipe_occ[2];
   int64_t env_offset;
   DevConst hc;       // host copy
@@ -357,10 +355,8 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   p->variant = 0;
   p->stream_bpc = 0;
   p->nt_stores = 1;  // measured: 20.3 -> 18.7 us per launch on the cstr workload (profiles/)
-  p->prio_mode = 0;
   p->num_cus = 0;
-  for (auto& r : p->stream_occ) for (int& v : r) v = 0;
-  p->stream_unr = 0;
+  p->stream_occ[0] = p->stream_occ[1] = 0;
   p->pipe_occ[0] = p->pipe_occ[1] = 0;
   p->env_offset = 0;
   p->dC = nullptr;
@@ -418,8 +414,6 @@ int pcg_plan_set_option(pcg_plan* p, int option, int64_t value) {
     case PCG_OPT_LDS_STAGES: p->lds_stages = value ? 1 : 0; return PCG_OK;
     case PCG_OPT_STREAM_BLOCKS_PER_CU: p->stream_bpc = (int)value; return PCG_OK;
     case PCG_OPT_NT_STORES: p->nt_stores = value ? 1 : 0; return PCG_OK;
-    case PCG_OPT_STREAM_UNROLL: p->stream_unr = (int)value; return PCG_OK;
-    case PCG_OPT_PRIO_STAGGER: p->prio_mode = (int)value; return PCG_OK;
     case PCG_OPT_VARIANT:
       if (value < 0 || value > 4) return PCG_E_VALUE;
       p->variant = (int)value;
@@ -453,7 +447,6 @@ static int fill_args(const pcg_plan* p, const pcg_buffers* io, StepArgs* a) {
   a->rew = io->rew; a->done = io->done; a->viol = io->viol; a->g = io->g; a->g_pre = io->g_pre;
   a->nsteps = io->nsteps; a->B = io->B; a->env_offset = p->env_offset;
   a->p_unc = io->p_unc;
-  a->prio_mode = p->prio_mode;
   return PCG_OK;
 }
 
@@ -487,12 +480,11 @@ static int warm_occupancy(pcg_plan* p) {
       if (q < 0) return -q;
       p->pipe_occ[e] = q;
     }
-    for (int lu = 0; lu < 3; ++lu)
-      if (k.stream[p->integrator_id][e][lu] && p->stream_occ[e][lu] == 0) {
-        const int q = resident_blocks(k.stream[p->integrator_id][e][lu]);
-        if (q < 0) return -q;
-        p->stream_occ[e][lu] = q;
-      }
+    if (k.stream[p->integrator_id][e] && p->stream_occ[e] == 0) {
+      const int q = resident_blocks(k.stream[p->integrator_id][e]);
+      if (q < 0) return -q;
+      p->stream_occ[e] = q;
+    }
   }
   return PCG_OK;
 }
@@ -544,29 +536,24 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   // lanes take different numbers of steps, and a persistent grid fixes each wave's share of the batch up front,
   // whereas the dispatcher hands single-wave workgroups to whichever SIMD slot frees first.
   const bool stream_ok = p->integrator_id == PCG_INT_RK4 || p->variant == 2 || p->variant == 3;
-  if (!per_env_t && !extras && !lds_st && !io->viol && p->variant != 1 && stream_ok && k.stream[p->integrator_id][0][0]) {
+  if (!per_env_t && !extras && !lds_st && !io->viol && p->variant != 1 && stream_ok && k.stream[p->integrator_id][0]) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    const bool epl2_ok = k.stream[p->integrator_id][1][0] && (io->B % 2 == 0) && al16(io->x) && al16(io->a) &&
+    const bool epl2_ok = k.stream[p->integrator_id][1] && (io->B % 2 == 0) && al16(io->x) && al16(io->a) &&
                          al16(io->obs) && al16(io->rew) && (reinterpret_cast<uintptr_t>(io->done) & 1u) == 0;
     int epl = (p->variant == 2) ? 1 : (epl2_ok ? 2 : 1);
     if (p->variant == 3 && !epl2_ok) return PCG_E_UNSUPPORTED;
-    int lu = p->stream_unr;  // log2(sub-tiles per workgroup)
-    if (lu < 0 || lu > 2 || !k.stream[p->integrator_id][epl - 1][lu]) lu = 0;
-    StepFn sfn = k.stream[p->integrator_id][epl - 1][lu];
+    StepFn sfn = k.stream[p->integrator_id][epl - 1];
     // auto (0): the software-pipelined kernel where it exists (measured best on the cstr workload:
     // 14.9 us vs 15.0 two-sub-tile streaming vs 16.9 plain streaming vs 21 classic, profiles/r1)
     const bool piped = (p->variant == 4 || p->variant == 0) && p->integrator_id == PCG_INT_RK4 && k.pipe[epl - 1];
-    if (piped) {
-      sfn = k.pipe[epl - 1];
-      lu = 0;
-    }
-    int& occ = piped ? p->pipe_occ[epl - 1] : p->stream_occ[epl - 1][lu];
+    if (piped) sfn = k.pipe[epl - 1];
+    int& occ = piped ? p->pipe_occ[epl - 1] : p->stream_occ[epl - 1];
     if (occ == 0) {
       const int q = resident_blocks(sfn);
       if (q < 0) return -q;
       occ = q;
     }
-    const int64_t tile_envs = (int64_t)BLOCK * epl * (1 << lu);
+    const int64_t tile_envs = (int64_t)BLOCK * epl;
     const int64_t ntile = (io->B + tile_envs - 1) / tile_envs;
     int bpc = occ;
     if (p->stream_bpc > 0 && p->stream_bpc < bpc) bpc = p->stream_bpc;

@@ -121,7 +121,6 @@ struct StepArgs {
   int32_t t_scalar;
   int32_t sched_in_lds;  // per-env-t kernels: schedules staged in LDS
   int32_t nt_stores;     // stream kernels: non-temporal stores for obs / reward
-  int32_t prio_mode;     // wave priority staggering (0 off)
   // rollout
   const double* a_seq;
   double* obs_seq;
@@ -170,21 +169,6 @@ PCG_DEV void rng_normal2(uint64_t seed, uint64_t env, uint32_t t, uint32_t strea
   sincospi(2.0 * u1, &s, &c);  // angle = 2*pi*u1, u1 in [0,1): no large-argument reduction
   z0 = r * c;
   z1 = r * s;
-}
-
-// Stagger the waves that share a SIMD: identical waves started together otherwise advance in
-// lock-step (all load, all integrate, all store) and the memory system idles while the VALU works.
-// Giving them distinct static priorities makes them finish one after the other, so stores and the
-// next workgroups' loads overlap the remaining waves' arithmetic.
-PCG_DEV void stagger_priority(int mode) {
-  if (mode == 0) return;
-  const unsigned k = (mode == 1) ? (blockIdx.x & 3u) : ((blockIdx.x >> 1) & 3u);
-  switch (k) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-  }
 }
 
 // value at runtime index `idx` of a register array, without dynamic register indexing
@@ -499,7 +483,6 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG), wpe(M::NX, INTEG, LDS_STAGES
   const int nx = M::DYNAMIC ? c.nx : NX;
   const int na = M::DYNAMIC ? c.na : NA;
   const int t = PER_ENV_T ? A.t[e] : A.t_scalar;
-  stagger_priority(A.prio_mode);
   double x[NX], a[NA];
 #pragma unroll
   for (int i = 0; i < NX; ++i) x[i] = (i < nx) ? A.x[(size_t)i * B + e] : 0.0;
@@ -644,7 +627,6 @@ void step_kernel_stream(const StepArgs A) {
   const int nso = c.nsp_obs;
   const int t = A.t_scalar;
   const bool nt = A.nt_stores != 0;
-  stagger_priority(A.prio_mode);
   constexpr int64_t SUB = (int64_t)BLOCK * EPL;  // envs per sub-tile
   const int64_t tile = SUB * UNR;
   const int64_t ntile = (B + tile - 1) / tile;
@@ -1079,7 +1061,7 @@ using IntKFn = void (*)(CDevConst*, int64_t, int, double*, const double*, int32_
 
 struct Kernels {
   StepFn step[PCG_INT_COUNT][2][2][2];  // [integrator][per_env_t][lds_stages][extras]
-  StepFn stream[PCG_INT_COUNT][2][3];   // [integrator][EPL-1][log2 UNR]  (entries may be null)
+  StepFn stream[PCG_INT_COUNT][2];      // persistent streaming kernel [integrator][EPL-1] (entries may be null)
   StepFn step_unc[PCG_INT_COUNT][2]; // per-env parameter uncertainty [integrator][per_env_t] (null for affine)
   StepFn pipe[2];                    // RK4 software-pipelined lean kernel [EPL-1] (may be null)
   StepFn roll_lean[2];               // RK4 lean fused rollout [EPL-1] (may be null)
@@ -1126,18 +1108,15 @@ Kernels make_kernels() {
     k.integ[PCG_INT_DOPRI5][1] = integrate_kernel<M, PCG_INT_DOPRI5, true>;
     // streaming / pipelined lean kernels
     k.roll_lean[0] = rollout_kernel_lean<M, 1>;
-    k.stream[PCG_INT_RK4][0][0] = step_kernel_stream<M, PCG_INT_RK4, 1, 1>;
-    k.stream[PCG_INT_DOPRI5][0][0] = step_kernel_stream<M, PCG_INT_DOPRI5, 1, 1>;
-    // several envs per lane / sub-tiles per workgroup only where the per-env register footprint is
+    k.stream[PCG_INT_RK4][0] = step_kernel_stream<M, PCG_INT_RK4, 1, 1>;
+    k.stream[PCG_INT_DOPRI5][0] = step_kernel_stream<M, PCG_INT_DOPRI5, 1, 1>;
+    // several envs per lane only where the per-env register footprint is
     // small (the HBM-bound models)
     if constexpr (M::NX <= 4) {
       k.roll_lean[1] = rollout_kernel_lean<M, 2>;
       k.pipe[0] = step_kernel_pipe<M, 1>;
       k.pipe[1] = step_kernel_pipe<M, 2>;
-      k.stream[PCG_INT_RK4][0][1] = step_kernel_stream<M, PCG_INT_RK4, 1, 2>;
-      k.stream[PCG_INT_RK4][0][2] = step_kernel_stream<M, PCG_INT_RK4, 1, 4>;
-      k.stream[PCG_INT_RK4][1][0] = step_kernel_stream<M, PCG_INT_RK4, 2, 1>;
-      k.stream[PCG_INT_RK4][1][1] = step_kernel_stream<M, PCG_INT_RK4, 2, 2>;
+      k.stream[PCG_INT_RK4][1] = step_kernel_stream<M, PCG_INT_RK4, 2, 1>;
     }
   }
   // where no LDS-stage / RK4 variant exists the plain one is used

@@ -104,8 +104,7 @@ class VecEnv:
         if variant:
             _lib.check(self._lib.pcg_plan_set_option(plan, abi.PCG_OPT_VARIANT, int(variant)),
                        "pcg_plan_set_option")
-        for key, opt in (("PCG_BPC", abi.PCG_OPT_STREAM_BLOCKS_PER_CU), ("PCG_NT", abi.PCG_OPT_NT_STORES),
-                         ("PCG_UNR", abi.PCG_OPT_STREAM_UNROLL), ("PCG_PRIO", abi.PCG_OPT_PRIO_STAGGER)):
+        for key, opt in (("PCG_BPC", abi.PCG_OPT_STREAM_BLOCKS_PER_CU), ("PCG_NT", abi.PCG_OPT_NT_STORES)):
             if os.environ.get(key):  # measurement switches
                 _lib.check(self._lib.pcg_plan_set_option(plan, opt, int(os.environ[key])), "pcg_plan_set_option")
 
