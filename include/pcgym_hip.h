@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 2
+#define PCG_ABI_VERSION 3
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -119,6 +119,14 @@ enum pcg_integrator {
                                        tables (env_params["empirical_distribution"], pcgym.py:311-316:
                                        np.random.choice) instead of value*(1 +- pct)           */
 #define PCG_MAX_EMP 65536           /* total empirical samples over all parameters            */
+#define PCG_F_REWARD_TRACK 0x1000u  /* declarative form of the custom_reward family every paper script uses
+                                       (pc-gym_paper/train_policies/cstr/custom_reward.py:3-39, 4tank_train.py:16-52,
+                                       me_train.py:17-53, Biofilm/biofilm_train.py:13-41, constraint_showcase/
+                                       custom_reward.py:6-69):  r = -( sum_k r_scale_k ((o_k - SP_k[t]) / (hi_k - lo_k))^2
+                                       + sum_j [ R_du (du_j / (a_hi_j - a_lo_j))^2 + R_u ((u_j - a_lo_j) / (a_hi_j - a_lo_j))^2 ]
+                                       + [violated] sum_c box_c^2 )  on the (noisy) physical observation o and the
+                                       physical action u, with the previous action kept per env in u_prev         */
+#define PCG_MAX_RBOX 4              /* state boxes of the constraint-violation term                               */
 
 /*
  * Environment configuration: the numeric content of the reference's
@@ -190,6 +198,13 @@ typedef struct pcg_env_cfg {
   const double* unc_emp;  /* PCG_F_UNC_EMPIRICAL: concatenated sample tables, parameter j owns
                              unc_emp[unc_emp_off[j] .. unc_emp_off[j+1])                   */
   const int32_t* unc_emp_off; /* [nunc+1], unc_emp_off[0] = 0                              */
+  /* PCG_F_REWARD_TRACK */
+  double rew_R_du;        /* weight of the squared normalised action increment (R in custom_reward.py:6)     */
+  double rew_R_u;         /* weight of the squared normalised action itself (biofilm_train.py:16,39)         */
+  int32_t rew_nbox;       /* state boxes penalised while a constraint row is violated (0..PCG_MAX_RBOX)      */
+  const int32_t* rew_box_index; /* [rew_nbox] state index                                                     */
+  const double* rew_box_lo;     /* [rew_nbox] physical lower bound (constraint_showcase/custom_reward.py:4-5) */
+  const double* rew_box_hi;     /* [rew_nbox] physical upper bound                                            */
 } pcg_env_cfg;
 
 /*
@@ -213,6 +228,10 @@ typedef struct pcg_buffers {
   double* g_pre;      /* [ncon][B]  out|NULL rows of the pre-step check the reference runs when
                                             t==0 (pcgym.py:416-420); untouched for other t      */
   int32_t* nsteps;    /* [2][B]     out|NULL DOPRI5 accepted / rejected step counts             */
+  double* u_prev;     /* [na][B]    in/out|NULL previous physical action (required with PCG_F_REWARD_TRACK);
+                                            NaN = "no previous action yet" (first step: du = 0, the reference's
+                                            hasattr(self, 'u_prev') branch, custom_reward.py:7-8); pcg_reset
+                                            leaves it alone, as the reference never clears u_prev              */
   double* p_unc;      /* [nunc][B]  in/out  per-env values of the uncertain parameters: written by
                                             pcg_reset, read by pcg_step (required when nunc > 0)        */
 } pcg_buffers;

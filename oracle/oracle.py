@@ -96,6 +96,7 @@ class OracleEnv:
         self.slots = np.zeros((max(s.nsp + s.nd + s.nunc, 1), B))
         self.p_unc = np.zeros((s.nunc, B)) if s.nunc else None
         self.a_save = np.zeros((s.na, B)) if s.a_delta else None
+        self.u_prev = np.full((s.na, B), np.nan) if s.reward_track is not None else None
         self.g = np.zeros((s.ncon, B)) if s.ncon else None
         self.g_pre = np.zeros((s.ncon, B)) if s.ncon else None
         self.t_env = np.zeros(B, dtype=np.int32) if per_env_t else None
@@ -106,6 +107,7 @@ class OracleEnv:
         b.a_save, b.g, b.g_pre, b.t, b.nsteps = (_p(self.a_save), _p(self.g), _p(self.g_pre), _p(self.t_env),
                                                  _p(self.nsteps))
         b.p_unc = _p(self.p_unc)
+        b.u_prev = _p(self.u_prev)
 
     def _seed(self):
         return (self.seed0 + self.episode) & 0xFFFFFFFFFFFFFFFF

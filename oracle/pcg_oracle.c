@@ -551,6 +551,7 @@ typedef struct {
   double* state;   /* [Nobs]  reference self.state = [x | SP | d]  in/out */
   double* a_save;  /* [na]    in/out (a_delta) */
   int32_t t;       /* in/out */
+  double* u_prev;  /* [na]    in/out (custom_reward family: self.u_prev; NaN = attribute not set yet) */
 } orc_env;
 
 static int cfg_nobs(const pcg_env_cfg* c) { return c->nx + c->nsp_obs + c->nd + c->nunc; }
@@ -685,6 +686,40 @@ static void env_step(const pcg_env_cfg* c, orc_env* e, const double* action_in, 
       if ((c->flags & PCG_F_R_PENALTY) && violated) r -= 1000; /* Q4: once per SP key */
     }
   }
+  if (c->flags & PCG_F_REWARD_TRACK) {
+    /* the custom_reward family of the paper scripts, called as custom_reward_f(self, self.obs, uk, violated)
+     * (pcgym.py:470-471).  pc-gym_paper/train_policies/cstr/custom_reward.py:3-39 line by line; the R_u term is
+     * Biofilm/biofilm_train.py:36-39, the box term constraint_showcase/custom_reward.py:40-62. */
+    double cost = 0.0;
+    int ti = (e->t < c->N) ? e->t : c->N - 1;
+    for (int k = 0; k < nsp; ++k) { /* :10-24 */
+      int i = c->sp_index[k];
+      double lo = c->o_low[i], hi = c->o_high[i];
+      double x_normalized = (o->obs[i] - lo) / (hi - lo);
+      double setpoint_normalized = (c->sp[(size_t)k * c->N + ti] - lo) / (hi - lo);
+      cost += ((x_normalized - setpoint_normalized) * (x_normalized - setpoint_normalized)) * c->r_scale[k];
+    }
+    for (int j = 0; j < c->na; ++j) { /* :25-34 */
+      double up = e->u_prev[j];
+      if (up != up) up = uk[j]; /* :7-8 first call: self.u_prev = u */
+      double u_normalized = (uk[j] - c->a_low[j]) / (c->a_high[j] - c->a_low[j]);
+      double u_prev_norm = (up - c->a_low[j]) / (c->a_high[j] - c->a_low[j]);
+      e->u_prev[j] = uk[j];
+      cost += c->rew_R_du * ((u_normalized - u_prev_norm) * (u_normalized - u_prev_norm));
+      cost += c->rew_R_u * (u_normalized * u_normalized);
+    }
+    if (violated) /* constraint_showcase/custom_reward.py:40-62 */
+      for (int q = 0; q < c->rew_nbox; ++q) {
+        int i = c->rew_box_index[q];
+        double lo = c->o_low[i], hi = c->o_high[i];
+        double x_normalized = (o->obs[i] - lo) / (hi - lo);
+        double lower_normalized = (c->rew_box_lo[q] - lo) / (hi - lo);
+        double upper_normalized = (c->rew_box_hi[q] - lo) / (hi - lo);
+        if (x_normalized > upper_normalized) cost += (x_normalized - upper_normalized) * (x_normalized - upper_normalized);
+        else if (x_normalized < lower_normalized) cost += (lower_normalized - x_normalized) * (lower_normalized - x_normalized);
+      }
+    r = -cost;
+  }
   o->rew = r;
   /* normalise :483-489 */
   if (c->flags & PCG_F_NORMALISE_O)
@@ -770,6 +805,7 @@ ORC_EXPORT int orc_integrate(const pcg_env_cfg* c, int64_t B, double* x, const d
  * state vector between calls (written by orc_reset / orc_step). */
 ORC_EXPORT int orc_step(const pcg_env_cfg* c, const pcg_buffers* io, double* slots, int32_t t_scalar,
                         uint64_t seed, int64_t env_offset, int n_threads) {
+  if ((c->flags & PCG_F_REWARD_TRACK) && !io->u_prev) return PCG_E_NULL;
   int nx = c->nx, na = c->na, nsp = c->nsp_obs, nd = c->nd, nobs = cfg_nobs(c), ncon = c->ncon;
   int64_t B = io->B;
   (void)n_threads;
@@ -793,7 +829,10 @@ ORC_EXPORT int orc_step(const pcg_env_cfg* c, const pcg_buffers* io, double* slo
       for (int i = 0; i < na; ++i) asave[i] = io->a_save[(size_t)i * B + b];
     if (io->d)
       for (int i = 0; i < nd; ++i) denv[i] = io->d[(size_t)i * B + b];
-    orc_env e = {state, asave, io->t ? io->t[b] : t_scalar};
+    double uprev[PCG_MAX_NA];
+    if (io->u_prev)
+      for (int i = 0; i < na; ++i) uprev[i] = io->u_prev[(size_t)i * B + b];
+    orc_env e = {state, asave, io->t ? io->t[b] : t_scalar, uprev};
     orc_out o;
     o.obs = obs;
     o.g = g;
@@ -805,6 +844,8 @@ ORC_EXPORT int orc_step(const pcg_env_cfg* c, const pcg_buffers* io, double* slo
       for (int i = 0; i < nsp + nd + c->nunc; ++i) slots[(size_t)i * B + b] = state[nx + i];
     if (io->a_save)
       for (int i = 0; i < na; ++i) io->a_save[(size_t)i * B + b] = asave[i];
+    if (io->u_prev)
+      for (int i = 0; i < na; ++i) io->u_prev[(size_t)i * B + b] = uprev[i];
     if (io->t) io->t[b] = e.t;
     for (int i = 0; i < nobs; ++i) io->obs[(size_t)i * B + b] = obs[i];
     io->rew[b] = o.rew;
@@ -826,7 +867,7 @@ ORC_EXPORT int orc_reset(const pcg_env_cfg* c, const pcg_buffers* io, double* sl
   for (int64_t b = 0; b < B; ++b) {
     if (mask && !mask[b]) continue;
     double state[PCG_MAX_NOBS], asave[PCG_MAX_NA], obs[PCG_MAX_NOBS];
-    orc_env e = {state, asave, 0};
+    orc_env e = {state, asave, 0, NULL};
     env_reset(c, &e, seed, (uint64_t)(env_offset + b), obs);
     for (int i = 0; i < nx; ++i) io->x[(size_t)i * B + b] = state[i];
     if (slots)

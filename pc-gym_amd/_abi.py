@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PCG_ABI_VERSION = 2
+PCG_ABI_VERSION = 3
 PCG_MAX_NX = 24
 PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
@@ -48,6 +48,8 @@ PCG_F_REF_COMPAT = 0x0100
 PCG_F_GAUSS_DIST = 0x0200
 PCG_F_X0_NORMAL = 0x0400
 PCG_F_UNC_EMPIRICAL = 0x0800
+PCG_F_REWARD_TRACK = 0x1000
+PCG_MAX_RBOX = 4
 PCG_MAX_EMP = 65536
 
 _pd = C.POINTER(C.c_double)
@@ -104,6 +106,12 @@ class pcg_env_cfg(C.Structure):
         ("unc_pct", _pd),
         ("unc_emp", _pd),
         ("unc_emp_off", _pi),
+        ("rew_R_du", C.c_double),
+        ("rew_R_u", C.c_double),
+        ("rew_nbox", C.c_int32),
+        ("rew_box_index", _pi),
+        ("rew_box_lo", _pd),
+        ("rew_box_hi", _pd),
     ]
 
 
@@ -122,6 +130,7 @@ class pcg_buffers(C.Structure):
         ("g", C.c_void_p),
         ("g_pre", C.c_void_p),
         ("nsteps", C.c_void_p),
+        ("u_prev", C.c_void_p),
         ("p_unc", C.c_void_p),
     ]
 

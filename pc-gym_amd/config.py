@@ -128,6 +128,21 @@ class EnvSpec:
         # --- reward kind, pcgym.py:94-103 --------------------------------------
         self.SP = p.get("SP")
         self.custom_reward = p.get("custom_reward")
+        # A dict in place of the callable selects the in-kernel form of the custom_reward family every paper
+        # script uses (pc-gym_paper/train_policies/*/custom_reward.py, constraint_showcase/custom_reward.py):
+        #   {"kind": "sp_track", "R": 0.1, "R_u": 0.0, "box": {"T": [lower_bound, upper_bound]}}
+        self.reward_track = None
+        if isinstance(self.custom_reward, dict):
+            rt = dict(self.custom_reward)
+            if rt.pop("kind", "sp_track") != "sp_track":
+                raise ValueError("declarative custom_reward: only kind 'sp_track' is built")
+            self.reward_track = {"R": float(rt.pop("R", 0.1)), "R_u": float(rt.pop("R_u", 0.0)),
+                                 "box": dict(rt.pop("box", {}) or {})}
+            if rt:
+                raise ValueError(f"declarative custom_reward: unknown keys {sorted(rt)}")
+            if self.SP is None:
+                raise ValueError("declarative custom_reward 'sp_track' needs set-points (SP)")
+            self.custom_reward = None
         self.reward_batch = self.SP is None
         if self.reward_batch and self.custom_reward is None:
             self.reward_states = list(p["reward_states"])
@@ -387,6 +402,26 @@ class EnvSpec:
                     self.con_A = np.ascontiguousarray(np.concatenate(
                         [A[:, :nst], np.zeros((A.shape[0], self.nunc)), A[:, nst:]], axis=1))
 
+        # --- declarative tracking reward: state boxes of the violation term ---------------------
+        self.rew_box_index = np.zeros(0, dtype=np.int32)
+        self.rew_box_lo = np.zeros(0)
+        self.rew_box_hi = np.zeros(0)
+        if self.reward_track is not None:
+            if self.nd:
+                raise ValueError("declarative custom_reward with disturbances is not supported (the reference's "
+                                 "callables broadcast uk[Nu+Nd] against a_space[Nu])")
+            box = self.reward_track["box"]
+            if len(box) > abi.PCG_MAX_RBOX:
+                raise ValueError(f"at most {abi.PCG_MAX_RBOX} boxed states are supported")
+            for k in box:
+                if k not in info["states"]:
+                    raise ValueError(f"custom_reward box: '{k}' is not a state of model '{self.model.name}'")
+            self.rew_box_index = np.array([info["states"].index(k) for k in box], dtype=np.int32)
+            # [lower_bound, upper_bound] in the order the reference's con_reward unpacks them
+            # (constraint_showcase/custom_reward.py:45) -- not sorted: its own {'T': [327, 321]} stays as written
+            self.rew_box_lo = np.array([float(box[k][0]) for k in box], dtype=_f64)
+            self.rew_box_hi = np.array([float(box[k][1]) for k in box], dtype=_f64)
+
         # --- integrator selection (new keys) -------------------------------------------
         d_int = DEFAULT_INTEGRATOR[self.model.model_id]
         if self.integration_method == "jax":
@@ -464,6 +499,7 @@ class EnvSpec:
         f |= abi.PCG_F_DONE_ON_CONS if self.done_on_constraint else 0
         f |= abi.PCG_F_NOISE if self.noise else 0
         f |= abi.PCG_F_REWARD_BATCH if self.reward_batch else 0
+        f |= abi.PCG_F_REWARD_TRACK if self.reward_track is not None else 0
         f |= abi.PCG_F_MAXIMISE if self.maximise_reward else 0
         f |= abi.PCG_F_REF_COMPAT if self.reference_compat else 0
         f |= abi.PCG_F_GAUSS_DIST if self.gauss else 0
@@ -533,4 +569,9 @@ class EnvSpec:
         cfg.unc_pct = pd(self.unc_pct)
         cfg.unc_emp = pd(self.unc_emp)
         cfg.unc_emp_off = pi(self.unc_emp_off)
+        if self.reward_track is not None:
+            cfg.rew_R_du, cfg.rew_R_u = self.reward_track["R"], self.reward_track["R_u"]
+            cfg.rew_nbox = len(self.rew_box_index)
+            cfg.rew_box_index = pi(self.rew_box_index)
+            cfg.rew_box_lo, cfg.rew_box_hi = pd(self.rew_box_lo), pd(self.rew_box_hi)
         return cfg, keep

@@ -266,6 +266,41 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   }
   const int nrs = (c->flags & PCG_F_REWARD_BATCH) ? nrew : nsp;
   for (int i = 0; i < nrs; ++i) d->r_scale[i] = c->r_scale[i];
+  if (c->flags & PCG_F_REWARD_TRACK) {
+    // normalisation of the tracking reward is always by o_space / a_space (custom_reward.py:14-31), whether or
+    // not the env normalises its observations / actions
+    if ((c->flags & PCG_F_REWARD_BATCH) || nsp == 0) return PCG_E_UNSUPPORTED;
+    if (c->rew_nbox < 0 || c->rew_nbox > PCG_MAX_RBOX) return PCG_E_DIM;
+    if (c->rew_nbox > 0 && (!c->rew_box_index || !c->rew_box_lo || !c->rew_box_hi)) return PCG_E_NULL;
+    if (nd > 0) return PCG_E_UNSUPPORTED;  // the reference broadcasts uk (Nu + Nd) against a_space (Nu) there
+    for (int k = 0; k < nsp; ++k) {
+      const int i = c->sp_index[k];
+      const double w = c->o_high[i] - c->o_low[i];
+      if (!(w != 0.0)) return PCG_E_VALUE;
+      d->trk_lo[k] = c->o_low[i];
+      d->trk_inv[k] = 1.0 / w;
+    }
+    for (int j = 0; j < na; ++j) {
+      const double w = c->a_high[j] - c->a_low[j];
+      if (!(w != 0.0)) return PCG_E_VALUE;
+      d->act_lo[j] = c->a_low[j];
+      d->act_inv[j] = 1.0 / w;
+    }
+    d->R_du = c->rew_R_du;
+    d->R_u = c->rew_R_u;
+    d->nbox = c->rew_nbox;
+    for (int q = 0; q < c->rew_nbox; ++q) {
+      const int i = c->rew_box_index[q];
+      if (i < 0 || i >= nx) return PCG_E_DIM;
+      const double w = c->o_high[i] - c->o_low[i];
+      if (!(w != 0.0)) return PCG_E_VALUE;
+      d->box_index[q] = i;
+      d->box_lo[q] = c->o_low[i];
+      d->box_inv[q] = 1.0 / w;
+      d->box_lon[q] = (c->rew_box_lo[q] - c->o_low[i]) / w;
+      d->box_hin[q] = (c->rew_box_hi[q] - c->o_low[i]) / w;
+    }
+  }
   if (c->flags & PCG_F_NOISE)
     for (int i = 0; i < nx; ++i) d->noise_pct[i] = c->noise_pct[i];
   for (int i = 0; i < nx + nso; ++i) d->x0[i] = c->x0[i];
@@ -432,6 +467,7 @@ int64_t pcg_plan_bytes_per_env_step(const pcg_plan* p, const pcg_buffers* io) {
   if (io->g) A += 8 * c.ncon;
   if (io->t) A += 8;
   if ((c.flags & PCG_F_A_DELTA) && io->a_save) A += 16 * c.na;
+  if ((c.flags & PCG_F_REWARD_TRACK) && io->u_prev) A += 16 * c.na;
   if (io->nsteps) A += 8;
   A += 16 * c.nunc;  // per-env parameters read + their observation slots written
   return A;
@@ -447,6 +483,7 @@ static int fill_args(const pcg_plan* p, const pcg_buffers* io, StepArgs* a) {
   a->rew = io->rew; a->done = io->done; a->viol = io->viol; a->g = io->g; a->g_pre = io->g_pre;
   a->nsteps = io->nsteps; a->B = io->B; a->env_offset = p->env_offset;
   a->p_unc = io->p_unc;
+  a->u_prev = io->u_prev;
   return PCG_OK;
 }
 
@@ -497,6 +534,7 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   if (!io->x || !io->a || !io->obs || !io->rew || !io->done) return PCG_E_NULL;
   const DevConst& c = p->hc;
   if ((c.flags & PCG_F_A_DELTA) && !io->a_save) return PCG_E_NULL;
+  if ((c.flags & PCG_F_REWARD_TRACK) && !io->u_prev) return PCG_E_NULL;
   a.t_scalar = t;
   a.seed = seed;
   const bool per_env_t = io->t != nullptr;
@@ -529,7 +567,7 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   }
   // lean variant when no noise / Gaussian disturbance / constraint work is configured
   // (the lean kernels also compile out a_delta, the terminal "batch" reward and per-env disturbances)
-  const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH)) ||
+  const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH | PCG_F_REWARD_TRACK)) ||
                       c.ncon > 0 || io->d != nullptr;
   // streaming (persistent, prefetching, 16 B/lane) kernel for the lean lock-stepped path
   // Adaptive stepping is left to the one-wave-per-workgroup classic kernel unless a streaming variant is forced:
@@ -583,6 +621,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   if (!io->x || !a_seq || !io->obs || !io->rew || !io->done) return PCG_E_NULL;
   const DevConst& c = p->hc;
   if ((c.flags & PCG_F_A_DELTA) && !io->a_save) return PCG_E_NULL;
+  if ((c.flags & PCG_F_REWARD_TRACK) && !io->u_prev) return PCG_E_NULL;
   if (c.nunc > 0) return PCG_E_UNSUPPORTED;  // parameter uncertainty: per-step kernel only
   a.t_scalar = t0;
   a.seed = seed;
@@ -596,7 +635,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   if (a.a_cs < io->B || (obs_seq && a.o_cs < io->B)) return PCG_E_DIM;
   const Kernels& k = kernels(p->model_id);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
-  const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH)) ||
+  const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH | PCG_F_REWARD_TRACK)) ||
                       c.ncon > 0 || io->d != nullptr;
   if (!extras && p->integrator_id == PCG_INT_RK4 && !io->viol && p->variant != 1 && k.roll_lean[0]) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };

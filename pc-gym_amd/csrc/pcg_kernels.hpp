@@ -94,6 +94,13 @@ struct DevConst {
   double unc_pct[PCG_MAX_NUNC];
   int32_t unc_index[PCG_MAX_NUNC];
   int32_t emp_off[PCG_MAX_NUNC + 1];  // PCG_F_UNC_EMPIRICAL: sample tables live behind the schedules in `sched`
+  // PCG_F_REWARD_TRACK: normalised tracking + action-increment reward (pc-gym_paper custom_reward family)
+  double trk_lo[PCG_MAX_NSP], trk_inv[PCG_MAX_NSP];  // o_space low and 1/(high-low) of each SP state
+  double act_lo[PCG_MAX_NA], act_inv[PCG_MAX_NA];    // a_space low and 1/(high-low)
+  double R_du, R_u;
+  int32_t nbox, box_index[PCG_MAX_RBOX];
+  double box_lo[PCG_MAX_RBOX], box_inv[PCG_MAX_RBOX];    // o_space low and 1/(high-low) of each boxed state
+  double box_lon[PCG_MAX_RBOX], box_hin[PCG_MAX_RBOX];   // box bounds, normalised
 };
 
 using CDevConst = const PCG_CONSTANT DevConst;
@@ -114,6 +121,7 @@ struct StepArgs {
   double* g_pre;
   int32_t* nsteps;
   double* p_unc;        // [nunc][B] per-env uncertain parameters
+  double* u_prev;       // [na][B] previous physical action (PCG_F_REWARD_TRACK)
   const uint8_t* mask;  // reset only
   int64_t B;
   int64_t env_offset;
@@ -399,13 +407,47 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
       if (i + 1 < NX) zn[i + 1] = z1;
     }
   }
+  double on[NX];  // physical observation of the states, noise included (what custom_reward receives, pcgym.py:470-471)
 #pragma unroll
-  for (int i = 0; i < NX; ++i)
+  for (int i = 0; i < NX; ++i) {
+    on[i] = 0.0;
     if (i < nx) {
       double o = x[i];
       if (EXTRAS && (flags & PCG_F_NOISE)) o += zn[i] * x[i] * c.noise_pct[i];
+      on[i] = o;
       out.ox[i] = (o - c.omap[i].lo) * c.omap[i].sc + c.omap[i].off;
     }
+  }
+  if (EXTRAS && (flags & PCG_F_REWARD_TRACK)) {
+    // declarative form of the paper's custom_reward family (custom_reward.py:3-39; constraint_showcase/
+    // custom_reward.py:6-69): normalised squared tracking error at SP[t_new], squared normalised action increment
+    // (and level), squared normalised box excess while a constraint row is violated
+    double cost = 0.0;
+#pragma unroll
+    for (int k = 0; k < PCG_MAX_NSP; ++k)
+      if (k < nsp) {
+        const double xn = (pick<NX>(on, c.sp_index[k]) - c.trk_lo[k]) * c.trk_inv[k];
+        const double sn = (spn[k] - c.trk_lo[k]) * c.trk_inv[k];
+        cost += ((xn - sn) * (xn - sn)) * c.r_scale[k];
+      }
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      if (j < na) {
+        const double up0 = A.u_prev[(size_t)j * B + e];
+        const double up = (up0 == up0) ? up0 : u[j];  // NaN: no previous action yet (hasattr branch, :7-8)
+        const double un = (u[j] - c.act_lo[j]) * c.act_inv[j];
+        const double upn = (up - c.act_lo[j]) * c.act_inv[j];
+        cost += c.R_du * ((un - upn) * (un - upn)) + c.R_u * (un * un);
+        A.u_prev[(size_t)j * B + e] = u[j];
+      }
+    if (violated)
+      for (int q = 0; q < c.nbox; ++q) {
+        const double xn = (pick<NX>(on, c.box_index[q]) - c.box_lo[q]) * c.box_inv[q];
+        if (xn > c.box_hin[q]) cost += (xn - c.box_hin[q]) * (xn - c.box_hin[q]);
+        else if (xn < c.box_lon[q]) cost += (c.box_lon[q] - xn) * (c.box_lon[q] - xn);
+      }
+    out.rew = -cost;
+  }
 #pragma unroll
   for (int k = 0; k < PCG_MAX_NSP; ++k)
     if (k < nso) out.osp[k] = (spv[k] - c.omap[nx + k].lo) * c.omap[nx + k].sc + c.omap[nx + k].off;

@@ -121,6 +121,9 @@ class VecEnv:
         self.nsteps = (torch.zeros((2, B), dtype=torch.int32, device=dev)
                        if s.integrator == "dopri5" else None)
         self.p_unc = torch.zeros((s.nunc, B), dtype=f64, device=dev) if s.nunc else None  # per-env parameters
+        # previous physical action of the declarative tracking reward; NaN = none yet (custom_reward.py:7-8)
+        self.u_prev = (torch.full((s.na, B), float("nan"), dtype=f64, device=dev)
+                       if s.reward_track is not None else None)
         b = self._buf = abi.pcg_buffers()
         b.B = B
         b.x = self.x.data_ptr()
@@ -134,6 +137,7 @@ class VecEnv:
         b.t = self.t_env.data_ptr() if self.t_env is not None else None
         b.nsteps = self.nsteps.data_ptr() if self.nsteps is not None else None
         b.p_unc = self.p_unc.data_ptr() if self.p_unc is not None else None
+        b.u_prev = self.u_prev.data_ptr() if self.u_prev is not None else None
         self._bufp = C.byref(b)
         self._a_hold = None
         self._d_hold = None
@@ -273,6 +277,8 @@ class VecEnv:
             d["a_save"] = self.a_save_t.clone()
         if self.t_env is not None:
             d["t_env"] = self.t_env.clone()
+        if self.u_prev is not None:
+            d["u_prev"] = self.u_prev.clone()
         return d
 
     def load_state_dict(self, d):
@@ -282,6 +288,8 @@ class VecEnv:
             self.a_save_t.copy_(d["a_save"])
         if self.t_env is not None:
             self.t_env.copy_(d["t_env"])
+        if self.u_prev is not None:
+            self.u_prev.copy_(d["u_prev"])
 
 
 class StepGraph:

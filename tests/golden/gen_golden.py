@@ -276,6 +276,16 @@ def gen_steps(P, out, only_new=False):
         if only_new and os.path.exists(os.path.join(out, f"step_{name}.npz")):
             continue
         p = sc["env_params"]
+        if sc.get("ref_custom_reward"):  # the reference side runs its own callable (loaded from the reference tree)
+            import copy
+            import importlib.util
+
+            rel, fname = sc["ref_custom_reward"]
+            spec = importlib.util.spec_from_file_location("ref_custom_reward_" + name, os.path.join(REF, rel))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            p = copy.deepcopy(p)
+            p["custom_reward"] = getattr(mod, fname)
         A = SC.actions_for(name, sc)
         np.random.seed(12345)  # only matters for action_space.sample() in _setup_constraints
         env = P.make_env(p)

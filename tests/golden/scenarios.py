@@ -297,6 +297,27 @@ def scenarios():
         "x0": np.array([340.0, 320.0, 300.0] * 8 + [330.0]), "r_scale": {"Tt8": 1e-2}, "model": "heat_exchanger"},
         steps=29, action_seed=26)
 
+    # ---- the custom_reward family of the paper scripts, declarative on our side ------------------------
+    # (the reference run uses the callable named in ref_custom_reward, loaded by gen_golden.py from the
+    # reference tree; the fixture only holds the recorded tuples)
+    p = _cstr_base()
+    p.update(custom_reward={"kind": "sp_track", "R": 0.1})
+    S["cstr_paper_reward"] = dict(env_params=p, steps=59, action_seed=31,
+                                  ref_custom_reward=("pc-gym_paper/train_policies/cstr/custom_reward.py",
+                                                     "sp_track_reward"))
+    p = _four_tank_base()
+    p.update(custom_reward={"kind": "sp_track", "R": 0.1})
+    S["four_tank_paper_reward"] = dict(env_params=p, steps=59, action_seed=32,
+                                       ref_custom_reward=("pc-gym_paper/train_policies/cstr/custom_reward.py",
+                                                          "sp_track_reward"))
+    # constraint showcase: box term while a constraint row is violated; the bounds are given in the order the
+    # reference's con_reward unpacks them ("lower_bound, upper_bound = [327, 321]", custom_reward.py:4-5,45)
+    p = _cstr_base()
+    p.update(normalise_a=False, normalise_o=False, constraints=cons_cstr_T, done_on_cons_vio=False, r_penalty=False,
+             custom_reward={"kind": "sp_track", "R": 0.01, "box": {"T": [327, 321]}})
+    S["cstr_con_reward"] = dict(env_params=p, steps=59, action_seed=33, raw_actions=True,
+                                ref_custom_reward=("pc-gym_paper/constraint_showcase/custom_reward.py", "con_reward"))
+
     # the reference's own known-answer test (custom linear model)
     S["custom_linear_kat"] = dict(
         env_params={

@@ -247,6 +247,9 @@ BATCH_CASES = [
     ("cryst_adelta", {}, 1e-10),
     ("me_reactive", dict(integrator="rk4", substeps=32), 1e-11),
     ("cstr_batch_reward", {}, 1e-12),
+    ("cstr_paper_reward", {}, 1e-12),
+    ("four_tank_paper_reward", {}, 1e-12),
+    ("cstr_con_reward", {}, 1e-12),
     ("cstr_partial_obs", {}, 1e-12),
 ]
 
@@ -398,7 +401,7 @@ def test_rollout_equals_stepping():
 
     from pcgym_amd import VecEnv
 
-    for name in ("cstr_canonical", "four_tank_canonical"):
+    for name in ("cstr_canonical", "four_tank_canonical", "cstr_paper_reward"):
         sc = SC.scenarios()[name]
         B, T = 1000, 20
         e1 = VecEnv(copy.deepcopy(sc["env_params"]), n_envs=B)
@@ -581,6 +584,35 @@ def test_sixteen_million_envs_tail_window_vs_oracle():
         assert np.allclose(rg[B - W:].cpu().numpy(), rc, rtol=1e-10, atol=1e-12)
     assert bool(torch.isfinite(env.x).all()) and bool(torch.isfinite(env.rew).all())
     assert float(env.x[0].min()) > 0.0 and not bool(env.done.any())
+    env.close()
+
+
+def test_tracking_reward_u_prev_survives_reset_like_the_reference():
+    """custom_reward.py:7-8,33: u_prev is set on the first call and never cleared -- the first step of the SECOND
+    episode is charged the increment from the last action of the first one."""
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    p = copy.deepcopy(SC.scenarios()["cstr_paper_reward"]["env_params"])
+    B = 257
+    env = VecEnv(p, n_envs=B, seed=2)
+    orc = O.OracleEnv(env.spec, B, seed=2)
+    assert bool(torch.isnan(env.u_prev).all())
+    acts = _rand_actions(env.spec, 4, B, 8)
+    for ep in range(2):
+        env.reset()
+        orc.reset()
+        for i in range(2):
+            o, r, d, _, _ = env.step(torch.tensor(acts[2 * ep + i], device=env.device))
+            oc, rc, dc = orc.step(acts[2 * ep + i])
+            assert np.allclose(r.cpu().numpy(), rc, rtol=1e-12, atol=1e-12), (ep, i)
+            assert np.allclose(env.u_prev.cpu().numpy(), orc.u_prev, rtol=1e-15, atol=0)
+        if ep == 0:
+            env.reset()
+            assert not bool(torch.isnan(env.u_prev).any())  # reset leaves u_prev alone
     env.close()
 
 
