@@ -155,14 +155,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
                          f"(WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PCG_BENCH_BACKEND=gloo is a test switch: it lets the N-rank code path run on a box with fewer GPUs than
+    # ranks (ranks share devices); the driver's runs use the default, RCCL with one rank per GPU.
+    backend = os.environ.get("PCG_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     B, K, W = args.batch, args.steps, args.warmup
     params = workload_params(B)

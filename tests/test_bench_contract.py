@@ -1,0 +1,47 @@
+"""GPU: bench.py prints ONE JSON line with the contract's keys, single-rank and through the N-rank launch path
+(two ranks sharing this box's GPU over gloo -- the RCCL run with one rank per GPU is the driver's)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_rank_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "70", "--warmup", "11",
+                        "--preheat-ms", "20"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert KEYS <= set(d) and "cpu_baseline" in d
+    assert d["n_gpus"] == 1 and d["steps"] == 70 and d["warmup"] == 11 and d["unit"] == "env-steps/s"
+    assert d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["config"]["finite"]
+    rf, cb = d["roofline"], d["cpu_baseline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
+    assert abs(d["value"] - d["config"]["global_envs"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert cb["kind"] == "port" and cb["unit"] == "env-steps/s" and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_two_rank_launch_path():
+    env = dict(os.environ, PCG_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "70", "--warmup", "11", "--preheat-ms", "20"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert KEYS <= set(d) and "cpu_baseline" not in d  # the CPU leg runs at N = 1 only
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"]
+    assert abs(d["value"] - d["config"]["global_envs"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
