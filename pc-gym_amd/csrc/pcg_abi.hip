@@ -71,14 +71,14 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs A) {
 Kernels kernels_cstr(), kernels_four_tank(), kernels_me(), kernels_me_reactive(), kernels_cryst(), kernels_affine();
 Kernels kernels_complex_cstr(), kernels_disease(), kernels_batch(), kernels_photo(), kernels_cstr_series();
 Kernels kernels_distillation(), kernels_polymer(), kernels_biofilm(), kernels_heat_ex(), kernels_inv_batch();
-Kernels kernels_oscillators();
+Kernels kernels_oscillators(), kernels_me_sq(), kernels_me_reactive_sq();
 
 static const Kernels& kernels(int id) {
-  static const Kernels K[PCG_MODEL_COUNT] = {
+  static const Kernels K[PCG_KID_COUNT] = {
       kernels_cstr(),        kernels_four_tank(),   kernels_me(),      kernels_me_reactive(), kernels_cryst(),
       kernels_affine(),      kernels_complex_cstr(), kernels_disease(), kernels_batch(),       kernels_photo(),
       kernels_cstr_series(), kernels_distillation(), kernels_polymer(), kernels_biofilm(),     kernels_heat_ex(),
-      kernels_inv_batch(),   kernels_oscillators()};
+      kernels_inv_batch(),   kernels_oscillators(),  kernels_me_sq(),   kernels_me_reactive_sq()};
   return K[id];
 }
 
@@ -115,6 +115,7 @@ struct pcg_plan {
   uint32_t magic;
   int device;
   int model_id, integrator_id;
+  int kid;           // kernel-table id: model_id, or the *_SQ specialisation of the extraction models
   int lds_stages;
   int variant;       // PCG_OPT_VARIANT: 0 auto, 1 classic, 2 stream EPL=1, 3 stream EPL=2
   int stream_bpc;    // PCG_OPT_STREAM_BLOCKS_PER_CU: 0 = occupancy query
@@ -373,6 +374,18 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   return PCG_OK;
 }
 
+// eq_exponent == 2 (the reference default) selects the multiply-only instantiation of the extraction models;
+// not when the exponent itself is one of the per-env uncertain parameters.
+static int kernel_id_for(const pcg_env_cfg* c) {
+  int epos = -1, kid = c->model_id;
+  if (c->model_id == PCG_MODEL_ME) { epos = 4; kid = PCG_KID_ME_SQ; }
+  if (c->model_id == PCG_MODEL_ME_REACTIVE) { epos = 5; kid = PCG_KID_ME_REACTIVE_SQ; }
+  if (epos < 0 || c->params[epos] != 2.0) return c->model_id;
+  for (int j = 0; j < c->nunc; ++j)
+    if (c->unc_index[j] == epos) return c->model_id;
+  return kid;
+}
+
 int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   if (!out || !cfg) return PCG_E_NULL;
   *out = nullptr;
@@ -385,6 +398,7 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   }
   p->magic = PLAN_MAGIC;
   p->model_id = cfg->model_id;
+  p->kid = kernel_id_for(cfg);
   p->integrator_id = cfg->integrator_id;
   p->lds_stages = 0;
   p->variant = 0;
@@ -510,7 +524,7 @@ static int resident_blocks(StepFn fn) {
 // Fill every lazily queried occupancy of the plan's candidate persistent kernels (done before a stream
 // capture so that no query runs while capturing).
 static int warm_occupancy(pcg_plan* p) {
-  const Kernels& k = kernels(p->model_id);
+  const Kernels& k = kernels(p->kid);
   for (int e = 0; e < 2; ++e) {
     if (p->integrator_id == PCG_INT_RK4 && k.pipe[e] && p->pipe_occ[e] == 0) {
       const int q = resident_blocks(k.pipe[e]);
@@ -538,7 +552,7 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   a.t_scalar = t;
   a.seed = seed;
   const bool per_env_t = io->t != nullptr;
-  const Kernels& k = kernels(p->model_id);
+  const Kernels& k = kernels(p->kid);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
   const int block = tb(lds_st, p->integrator_id);
   size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
@@ -633,7 +647,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   a.o_ss = obs_step_stride; a.o_cs = obs_comp_stride;
   a.r_ss = rew_step_stride;
   if (a.a_cs < io->B || (obs_seq && a.o_cs < io->B)) return PCG_E_DIM;
-  const Kernels& k = kernels(p->model_id);
+  const Kernels& k = kernels(p->kid);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
   const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH | PCG_F_REWARD_TRACK)) ||
                       c.ncon > 0 || io->d != nullptr;
@@ -791,7 +805,7 @@ int pcg_rhs(pcg_plan* p, int64_t B, const double* x, const double* u, double* dx
   if (!plan_ok(p)) return PCG_E_PLAN;
   if (!x || !u || !dx) return PCG_E_NULL;
   if (B <= 0) return B == 0 ? PCG_OK : PCG_E_DIM;
-  const Kernels& k = kernels(p->model_id);
+  const Kernels& k = kernels(p->kid);
   hipLaunchKernelGGL(k.rhs, dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, (CDevConst*)p->dC, B, p->cfg_nu, x, u, dx);
   return (int)hipGetLastError();
 }
@@ -800,7 +814,7 @@ int pcg_integrate(pcg_plan* p, int64_t B, double* x, const double* u, int32_t* n
   if (!plan_ok(p)) return PCG_E_PLAN;
   if (!x || !u) return PCG_E_NULL;
   if (B <= 0) return B == 0 ? PCG_OK : PCG_E_DIM;
-  const Kernels& k = kernels(p->model_id);
+  const Kernels& k = kernels(p->kid);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
   const int block = tb(lds_st, p->integrator_id);
   const size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;

@@ -131,25 +131,31 @@ struct Model<PCG_MODEL_FOUR_TANK> {
   }
 };
 
-// Y^e/m for the extraction models: e == 2 (the reference default,
-// model_classes.py:365) is the hot case and is a multiply; any other exponent
-// goes through pow().  `sq` is wave-uniform.
-template <class R>
-PCG_DEV R eq_curve(const R& Y, double e, double inv_m, bool sq) {
-  return (sq ? Y * Y : pow(Y, e)) * inv_m;
+// Y^e/m for the extraction models: e == 2 (the reference default, model_classes.py:365) is the hot case
+// and is a multiply (bit-identical to pow(Y, 2.0)); any other exponent goes through pow().  The choice is a
+// COMPILE-TIME parameter: with a run-time branch the ~250-instruction pow sits between the five stages of
+// every RHS evaluation, splits them into separate basic blocks and inflates the DOPRI5 loop to 70 KB of code.
+// Plans with eq_exponent == 2 are routed to the *_SQ instantiations (internal ids below).
+template <bool SQ, class R>
+PCG_DEV R eq_curve(const R& Y, double e, double inv_m) {
+  if constexpr (SQ) return (Y * Y) * inv_m;
+  else return pow(Y, e) * inv_m;
 }
+// internal kernel-table ids behind the public enum pcg_model
+constexpr int PCG_KID_ME_SQ = PCG_MODEL_COUNT, PCG_KID_ME_REACTIVE_SQ = PCG_MODEL_COUNT + 1,
+              PCG_KID_COUNT = PCG_MODEL_COUNT + 2;
 
 // ---------------------------------------------------------------------------
 // multistage_extraction -- model_classes.py:346-430.  raw = Vl,Vg,m,Kla,eq_exponent,X0,Y6
 // u = [L, G | X0, Y6];  x = X1,Y1,...,X5,Y5
 // ---------------------------------------------------------------------------
-template <>
-struct Model<PCG_MODEL_ME> {
+template <bool SQ>
+struct MEImpl {
   static constexpr int NX = 10, NA = 2, NDM = 2, NRAW = 7;
   static constexpr bool DYNAMIC = false;
   static constexpr bool FULL = true;  // all kernel specialisations
   struct KP {
-    double iVl, iVg, inv_m, KlaVl, e, sq;
+    double iVl, iVg, inv_m, KlaVl, e;
   };
   using CKP = const PCG_CONSTANT KP;
   template <class R>
@@ -164,7 +170,6 @@ struct Model<PCG_MODEL_ME> {
     k.inv_m = 1 / r[2];
     k.KlaVl = r[3] * r[0];
     k.e = r[4];
-    k.sq = (r[4] == 2.0) ? 1.0 : 0.0;
     __builtin_memcpy(kp_out, &k, sizeof(k));
     ddef[0] = r[5];
     ddef[1] = r[6];
@@ -175,11 +180,10 @@ struct Model<PCG_MODEL_ME> {
   }
   template <class R, class K>
   PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
-    const bool sq = k.sq != 0.0;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       const R X = x[2 * s], Y = x[2 * s + 1];
-      const R Q = k.KlaVl * (X - eq_curve(Y, k.e, k.inv_m, sq));
+      const R Q = k.KlaVl * (X - eq_curve<SQ>(Y, k.e, k.inv_m));
       const R Xp = (s == 0) ? h.X0 : x[2 * s - 2];
       const R Yn = (s == 4) ? h.Y6 : x[2 * s + 3];
       dx[2 * s] = k.iVl * (h.L * (Xp - X) - Q);
@@ -187,18 +191,23 @@ struct Model<PCG_MODEL_ME> {
     }
   }
 };
+template <>
+struct Model<PCG_MODEL_ME> : MEImpl<false> {};
+template <>
+struct Model<PCG_KID_ME_SQ> : MEImpl<true> {};
+
 
 // ---------------------------------------------------------------------------
 // multistage_extraction_reactive -- model_classes.py:763-861.
 // raw = Vl,Vg,m,Kla,k,eq_exponent,XA0,YA6,YB6,YC6 ; x = (XA,YA,YB,YC) x 5
 // ---------------------------------------------------------------------------
-template <>
-struct Model<PCG_MODEL_ME_REACTIVE> {
+template <bool SQ>
+struct MEReactiveImpl {
   static constexpr int NX = 20, NA = 2, NDM = 0, NRAW = 10;
   static constexpr bool DYNAMIC = false;
   static constexpr bool FULL = true;  // all kernel specialisations
   struct KP {
-    double iVl, iVg, inv_m, KlaVl, kVg, e, sq, XA0, YA6, YB6, YC6;
+    double iVl, iVg, inv_m, KlaVl, kVg, e, XA0, YA6, YB6, YC6;
   };
   using CKP = const PCG_CONSTANT KP;
   template <class R>
@@ -214,7 +223,6 @@ struct Model<PCG_MODEL_ME_REACTIVE> {
     k.KlaVl = r[3] * r[0];
     k.kVg = r[4] * r[1];
     k.e = r[5];
-    k.sq = (r[5] == 2.0) ? 1.0 : 0.0;
     k.XA0 = r[6];
     k.YA6 = r[7];
     k.YB6 = r[8];
@@ -227,11 +235,10 @@ struct Model<PCG_MODEL_ME_REACTIVE> {
   }
   template <class R, class K>
   PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {
-    const bool sq = k.sq != 0.0;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       const R XA = x[4 * s], YA = x[4 * s + 1], YB = x[4 * s + 2], YC = x[4 * s + 3];
-      const R Q = k.KlaVl * (XA - eq_curve(YA, k.e, k.inv_m, sq));
+      const R Q = k.KlaVl * (XA - eq_curve<SQ>(YA, k.e, k.inv_m));
       const R rV = k.kVg * YA * YB;  // r * Vg
       const R XAp = (s == 0) ? R(k.XA0) : x[4 * s - 4];
       const R YAn = (s == 4) ? R(k.YA6) : x[4 * s + 5];
@@ -244,6 +251,11 @@ struct Model<PCG_MODEL_ME_REACTIVE> {
     }
   }
 };
+template <>
+struct Model<PCG_MODEL_ME_REACTIVE> : MEReactiveImpl<false> {};
+template <>
+struct Model<PCG_KID_ME_REACTIVE_SQ> : MEReactiveImpl<true> {};
+
 
 // ---------------------------------------------------------------------------
 // crystallization -- model_classes.py:1232-1345.

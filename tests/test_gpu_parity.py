@@ -100,6 +100,45 @@ def test_rhs_vs_reference_and_oracle(fix, model):
     assert np.max(np.abs(got - want_ref) / scale) <= 1e-12
 
 
+@pytest.mark.parametrize("model,fix", [("multistage_extraction", "multistage_extraction"),
+                                       ("multistage_extraction_reactive", "multistage_extraction_reactive")])
+@pytest.mark.parametrize("expo", [2.0, 1.5, 3.0])
+def test_extraction_equilibrium_exponent_paths(model, fix, expo):
+    """eq_exponent == 2 runs the multiply-only instantiation, anything else the pow() one (pcg_models.hpp):
+    both must agree with the oracle's pow() restatement (model_classes.py:386-395, 806-815)."""
+    torch = _torch()
+    from oracle import oracle as O
+    from test_oracle_golden import _spec_for_integration
+
+    g = H.gold("rhs_" + fix)
+    spec = _spec_for_integration(model, 1.0, g["u"].shape[1], integrator="rk4", substeps=16)
+    spec.model.parameters["eq_exponent"] = expo
+    lib, plan = _plan_for(spec, torch)
+    xs, us = g["x"].T.copy(), g["u"].T.copy()
+    us[0] = 5.0 + 0.1 * us[0]  # mild flows: the fixed-step integration below stays stable
+    us[1] = 10.0 + 0.1 * us[1]
+    x = torch.tensor(xs, device="cuda")
+    u = torch.tensor(us, device="cuda")
+    dx = torch.zeros_like(x)
+    assert lib.pcg_rhs(plan, x.shape[1], x.data_ptr(), u.data_ptr(), dx.data_ptr(), None) == 0
+    want = O.rhs(spec.model.model_id, spec.model.param_vector(), xs, us)
+    scale = np.maximum(np.abs(want), 1e-3 * np.max(np.abs(want), axis=1, keepdims=True))
+    assert np.max(np.abs(dx.cpu().numpy() - want) / scale) <= 1e-12
+    assert lib.pcg_integrate(plan, x.shape[1], x.data_ptr(), u.data_ptr(), None, None) == 0
+    torch.cuda.synchronize()
+    lib.pcg_plan_destroy(plan)
+    want_x, _ = O.integrate(spec, xs, us)
+    got_x = x.cpu().numpy()
+    # a fractional power of a state that dips below zero is NaN on both sides (numpy pow in the reference too)
+    fin = np.isfinite(want_x)
+    assert np.array_equal(np.isfinite(got_x), fin) and fin.all(axis=0).mean() > 0.7
+    assert np.max(np.abs(got_x[fin] - want_x[fin]) / np.maximum(np.abs(want_x[fin]), 1e-6)) <= 1e-11
+    if expo != 2.0:  # and the exponent matters
+        spec2 = _spec_for_integration(model, 1.0, g["u"].shape[1], integrator="rk4", substeps=16)
+        other, _ = O.integrate(spec2, xs, us)
+        assert np.max(np.abs(other[fin] - want_x[fin])) > 1e-4
+
+
 # ------------------------------------------------------------ integrate ------
 INT_CASES = [
     ("cstr", "cstr", dict(integrator="rk4", substeps=4), 1e-12),
