@@ -359,7 +359,9 @@ class EnvSpec:
                 raise ValueError("distribution must be 'uniform' or 'normal'")
             self.x0_normal = dist == "normal"
             if "x0" in up:
-                xu = _arr(up["x0"])
+                # the reference walks "for idx, uncertainty in enumerate(x0_uncertainty)" (pcgym.py:286-288): a
+                # sequence gives per-state fractions; a dict (tests/models/test_model.py:99) yields its KEYS
+                xu = _arr(list(up["x0"]))
                 self.x0_unc = np.zeros(self.nx)
                 n = min(self.nx, xu.shape[0])
                 self.x0_unc[:n] = xu[:n]

@@ -373,6 +373,7 @@ class make_env(VecEnv):
         self.state = s.x0_full().copy()
         self.obs_np = self.state.copy()
         self.a_save = s.a_0.copy() if s.a_delta else None
+        self.a_0 = s.a_0.copy() if s.a_delta else None  # read by callers (tests/environment/test_make_env_delta_u.py:24)
 
     # -- host-side mirrors needed only for the callable custom_reward path -------------
     def _host_uk(self, action):
@@ -406,6 +407,10 @@ class make_env(VecEnv):
         self._sync_state()
         if s.a_delta:
             self.a_save = s.a_0.copy()
+        if s.nunc:  # the reference setattr()s the sampled values onto its model object (pcgym.py:306-307, 314):
+            pu = self.p_unc[:, 0].cpu().numpy()  # callers read them back as env.model.<param>
+            for k, v in zip(s.unc_keys, pu):
+                self.model.parameters[k] = float(v)
         o = obs[0].cpu().numpy().copy()
         self.obs_np = self.state.copy()
         self.info["obs"] = o.copy()

@@ -48,7 +48,7 @@ class ModelInfo:
         raise AttributeError(k)
 
     def copy(self):
-        return ModelInfo(self.name, self.model_id, self.states, self.inputs, self.disturbances,
+        return type(self)(self.name, self.model_id, self.states, self.inputs, self.disturbances,
                          self.parameters, self.affine_builder)
 
 
@@ -167,9 +167,23 @@ _REGISTRY = _registry()
 NOT_BUILT = []
 
 
+# class names of the reference's model objects (pcgym.py:128-148): callers inspect env.model.__class__.__name__
+# (tests/environment/test_make_env_basic.py:26)
+_CLASS_NAME = {"photobioreactor": "photo_production", "disease": "disease_model",
+               "coupled_oscillator": "coupled_oscillators"}
+_CLASS_CACHE = {}
+
+
+def _named(mi: ModelInfo) -> ModelInfo:
+    cname = _CLASS_NAME.get(mi.name, mi.name)
+    cls = _CLASS_CACHE.setdefault(cname, type(cname, (ModelInfo,), {}))
+    mi.__class__ = cls
+    return mi
+
+
 def get_model(name: str) -> ModelInfo:
     if name in _REGISTRY:
-        return _REGISTRY[name].copy()
+        return _named(_REGISTRY[name].copy())
     if name in NOT_BUILT:  # pragma: no cover - empty since every registry model has a kernel
         raise ValueError(
             f"Model '{name}' exists in pc-gym but has no HIP kernel in this build "
