@@ -126,6 +126,9 @@ enum pcg_integrator {
                                        + sum_j [ R_du (du_j / (a_hi_j - a_lo_j))^2 + R_u ((u_j - a_lo_j) / (a_hi_j - a_lo_j))^2 ]
                                        + [violated] sum_c box_c^2 )  on the (noisy) physical observation o and the
                                        physical action u, with the previous action kept per env in u_prev         */
+#define PCG_F_REWARD_CRYST 0x2000u  /* with PCG_F_REWARD_TRACK on the crystallisation model: the tracked CV and Ln are
+                                       recomputed from the observed moments, CV = sqrt(mu2 mu0 / mu1^2 - 1), Ln = mu1/mu0
+                                       (pc-gym_paper/train_policies/crystalisation/cryst_train.py:17-48)                 */
 #define PCG_MAX_RBOX 4              /* state boxes of the constraint-violation term                               */
 
 /*

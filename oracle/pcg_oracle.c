@@ -695,7 +695,12 @@ static void env_step(const pcg_env_cfg* c, orc_env* e, const double* action_in, 
     for (int k = 0; k < nsp; ++k) { /* :10-24 */
       int i = c->sp_index[k];
       double lo = c->o_low[i], hi = c->o_high[i];
-      double x_normalized = (o->obs[i] - lo) / (hi - lo);
+      double xv = o->obs[i];
+      if ((c->flags & PCG_F_REWARD_CRYST) && i == 5) /* crystalisation/cryst_train.py:24 */
+        xv = pow(o->obs[2] * o->obs[0] / (o->obs[1] * o->obs[1]) - 1, 0.5);
+      if ((c->flags & PCG_F_REWARD_CRYST) && i == 6) /* :25 */
+        xv = o->obs[1] / o->obs[0];
+      double x_normalized = (xv - lo) / (hi - lo);
       double setpoint_normalized = (c->sp[(size_t)k * c->N + ti] - lo) / (hi - lo);
       cost += ((x_normalized - setpoint_normalized) * (x_normalized - setpoint_normalized)) * c->r_scale[k];
     }

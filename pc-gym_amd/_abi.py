@@ -49,6 +49,7 @@ PCG_F_GAUSS_DIST = 0x0200
 PCG_F_X0_NORMAL = 0x0400
 PCG_F_UNC_EMPIRICAL = 0x0800
 PCG_F_REWARD_TRACK = 0x1000
+PCG_F_REWARD_CRYST = 0x2000
 PCG_MAX_RBOX = 4
 PCG_MAX_EMP = 65536
 

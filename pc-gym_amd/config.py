@@ -134,10 +134,14 @@ class EnvSpec:
         self.reward_track = None
         if isinstance(self.custom_reward, dict):
             rt = dict(self.custom_reward)
-            if rt.pop("kind", "sp_track") != "sp_track":
-                raise ValueError("declarative custom_reward: only kind 'sp_track' is built")
-            self.reward_track = {"R": float(rt.pop("R", 0.1)), "R_u": float(rt.pop("R_u", 0.0)),
-                                 "box": dict(rt.pop("box", {}) or {})}
+            kind = rt.pop("kind", "sp_track")
+            if kind not in ("sp_track", "cryst_moments"):
+                raise ValueError("declarative custom_reward: kinds 'sp_track' and 'cryst_moments' are built")
+            # 'cryst_moments' (crystalisation/cryst_train.py:17-48): sp_track on CV and Ln recomputed from the observed
+            # moments, unit weights, R = 0.01
+            self.reward_track = {"R": float(rt.pop("R", 0.1 if kind == "sp_track" else 0.01)),
+                                 "R_u": float(rt.pop("R_u", 0.0)), "box": dict(rt.pop("box", {}) or {}),
+                                 "cryst": kind == "cryst_moments"}
             if rt:
                 raise ValueError(f"declarative custom_reward: unknown keys {sorted(rt)}")
             if self.SP is None:
@@ -207,6 +211,11 @@ class EnvSpec:
         else:
             self.rew_index = np.zeros(0, dtype=np.int32)
             self.r_scale = np.array([float(r_scale.get(k, 1)) for k in self.sp_keys], dtype=_f64)
+            if self.reward_track is not None and self.reward_track["cryst"]:
+                self.r_scale[:] = 1.0  # cryst_train.py:37 has no r_scale
+                if self.sp_keys != ["CV", "Ln"] or p.get("model") != "crystallization":
+                    raise ValueError("custom_reward kind 'cryst_moments' needs model 'crystallization' and SP keys "
+                                     "['CV', 'Ln'] (cryst_train.py:34-35)")
         self.nrew = self.rew_index.shape[0]
 
         # x0 normally carries the SP slots ([x | SP], README.md:47).  With only the nx physical
@@ -502,6 +511,7 @@ class EnvSpec:
         f |= abi.PCG_F_NOISE if self.noise else 0
         f |= abi.PCG_F_REWARD_BATCH if self.reward_batch else 0
         f |= abi.PCG_F_REWARD_TRACK if self.reward_track is not None else 0
+        f |= abi.PCG_F_REWARD_CRYST if (self.reward_track is not None and self.reward_track["cryst"]) else 0
         f |= abi.PCG_F_MAXIMISE if self.maximise_reward else 0
         f |= abi.PCG_F_REF_COMPAT if self.reference_compat else 0
         f |= abi.PCG_F_GAUSS_DIST if self.gauss else 0

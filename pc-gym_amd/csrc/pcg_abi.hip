@@ -271,6 +271,7 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
     // normalisation of the tracking reward is always by o_space / a_space (custom_reward.py:14-31), whether or
     // not the env normalises its observations / actions
     if ((c->flags & PCG_F_REWARD_BATCH) || nsp == 0) return PCG_E_UNSUPPORTED;
+    if ((c->flags & PCG_F_REWARD_CRYST) && c->model_id != PCG_MODEL_CRYST) return PCG_E_UNSUPPORTED;
     if (c->rew_nbox < 0 || c->rew_nbox > PCG_MAX_RBOX) return PCG_E_DIM;
     if (c->rew_nbox > 0 && (!c->rew_box_index || !c->rew_box_lo || !c->rew_box_hi)) return PCG_E_NULL;
     if (nd > 0) return PCG_E_UNSUPPORTED;  // the reference broadcasts uk (Nu + Nd) against a_space (Nu) there

@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/pcgym_hip.h"
@@ -426,7 +427,14 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
 #pragma unroll
     for (int k = 0; k < PCG_MAX_NSP; ++k)
       if (k < nsp) {
-        const double xn = (pick<NX>(on, c.sp_index[k]) - c.trk_lo[k]) * c.trk_inv[k];
+        double xv = pick<NX>(on, c.sp_index[k]);
+        if constexpr (std::is_same<M, Model<PCG_MODEL_CRYST>>::value) {
+          if (flags & PCG_F_REWARD_CRYST) {  // cryst_train.py:24-25: CV and Ln from the observed moments
+            if (c.sp_index[k] == 5) xv = sqrt(on[2] * on[0] / (on[1] * on[1]) - 1.0);
+            if (c.sp_index[k] == 6) xv = on[1] / on[0];
+          }
+        }
+        const double xn = (xv - c.trk_lo[k]) * c.trk_inv[k];
         const double sn = (spn[k] - c.trk_lo[k]) * c.trk_inv[k];
         cost += ((xn - sn) * (xn - sn)) * c.r_scale[k];
       }

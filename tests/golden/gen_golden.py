@@ -280,12 +280,23 @@ def gen_steps(P, out, only_new=False):
             import copy
             import importlib.util
 
-            rel, fname = sc["ref_custom_reward"]
-            spec = importlib.util.spec_from_file_location("ref_custom_reward_" + name, os.path.join(REF, rel))
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
+            rel, fname = sc["ref_custom_reward"][:2]
             p = copy.deepcopy(p)
-            p["custom_reward"] = getattr(mod, fname)
+            if "extract" in sc["ref_custom_reward"][2:]:
+                # the function sits in a training script that cannot be imported (it trains on import): compile just
+                # that def from the reference file, at generation time only
+                import ast
+
+                src = open(os.path.join(REF, rel)).read()
+                fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == fname)
+                ns = {"np": np}
+                exec(compile(ast.Module(body=[fn], type_ignores=[]), rel, "exec"), ns)
+                p["custom_reward"] = ns[fname]
+            else:
+                spec = importlib.util.spec_from_file_location("ref_custom_reward_" + name, os.path.join(REF, rel))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                p["custom_reward"] = getattr(mod, fname)
         A = SC.actions_for(name, sc)
         np.random.seed(12345)  # only matters for action_space.sample() in _setup_constraints
         env = P.make_env(p)

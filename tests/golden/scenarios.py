@@ -318,6 +318,14 @@ def scenarios():
     S["cstr_con_reward"] = dict(env_params=p, steps=59, action_seed=33, raw_actions=True,
                                 ref_custom_reward=("pc-gym_paper/constraint_showcase/custom_reward.py", "con_reward"))
 
+    # crystallisation: CV and Ln recomputed from the observed moments (cryst_train.py:17-48; the def is compiled out of
+    # the training script by gen_golden.py -- the script itself trains on import)
+    p = _cryst_base()
+    p.update(custom_reward={"kind": "cryst_moments"})
+    S["cryst_paper_reward"] = dict(env_params=p, steps=29, action_seed=34,
+                                   ref_custom_reward=("pc-gym_paper/train_policies/crystalisation/cryst_train.py",
+                                                      "oracle_reward", "extract"))
+
     # the reference's own known-answer test (custom linear model)
     S["custom_linear_kat"] = dict(
         env_params={

@@ -289,6 +289,7 @@ BATCH_CASES = [
     ("cstr_paper_reward", {}, 1e-12),
     ("four_tank_paper_reward", {}, 1e-12),
     ("cstr_con_reward", {}, 1e-12),
+    ("cryst_paper_reward", {}, 1e-10),
     ("cstr_partial_obs", {}, 1e-12),
 ]
 
