@@ -167,7 +167,18 @@ def main():
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+            try:
+                dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+                probe = torch.zeros(1, device=dev)
+                dist.all_reduce(probe)  # communicator creation is lazy: fail here, not inside the timed region
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001 -- the collectives only carry a barrier and one scalar
+                print(f"[bench] rank {rank}: RCCL unavailable ({type(e).__name__}: {e}); using gloo for the "
+                      f"barrier / max-reduce", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend=backend)
 

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""cstr at B = 2^20, one RK4 step per env step: lean path vs the general (EXTRAS) kernel with noise / constraints /
+Gaussian disturbance / per-env t switched on one at a time.  Run on the GPU box."""
+import os, sys, time, copy
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench as BN
+from pcgym_amd import VecEnv
+
+def run(label, extra, per_env_t=False):
+    B = 1 << 20
+    p = BN.workload_params(B); p.update(extra)
+    env = VecEnv(p, n_envs=B, seed=1, per_env_t=per_env_t, auto_reset=True); env.reset()
+    acts = 2 * torch.rand((16, 1, B), device=env.device, dtype=torch.float64) - 1
+    for i in range(600): env.step(acts[i % 16])
+    torch.cuda.synchronize(); t0 = time.perf_counter(); K = 3000
+    for i in range(K): env.step(acts[i % 16])
+    torch.cuda.synchronize(); w = time.perf_counter() - t0
+    bpe = env.bytes_per_env_step
+    print(f"{label:34s} {w/K*1e6:7.2f} us/step  {B*K/w:.3e} env-steps/s  {bpe} B/env-step -> {bpe*B*K/w/1e12:.2f} TB/s")
+
+def cons(x, u):
+    return np.array([x[1] - 340.0, 300.0 - x[1]])
+
+run("lean (bench workload)", {})
+run("noise 0.1 %", {"noise": True, "noise_percentage": 0.001})
+run("constraints (2 rows)", {"constraints": cons, "done_on_cons_vio": False, "r_penalty": True})
+run("tracking reward (sp_track)", {"custom_reward": {"kind": "sp_track", "R": 0.1}})
+run("per-env t", {}, per_env_t=True)
+run("noise + constraints + per-env t", {"noise": True, "noise_percentage": 0.001, "constraints": cons,
+    "done_on_cons_vio": True, "r_penalty": True}, per_env_t=True)
