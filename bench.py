@@ -158,7 +158,7 @@ def main():
     # PCG_BENCH_BACKEND=gloo is a test switch: it lets the N-rank code path run on a box with fewer GPUs than
     # ranks (ranks share devices); the driver's runs use the default, RCCL with one rank per GPU.
     backend = os.environ.get("PCG_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a node with one GPU per rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
