@@ -323,6 +323,13 @@ PCG_API int pcg_rollout_strided(pcg_plan* plan, const pcg_buffers* io, int32_t t
                                 int64_t obs_step_stride, int64_t obs_comp_stride, double* rew_seq,
                                 int64_t rew_step_stride, uint64_t seed, void* stream);
 
+/* pcg_step followed, in the same launch, by the reset of every env that finished in it (gymnasium "same-step"
+ * auto-reset: rew / done / viol are those of the finished step; x, obs, t, a_save and the per-env parameters are
+ * those of the new episode, drawn with `reset_seed`).  Equivalent to pcg_step + pcg_reset(mask = io->done,
+ * seed = reset_seed) -- the reference has no counterpart (its callers loop "if done: env.reset()",
+ * policy_evaluation.py:86-128) -- but one launch instead of two.  Needs per-env step counters (io->t). */
+PCG_API int pcg_step_autoreset(pcg_plan* plan, const pcg_buffers* io, uint64_t seed, uint64_t reset_seed, void* stream);
+
 /* Step graph: T consecutive pcg_step launches (t = t0 .. t0+T-1, optionally preceded by a full pcg_reset)
  * recorded once as a HIP graph and replayed with ONE host call.  This is the on-device form of the
  * reference's per-episode Python loop "for i in range(N-1): env.step(a_i)" (policy_evaluation.py:86-128)

@@ -154,6 +154,7 @@ EXPORTS = [
     "pcg_integrate",
     "pcg_rollout",
     "pcg_rollout_strided",
+    "pcg_step_autoreset",
     "pcg_graph_create",
     "pcg_graph_launch",
     "pcg_graph_set_seed",
@@ -199,6 +200,8 @@ def declare(lib):
     lib.pcg_rollout_strided.restype = C.c_int
     lib.pcg_rollout_strided.argtypes = [vp, C.POINTER(pcg_buffers), C.c_int32, C.c_int32, vp, C.c_int64, C.c_int64,
                                         vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_uint64, vp]
+    lib.pcg_step_autoreset.restype = C.c_int
+    lib.pcg_step_autoreset.argtypes = [vp, C.POINTER(pcg_buffers), C.c_uint64, C.c_uint64, vp]
     lib.pcg_graph_create.restype = C.c_int
     lib.pcg_graph_create.argtypes = [C.POINTER(vp), vp, C.POINTER(pcg_buffers), C.POINTER(vp), C.POINTER(vp),
                                      C.c_int32, C.c_int32, C.c_uint64, C.c_int]

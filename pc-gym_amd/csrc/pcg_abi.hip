@@ -11,60 +11,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs A) {
   const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (e >= A.B) return;
   if (A.mask && !A.mask[e]) return;
-  const int64_t B = A.B;
-  const int nx = c.nx, nsp = c.nsp_obs, nd = c.nd;
-  const uint64_t env_id = (uint64_t)(A.env_offset + e);
-  for (int i = 0; i < nx; ++i) {
-    double v = c.x0[i];
-    if (c.has_x0_unc && c.x0_unc[i] != 0.0) {  // apply_uncertainties, pcgym.py:255-261
-      const double pct = c.x0_unc[i];
-      if (c.flags & PCG_F_X0_NORMAL) {
-        double z0, z1;
-        rng_normal2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(i >> 1), z0, z1);
-        v = c.x0[i] + pct * c.x0[i] * ((i & 1) ? z1 : z0);
-      } else {
-        double u0, u1;
-        rng_uniform2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(i >> 1), u0, u1);
-        v = c.x0[i] * (1 + pct * (2.0 * ((i & 1) ? u1 : u0) - 1.0));
-      }
-    }
-    A.x[(size_t)i * B + e] = v;
-    A.obs[(size_t)i * B + e] = (v - c.omap[i].lo) * c.omap[i].sc + c.omap[i].off;
-  }
-  for (int k = 0; k < nsp; ++k)
-    A.obs[(size_t)(nx + k) * B + e] = (c.x0[nx + k] - c.omap[nx + k].lo) * c.omap[nx + k].sc + c.omap[nx + k].off;
-  for (int k = 0; k < nd; ++k) {  // disturbances[k][0] (pcgym.py:291-298, quirk Q6)
-    const int j = nx + nsp + k;
-    A.obs[(size_t)j * B + e] = (A.sched[(size_t)(c.nsp + k) * c.N] - c.omap[j].lo) * c.omap[j].sc + c.omap[j].off;
-  }
-  // uncertain model parameters (pcgym.py:301-310): sampled per env, appended to the observation
-  for (int j = 0; j < c.nunc; ++j) {
-    const double orig = c.raw[c.unc_index[j]], pct = c.unc_pct[j];
-    const int ri = nx + j;  // RNG index after the x0 draws
-    double v;
-    if (c.flags & PCG_F_UNC_EMPIRICAL) {  // np.random.choice(samples), pcgym.py:311-316
-      double u0, u1;
-      rng_uniform2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), u0, u1);
-      const int len = c.emp_off[j + 1] - c.emp_off[j];
-      int idx = (int)(((ri & 1) ? u1 : u0) * (double)len);
-      idx = idx < len - 1 ? idx : len - 1;
-      v = A.sched[(size_t)(c.nsp + c.nd) * c.N + c.emp_off[j] + idx];
-    } else if (c.flags & PCG_F_X0_NORMAL) {
-      double z0, z1;
-      rng_normal2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), z0, z1);
-      v = orig + pct * orig * ((ri & 1) ? z1 : z0);
-    } else {
-      double u0, u1;
-      rng_uniform2(A.seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), u0, u1);
-      v = orig * (1 + pct * (2.0 * ((ri & 1) ? u1 : u0) - 1.0));
-    }
-    A.p_unc[(size_t)j * B + e] = v;
-    const int q = nx + nsp + nd + j;
-    A.obs[(size_t)q * B + e] = (v - c.omap[q].lo) * c.omap[q].sc + c.omap[q].off;
-  }
-  if ((c.flags & PCG_F_A_DELTA) && A.a_save)
-    for (int i = 0; i < c.na; ++i) A.a_save[(size_t)i * B + e] = c.a_0[i];
-  if (A.t) A.t[e] = 0;
+  reset_env(A, c, e, A.seed);
 }
 
 // one table of kernel instantiations per model, built in the pcg_inst_*.hip units
@@ -541,9 +488,12 @@ static int warm_occupancy(pcg_plan* p) {
   return PCG_OK;
 }
 
-int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void* stream) {
+static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void* stream, bool auto_reset,
+                     uint64_t reset_seed) {
   StepArgs a;
   int rc = fill_args(p, io, &a);
+  a.auto_reset = auto_reset ? 1 : 0;
+  a.reset_seed = reset_seed;
   if (rc != PCG_OK) return rc;
   if (io->B == 0) return PCG_OK;  // empty batch: nothing to do (zero-size buffers may be NULL)
   if (!io->x || !io->a || !io->obs || !io->rew || !io->done) return PCG_E_NULL;
@@ -621,6 +571,16 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(fn, dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
   return (int)hipGetLastError();
+}
+
+int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void* stream) {
+  return step_impl(p, io, t, seed, stream, false, 0);
+}
+
+int pcg_step_autoreset(pcg_plan* p, const pcg_buffers* io, uint64_t seed, uint64_t reset_seed, void* stream) {
+  if (io && !io->t && io->B > 0) return PCG_E_UNSUPPORTED;  // a lock-stepped batch resets as a whole: pcg_reset
+  if (plan_ok(p) && io && p->hc.nunc > 0 && !io->p_unc) return PCG_E_NULL;
+  return step_impl(p, io, 0, seed, stream, true, reset_seed);
 }
 
 int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t T, const double* a_seq,

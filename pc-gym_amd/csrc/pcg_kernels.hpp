@@ -130,6 +130,8 @@ struct StepArgs {
   int32_t t_scalar;
   int32_t sched_in_lds;  // per-env-t kernels: schedules staged in LDS
   int32_t nt_stores;     // stream kernels: non-temporal stores for obs / reward
+  int32_t auto_reset;    // per-env-t kernels: reset the envs that finished in this step (pcg_step_autoreset)
+  uint64_t reset_seed;   // RNG key of those resets
   // rollout
   const double* a_seq;
   double* obs_seq;
@@ -188,6 +190,66 @@ PCG_DEV double pick(const double (&v)[N], int idx) {
 #pragma unroll
   for (int i = 0; i < N; ++i) r = (i == idx) ? v[i] : r;
   return r;
+}
+
+// reset of ONE env (pcgym.py:263-349): initial state with optional x0 / parameter uncertainty (Philox keyed by
+// `seed`), first observation, a_delta accumulator, step counter.  Shared by reset_kernel and by the fused
+// "step, then reset what finished" path of step_kernel (pcg_step_autoreset).
+PCG_DEV void reset_env(const StepArgs& A, CDevConst& c, int64_t e, uint64_t seed) {
+  const int64_t B = A.B;
+  const int nx = c.nx, nsp = c.nsp_obs, nd = c.nd;
+  const uint64_t env_id = (uint64_t)(A.env_offset + e);
+  for (int i = 0; i < nx; ++i) {
+    double v = c.x0[i];
+    if (c.has_x0_unc && c.x0_unc[i] != 0.0) {  // apply_uncertainties, pcgym.py:255-261
+      const double pct = c.x0_unc[i];
+      if (c.flags & PCG_F_X0_NORMAL) {
+        double z0, z1;
+        rng_normal2(seed, env_id, 0u, RNG_RESET + (uint32_t)(i >> 1), z0, z1);
+        v = c.x0[i] + pct * c.x0[i] * ((i & 1) ? z1 : z0);
+      } else {
+        double u0, u1;
+        rng_uniform2(seed, env_id, 0u, RNG_RESET + (uint32_t)(i >> 1), u0, u1);
+        v = c.x0[i] * (1 + pct * (2.0 * ((i & 1) ? u1 : u0) - 1.0));
+      }
+    }
+    A.x[(size_t)i * B + e] = v;
+    A.obs[(size_t)i * B + e] = (v - c.omap[i].lo) * c.omap[i].sc + c.omap[i].off;
+  }
+  for (int k = 0; k < nsp; ++k)
+    A.obs[(size_t)(nx + k) * B + e] = (c.x0[nx + k] - c.omap[nx + k].lo) * c.omap[nx + k].sc + c.omap[nx + k].off;
+  for (int k = 0; k < nd; ++k) {  // disturbances[k][0] (pcgym.py:291-298, quirk Q6)
+    const int j = nx + nsp + k;
+    A.obs[(size_t)j * B + e] = (A.sched[(size_t)(c.nsp + k) * c.N] - c.omap[j].lo) * c.omap[j].sc + c.omap[j].off;
+  }
+  // uncertain model parameters (pcgym.py:301-310): sampled per env, appended to the observation
+  for (int j = 0; j < c.nunc; ++j) {
+    const double orig = c.raw[c.unc_index[j]], pct = c.unc_pct[j];
+    const int ri = nx + j;  // RNG index after the x0 draws
+    double v;
+    if (c.flags & PCG_F_UNC_EMPIRICAL) {  // np.random.choice(samples), pcgym.py:311-316
+      double u0, u1;
+      rng_uniform2(seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), u0, u1);
+      const int len = c.emp_off[j + 1] - c.emp_off[j];
+      int idx = (int)(((ri & 1) ? u1 : u0) * (double)len);
+      idx = idx < len - 1 ? idx : len - 1;
+      v = A.sched[(size_t)(c.nsp + c.nd) * c.N + c.emp_off[j] + idx];
+    } else if (c.flags & PCG_F_X0_NORMAL) {
+      double z0, z1;
+      rng_normal2(seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), z0, z1);
+      v = orig + pct * orig * ((ri & 1) ? z1 : z0);
+    } else {
+      double u0, u1;
+      rng_uniform2(seed, env_id, 0u, RNG_RESET + (uint32_t)(ri >> 1), u0, u1);
+      v = orig * (1 + pct * (2.0 * ((ri & 1) ? u1 : u0) - 1.0));
+    }
+    A.p_unc[(size_t)j * B + e] = v;
+    const int q = nx + nsp + nd + j;
+    A.obs[(size_t)q * B + e] = (v - c.omap[q].lo) * c.omap[q].sc + c.omap[q].off;
+  }
+  if ((c.flags & PCG_F_A_DELTA) && A.a_save)
+    for (int i = 0; i < c.na; ++i) A.a_save[(size_t)i * B + e] = c.a_0[i];
+  if (A.t) A.t[e] = 0;
 }
 
 template <class M, class R = double, class K = typename M::CKP>
@@ -543,6 +605,15 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG), wpe(M::NX, INTEG, LDS_STAGES
   for (int i = 0; i < NA; ++i) a[i] = (i < na) ? A.a[(size_t)i * B + e] : 0.0;
   EnvOut<M> out;
   env_step<M, INTEG, PER_ENV_T, LDS_STAGES, EXTRAS, UNC>(A, c, sched_l, stage_l, e, t, a, x, out);
+  if (PER_ENV_T && A.auto_reset && out.done) {
+    // gymnasium "same-step" auto-reset in the same launch: reward / done / viol of the finished step are kept,
+    // state, observation, step counter (and a_delta accumulator, per-env parameters) are those of the new episode
+    __builtin_nontemporal_store(out.rew, A.rew + e);
+    A.done[e] = 1;
+    if (A.viol) A.viol[e] = out.viol ? 1 : 0;
+    reset_env(A, c, e, A.reset_seed);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NX; ++i)
     if (i < nx) A.x[(size_t)i * B + e] = x[i];

@@ -219,8 +219,15 @@ class VecEnv:
             self._buf.d = d.data_ptr()
         else:
             self._buf.d = None
-        _lib.check(self._lib.pcg_step(self._plan, self._bufp, self.t, self._episode_seed(), self._stream()),
-                   "pcg_step")
+        fused_reset = self.auto_reset and self.per_env_t
+        if fused_reset:  # step + reset of what finished, one launch; every step opens a new RNG epoch for the resets
+            seed = self._episode_seed()
+            self.episode += 1
+            _lib.check(self._lib.pcg_step_autoreset(self._plan, self._bufp, seed, self._episode_seed(), self._stream()),
+                       "pcg_step_autoreset")
+        else:
+            _lib.check(self._lib.pcg_step(self._plan, self._bufp, self.t, self._episode_seed(), self._stream()),
+                       "pcg_step")
         self.t += 1
         info = {}
         if s.ncon:
@@ -228,13 +235,8 @@ class VecEnv:
             info["g"] = self.g
         if self.nsteps is not None:
             info["nsteps"] = self.nsteps
-        if self.auto_reset:
-            if self.per_env_t:
-                self.episode += 1
-                _lib.check(self._lib.pcg_reset(self._plan, self._bufp, self.done.data_ptr(),
-                                               self._episode_seed(), self._stream()), "pcg_reset")
-            elif self.t == self.N - 1:
-                self.reset()
+        if self.auto_reset and not self.per_env_t and self.t == self.N - 1:
+            self.reset()
         return self.obs, self.rew, self.done.view(_torch().bool), False, info
 
     def rollout(self, actions, collect_obs=False, collect_rew=True):

@@ -656,6 +656,42 @@ def test_tracking_reward_u_prev_survives_reset_like_the_reference():
     env.close()
 
 
+def test_fused_auto_reset_equals_step_then_masked_reset():
+    """pcg_step_autoreset == pcg_step + pcg_reset(mask = done): envs end at different times (done on constraint
+    violation), finished ones restart inside the same launch with fresh x0 draws; the oracle does the two calls."""
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    p = copy.deepcopy(SC.scenarios()["cstr_cons_done_raw"]["env_params"])
+    p.update(N=12, tsim=12 * 26.0 / 60.0, SP={"Ca": [0.85] * 12}, uncertainty_percentages={"x0": [0.1, 0.02]},
+             distribution="uniform")
+    B = 3000
+    env = VecEnv(p, n_envs=B, seed=40, per_env_t=True, auto_reset=True)
+    orc = O.OracleEnv(env.spec, B, seed=40, per_env_t=True)
+    env.reset()
+    orc.reset()
+    acts = _rand_actions(env.spec, 30, B, 6)
+    n_done = 0
+    for i in range(30):
+        og, rg, dg, _, _ = env.step(torch.tensor(acts[i], device=env.device))
+        oc, rc, dc = orc.step(acts[i])
+        oc, rc, dc = oc.copy(), rc.copy(), dc.copy()
+        orc.reset(mask=dc)  # what VecEnv.step did in the same launch (episode counter advances on both sides)
+        fin = dc.astype(bool)
+        n_done += int(fin.sum())
+        assert np.array_equal(dg.cpu().numpy().astype(np.uint8), dc), i
+        assert np.allclose(rg.cpu().numpy(), rc, rtol=1e-11, atol=1e-12), i
+        assert np.array_equal(env.t_env.cpu().numpy(), orc.t_env), i
+        assert np.allclose(env.x.cpu().numpy(), orc.x, rtol=1e-11, atol=0), i
+        assert np.allclose(og.cpu().numpy().T, orc.obs, rtol=1e-11, atol=1e-11), i  # reset obs for finished envs
+        assert np.all(env.t_env.cpu().numpy()[fin] == 0)
+    assert n_done > B  # every env finished at least once (N - 1 = 11 steps), many earlier through violations
+    env.close()
+
+
 # ------------------------------------------------ full-size property tests ---
 def test_full_size_cstr_properties():
     """BASELINE.json configs[1] size (B = 2^20): size-independent properties.
