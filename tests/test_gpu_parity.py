@@ -303,14 +303,15 @@ def _rand_actions(spec, T, B, seed):
 
 @pytest.mark.parametrize("name,kw,tol", BATCH_CASES)
 @pytest.mark.parametrize("per_env_t", [False, True])
-def test_batched_step_vs_oracle(name, kw, tol, per_env_t):
+@pytest.mark.parametrize("B", [777, 1026])  # ragged / odd (one env per lane) and even (two-envs-per-lane kernels)
+def test_batched_step_vs_oracle(name, kw, tol, per_env_t, B):
     torch = _torch()
     import copy
 
     from oracle import oracle as O
     from pcgym_amd import VecEnv
 
-    B, T = 777, 12  # ragged: not a multiple of the wave or block size
+    T = 12
     sc = SC.scenarios()[name]
     p = copy.deepcopy(sc["env_params"])
     p.update(kw)
