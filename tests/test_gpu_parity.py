@@ -370,6 +370,43 @@ def test_batched_step_vs_oracle(name, kw, tol, per_env_t, B):
     env.close()
 
 
+@pytest.mark.parametrize("name", ["cstr_canonical", "four_tank_canonical"])
+@pytest.mark.parametrize("B", [999, 4096])
+def test_observation_noise_vs_oracle(name, B):
+    """observation noise alone (the paper scripts' canonical setting): same Philox streams as the oracle,
+    multiplicative in the state (pcgym.py:452-466); default dispatch and the forced general kernel agree."""
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    p = copy.deepcopy(SC.scenarios()[name]["env_params"])
+    p.update(noise=True, noise_percentage=0.02)
+    env = VecEnv(p, n_envs=B, seed=13, env_offset=7 * 10**9)
+    gen = VecEnv(p, n_envs=B, seed=13, env_offset=7 * 10**9, variant=1)  # the general kernel, forced
+    orc = O.OracleEnv(env.spec, B, seed=13, env_offset=7 * 10**9)
+    for e in (env, gen, orc):
+        e.reset()
+    acts = _rand_actions(env.spec, 5, B, 1)
+    for i in range(5):
+        a = torch.tensor(acts[i], device=env.device)
+        og, rg, dg, _, _ = env.step(a)
+        o2, r2, d2, _, _ = gen.step(a)
+        oc, rc, dc = orc.step(acts[i])
+        assert np.max(np.abs(og.cpu().numpy().T - oc)) <= 1e-11, i
+        assert torch.allclose(og, o2, rtol=0, atol=1e-12) and torch.allclose(rg, r2, rtol=1e-12, atol=1e-12)
+        assert np.max(np.abs(env.x.cpu().numpy() - orc.x) / np.abs(orc.x)) <= 1e-12
+        assert np.allclose(rg.cpu().numpy(), rc, rtol=1e-11, atol=1e-12)
+    # the observation really is noisy: un-normalise and compare with the state
+    lo, hi = env.spec.o_low[: env.spec.nx, None], env.spec.o_high[: env.spec.nx, None]
+    obs_phys = (og.cpu().numpy().T[: env.spec.nx] + 1) / 2 * (hi - lo) + lo
+    rel = obs_phys / env.x.cpu().numpy() - 1
+    assert 0.015 < rel.std() < 0.025 and abs(rel.mean()) < 0.005
+    for e in (env, gen):
+        e.close()
+
+
 def test_noise_and_gaussian_disturbance_vs_oracle():
     """counter-based RNG: same Philox stream on both sides -> same noise to ~1e-13"""
     torch = _torch()
