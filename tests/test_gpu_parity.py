@@ -730,6 +730,43 @@ def test_fused_auto_reset_equals_step_then_masked_reset():
     env.close()
 
 
+def test_mixed_model_batch_segments_match_single_model_envs():
+    """BASELINE configs[4] layout: model-homogeneous segments on their own streams == the same envs stepped as
+    separate single-model batches (same global env offsets -> same Gaussian-disturbance streams)."""
+    torch = _torch()
+    import copy
+
+    from pcgym_amd import MixedVecEnv, VecEnv, make_mixed_sharded_env
+
+    p0 = copy.deepcopy(SC.scenarios()["cstr_dist_Ti"]["env_params"])
+    p0.update(gaussian_disturbances={"Ti": 2.0})
+    p1 = copy.deepcopy(SC.scenarios()["four_tank_canonical"]["env_params"])
+    p2 = copy.deepcopy(SC.scenarios()["me_canonical"]["env_params"])
+    sizes = [700, 500, 300]
+    mixed = MixedVecEnv(list(zip([p0, p1, p2], sizes)), seed=8, env_offset=1000)
+    assert mixed.B == sum(sizes) and mixed.offsets == [1000, 1700, 2200]
+    singles = [VecEnv(p, n_envs=n, seed=8, env_offset=o) for p, n, o in zip([p0, p1, p2], sizes, mixed.offsets)]
+    mixed.reset()
+    for e in singles:
+        e.reset()
+    gen = torch.Generator(device=mixed.device).manual_seed(3)
+    for i in range(6):
+        acts = [0.3 * (2 * torch.rand((e.spec.na, e.B), generator=gen, device=e.device, dtype=torch.float64) - 1) - 0.5
+                for e in singles]
+        outs = mixed.step(acts)
+        for e, a, (o, r, d, _, _) in zip(singles, acts, outs):
+            o1, r1, d1, _, _ = e.step(a)
+            assert torch.equal(o, o1) and torch.equal(r, r1) and torch.equal(d, d1)
+    torch.cuda.synchronize()
+    # sharding a mixed batch: every rank gets the same fraction of every segment, offsets follow the global layout
+    sh = make_mixed_sharded_env(list(zip([p0, p1, p2], sizes)), rank=1, world=2, device=0, seed=8)
+    assert [e.B for e in sh.envs] == [350, 250, 150] and sh.offsets == [350, 950, 1350]
+    for e in singles:
+        e.close()
+    mixed.close()
+    sh.close()
+
+
 # ------------------------------------------------ full-size property tests ---
 def test_full_size_cstr_properties():
     """BASELINE.json configs[1] size (B = 2^20): size-independent properties.

@@ -135,13 +135,14 @@ def mixed(B_total, K=60):
     p.pop("constraints"), p.pop("done_on_cons_vio"), p.pop("r_penalty")
     p.update(gaussian_disturbances={"X0": 0.02}, normalise_a=True, normalise_o=True)
     specs.append(p)
-    envs, streams, acts = [], [], []
+    from pcgym_amd import MixedVecEnv
+
+    mixed_env = MixedVecEnv([(p, Bm) for p in specs], seed=5)
+    envs = mixed_env.envs
+    mixed_env.reset()
     gen = torch.Generator(device="cuda").manual_seed(11)
-    for i, p in enumerate(specs):
-        e = VecEnv(p, n_envs=Bm, seed=5 + i, env_offset=i * Bm)
-        e.reset()
-        envs.append(e)
-        streams.append(torch.cuda.Stream())
+    acts = []
+    for e in envs:
         a = 2 * torch.rand((4, e.spec.na, Bm), generator=gen, device="cuda", dtype=torch.float64) - 1
         if e.spec.model.name.startswith("multistage"):
             a = a * 0.2 - 0.7  # moderate flows (|lambda| dt of a few tens): the paper's operating range
@@ -149,11 +150,9 @@ def mixed(B_total, K=60):
     torch.cuda.synchronize()
 
     def one_round(i):
-        for e, s, a in zip(envs, streams, acts):
-            with torch.cuda.stream(s):
-                e.step(a[i % 4])
-                if e.t == e.N - 1:
-                    e.reset()
+        mixed_env.step([a[i % 4] for a in acts])
+        if envs[0].t == envs[0].N - 1:  # the three configurations share N = 60
+            mixed_env.reset()
 
     for i in range(3):
         one_round(i)
