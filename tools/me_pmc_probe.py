@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Six DOPRI5 steps of a multistage-extraction config at B = 2^18: the workload rocprofv3 --pmc is pointed at to
+count VALU instructions per launch ("fp64-VALU-bound kernels").  usage: me_pmc_probe.py <scenario>"""
 import os, sys
-ROOT = "/root/repo"
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import torch
 import scenarios as SC
