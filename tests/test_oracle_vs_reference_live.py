@@ -1,0 +1,132 @@
+"""CPU, build container only: RANDOMISED differential test of the oracle against the reference itself.
+
+The committed fixtures pin the oracle on 26 hand-written scenarios; here env_params are drawn at random (model,
+set-point schedules, normalisation flags, a_delta, affine constraints with penalty / done-on-violation,
+disturbances, batch reward, partial observation) and the reference's own `make_env` -- imported from
+/root/reference behind the inert stubs of tests/golden/gen_golden.py, its CVODES call replaced by LSODA(1e-12) --
+is stepped side by side with the oracle.  Skipped wherever the reference tree is absent (e.g. on the GPU box);
+nothing here is needed by, or reachable from, the product.
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+REF = "/root/reference/src/pcgym/pcgym.py"
+pytestmark = pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    import gen_golden as G
+
+    P, M = G._import_reference()
+    P.integration_engine = G._TightEngine
+    return P
+
+
+def _cons_rows(A, b, nobs):
+    A, b = np.asarray(A), np.asarray(b)
+
+    def g(x, u):
+        z = np.concatenate([np.asarray(x, dtype=float).reshape(-1)[:nobs], np.asarray(u, dtype=float).reshape(-1)])
+        return (A[:, : z.size] @ z - b).reshape(-1,)
+
+    return g
+
+
+def _random_params(rng):
+    import scenarios as SC
+
+    S = SC.scenarios()
+    base = rng.choice(["cstr_canonical", "four_tank_canonical", "me_canonical", "cryst_adelta", "cstr_dist_Ti",
+                       "cstr_batch_reward"])
+    p = copy.deepcopy(S[base]["env_params"])
+    N = int(rng.integers(8, 20))
+    dt = float(p["tsim"]) / p["N"]
+    p["N"], p["tsim"] = N, N * dt
+    if p.get("SP") is not None:
+        for k in list(p["SP"]):
+            v = np.asarray(p["SP"][k], dtype=float)
+            lo, hi = v.min(), v.max() + 1e-3
+            p["SP"][k] = list(rng.uniform(lo, hi, N))
+        p["r_scale"] = {k: float(10 ** rng.uniform(-1, 3)) for k in p["SP"]}
+    if p.get("disturbances") is not None:
+        for k in list(p["disturbances"]):
+            v = np.asarray(p["disturbances"][k], dtype=float)
+            p["disturbances"][k] = rng.uniform(v.min(), v.max() + 1e-3, N)
+    norm_a = bool(rng.integers(0, 2))
+    p["normalise_o"] = bool(rng.integers(0, 2))
+    if not p.get("a_delta"):
+        p["normalise_a"] = norm_a
+    nx = {"cstr": 2, "four_tank": 4, "multistage_extraction": 10, "crystallization": 7}[p["model"]]
+    nobs = len(p["o_space"]["low"])
+    na = len(p["a_space"]["low"])
+    nu = na + (len(p["disturbances"]) if p.get("disturbances") is not None else 0)
+    if rng.random() < 0.5 and not (p.get("normalise_a", True) and nu != na and na != 1):
+        # affine constraint rows over [state | uk] with bounds near the operating point
+        ncon = int(rng.integers(1, 4))
+        x0 = np.asarray(p["x0"], dtype=float)
+        A = np.zeros((ncon, nobs + 8))  # wide enough for uk = [actions | model disturbance inputs] of any model
+        b = np.zeros(ncon)
+        for r in range(ncon):
+            i = int(rng.integers(0, nx))
+            sgn = rng.choice([-1.0, 1.0])
+            A[r, i] = sgn
+            b[r] = sgn * x0[i] * (1 + sgn * rng.uniform(-0.02, 0.05))
+        p["constraints"] = _cons_rows(A, b, nobs)
+        p["done_on_cons_vio"] = bool(rng.integers(0, 2))
+        p["r_penalty"] = bool(rng.integers(0, 2))
+    if rng.random() < 0.3:
+        names = {"cstr": ["Ca", "T"], "four_tank": ["h1", "h2", "h3", "h4"]}.get(p["model"])
+        if names:
+            p["partial_observation"] = list(rng.choice(names, size=max(1, len(names) // 2), replace=False))
+    return p
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_config_oracle_matches_reference(ref, seed):
+    from oracle import oracle as O
+    from pcgym_amd.config import EnvSpec
+
+    import helpers as H
+
+    rng = np.random.default_rng(1000 + seed)
+    p = _random_params(rng)
+    tight = H.tight_for(p)
+    try:
+        np.random.seed(1)
+        env = ref.make_env(copy.deepcopy(p))
+    except Exception as e_ref:  # the reference rejects the config: so must EnvSpec
+        with pytest.raises(Exception):
+            EnvSpec(dict(copy.deepcopy(p), **tight))
+        return
+    spec = EnvSpec(dict(copy.deepcopy(p), **tight))
+    orc = O.OracleEnv(spec, 1)
+    o_ref, _ = env.reset()
+    o_orc = orc.reset()[:, 0].copy()
+    assert np.allclose(o_orc, o_ref, rtol=1e-12, atol=1e-12)
+    na = spec.na_user
+    for i in range(spec.N - 1):
+        a = rng.uniform(-1, 1, na) * (0.3 if spec.model.name.startswith("multistage") else 1.0)
+        if spec.model.name.startswith("multistage"):
+            a = a - 0.6
+        if not spec.normalise_a:
+            a = (a + 1) * (spec.a_high[:na] - spec.a_low[:na]) / 2 + spec.a_low[:na]
+        try:
+            o_ref, r_ref, d_ref, _, info = env.step(a.copy())
+        except Exception:
+            return  # the reference itself fails on this configuration (e.g. the normalise_a broadcast, pcgym.py:597-600)
+        o, r, d = orc.step(a.reshape(-1, 1))
+        if not np.all(np.isfinite(o_ref)):
+            return
+        assert np.allclose(o[:, 0], o_ref, rtol=2e-8, atol=2e-9), (seed, i, p["model"])
+        assert abs(r[0] - r_ref) <= 1e-6 * max(1.0, abs(r_ref)), (seed, i)
+        assert bool(d[0]) == bool(d_ref), (seed, i)
+        if d_ref:
+            break
