@@ -767,6 +767,53 @@ def test_mixed_model_batch_segments_match_single_model_envs():
     sh.close()
 
 
+@pytest.mark.parametrize("seed", range(20))
+def test_random_configurations_vs_oracle(seed):
+    """random env_params (the generator of tests/test_oracle_vs_reference_live.py, which pins the oracle to the
+    reference on the same family): every flag combination must reach a kernel that agrees with the oracle."""
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+    from test_oracle_vs_reference_live import _random_params
+
+    rng = np.random.default_rng(5000 + seed)
+    p = _random_params(rng)
+    per_env_t = bool(rng.integers(0, 2))
+    B = int(rng.choice([255, 256, 770]))
+    try:
+        env = VecEnv(copy.deepcopy(p), n_envs=B, seed=seed, per_env_t=per_env_t)
+    except ValueError:
+        return  # a combination the reference rejects as well (checked in the live test)
+    spec = env.spec
+    orc = O.OracleEnv(spec, B, seed=seed, per_env_t=per_env_t)
+    env.reset()
+    orc.reset()
+    adaptive = spec.integrator == "dopri5"
+    for i in range(spec.N - 1):
+        a = rng.uniform(-1, 1, (spec.na, B))
+        if spec.model.name.startswith("multistage"):
+            a = 0.3 * a - 0.6
+        if not spec.normalise_a:
+            a = (a + 1) * (spec.a_high - spec.a_low)[:, None] / 2 + spec.a_low[:, None]
+        og, rg, dg, _, _ = env.step(torch.tensor(a, device=env.device))
+        oc, rc, dc = orc.step(a)
+        xs = np.maximum(np.abs(orc.x), 1e-6 * np.max(np.abs(orc.x), axis=1, keepdims=True))
+        ex = np.max(np.abs(env.x.cpu().numpy() - orc.x) / xs, axis=0)
+        if adaptive:
+            assert np.mean(ex <= 1e-9) >= 0.97 and np.max(ex) <= 1e-6, (seed, i)
+            env.x.copy_(torch.tensor(orc.x, device=env.device))
+        else:
+            assert np.max(ex) <= 1e-10, (seed, i, spec.model.name)
+            assert np.max(np.abs(og.cpu().numpy().T - oc) / np.maximum(np.abs(oc), 1e-3)) <= 1e-9, (seed, i)
+            assert np.allclose(rg.cpu().numpy(), rc, rtol=1e-8, atol=1e-9), (seed, i)
+            assert np.mean(dg.cpu().numpy().astype(np.uint8) == dc) >= 0.999, (seed, i)
+        if per_env_t:
+            assert np.array_equal(env.t_env.cpu().numpy(), orc.t_env)
+    env.close()
+
+
 # ------------------------------------------------ full-size property tests ---
 def test_full_size_cstr_properties():
     """BASELINE.json configs[1] size (B = 2^20): size-independent properties.
