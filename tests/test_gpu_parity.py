@@ -814,6 +814,45 @@ def test_random_configurations_vs_oracle(seed):
     env.close()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_configurations_rollout_equals_stepping(seed):
+    """pcg_rollout (T steps fused, state in registers) against T pcg_step launches on random configurations"""
+    torch = _torch()
+    import copy
+
+    from pcgym_amd import VecEnv
+    from test_oracle_vs_reference_live import _random_params
+
+    rng = np.random.default_rng(7000 + seed)
+    p = _random_params(rng)
+    B = int(rng.choice([254, 511]))
+    try:
+        e1 = VecEnv(copy.deepcopy(p), n_envs=B, seed=seed)
+    except ValueError:
+        return
+    e2 = VecEnv(copy.deepcopy(p), n_envs=B, seed=seed)
+    spec = e1.spec
+    T = spec.N - 1
+    a = rng.uniform(-1, 1, (T, spec.na, B))
+    if spec.model.name.startswith("multistage"):
+        a = 0.3 * a - 0.6
+    if not spec.normalise_a:
+        a = (a + 1) * (spec.a_high - spec.a_low)[None, :, None] / 2 + spec.a_low[None, :, None]
+    acts = torch.tensor(a, device=e1.device)
+    e1.reset()
+    e2.reset()
+    obs_seq, rew_seq = e2.rollout(acts, collect_obs=True, collect_rew=True)
+    tol = 1e-6 if spec.integrator == "dopri5" else 1e-11
+    for i in range(T):
+        o, r, d, _, _ = e1.step(acts[i])
+        assert torch.allclose(o.t().contiguous(), obs_seq[i], rtol=tol, atol=tol), (seed, i, spec.model.name)
+        assert torch.allclose(r, rew_seq[i], rtol=max(tol, 1e-9), atol=max(tol, 1e-9) * 1e3), (seed, i)
+    assert torch.allclose(e1.x, e2.x, rtol=tol, atol=0)
+    assert torch.equal(e1.done, e2.done)
+    e1.close()
+    e2.close()
+
+
 # ------------------------------------------------ full-size property tests ---
 def test_full_size_cstr_properties():
     """BASELINE.json configs[1] size (B = 2^20): size-independent properties.
