@@ -105,6 +105,31 @@ __global__ __launch_bounds__(256) void k6(Args A) {
   if ((threadIdx.x & 63) == 0) ((unsigned long long*)A.done)[e >> 6] = m;  // bitmask variant (1 bit/env)
 }
 
+// K2P: K2 with non-temporal stores and a padded component stride `ld` (instead of B) -- probes whether the seven
+// streams of the step (x0, x1, a, obs0..2, rew), 8 MiB apart in the product layout, alias in the DRAM channel / bank map
+struct ArgsP {
+  const double* x;
+  const double* a;
+  double* xo;
+  double* obs;
+  double* rew;
+  uint8_t* done;
+  int64_t B, ld;
+};
+__global__ __launch_bounds__(256) void k2p(ArgsP A) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (e >= A.B) return;
+  const d2 x0 = *(const d2*)(A.x + e), x1 = *(const d2*)(A.x + A.ld + e), a = *(const d2*)(A.a + e);
+  __builtin_nontemporal_store(x0 + a, (d2*)(A.xo + e));
+  __builtin_nontemporal_store(x1 + a, (d2*)(A.xo + A.ld + e));
+  __builtin_nontemporal_store(x0, (d2*)(A.obs + e));
+  __builtin_nontemporal_store(x1, (d2*)(A.obs + A.ld + e));
+  __builtin_nontemporal_store(a, (d2*)(A.obs + 2 * A.ld + e));
+  __builtin_nontemporal_store(x0 * x1, (d2*)(A.rew + e));
+  *(uint16_t*)(A.done + e) = (uint16_t)((x0.x > x1.x) | ((x0.y > x1.y) << 8));
+}
+
 int main(int argc, char** argv) {
   // launches per timed loop; the GPU needs ~50 ms of work to reach steady clocks: pass 3000 for the warm floor
   const int n_timed = argc > 1 ? atoi(argv[1]) : 300;
@@ -153,5 +178,24 @@ int main(int argc, char** argv) {
   }
   run("K5 persistent grid=1024 no done", [&](int i) { hipLaunchKernelGGL((k5<false>), dim3(1024), dim3(256), 0, 0, args(i)); });
   run("K6 1 env/lane, done as ballot bitmask", [&](int i) { hipLaunchKernelGGL(k6, dim3(B / 256), dim3(256), 0, 0, args(i)); });
+  {  // padded layouts: one big arena, rows placed `ld` elements apart, arrays staggered by `stag` bytes
+    double* arena;
+    const int64_t maxld = B + 65536;
+    CK(hipMalloc(&arena, (size_t)(8 * maxld + 8 * 65536) * 8 + (size_t)NA * B * 8));
+    CK(hipMemset(arena, 0, (size_t)(8 * maxld + 8 * 65536) * 8));
+    for (int64_t pad : {(int64_t)0, (int64_t)32, (int64_t)512, (int64_t)2080, (int64_t)33056}) {
+      const int64_t ld = B + pad;
+      double* px = arena;
+      double* pxo = px;                 // in place like the product
+      double* pobs = px + 2 * ld + pad; // staggered start
+      double* prew = pobs + 3 * ld + pad;
+      char nm[64];
+      snprintf(nm, sizeof nm, "K2P nt, component stride B+%lld", (long long)pad);
+      run(nm, [&](int i) {
+        hipLaunchKernelGGL(k2p, dim3(B / 512), dim3(256), 0, 0,
+                           ArgsP{px, a + (size_t)(i % NA) * B, pxo, pobs, prew, done, B, ld});
+      });
+    }
+  }
   return 0;
 }
