@@ -284,7 +284,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "cstr_b2^20_rk4_fp64",
-            "model": "cstr (nx=2, na=1, obs=3)",
+            "plant": "cstr (nx=2, na=1, obs=3)",
             "envs_per_gpu": B,
             "global_envs": B * world,
             "integrator": "rk4, 1 step per dt=1s (1/60 model time unit)",
