@@ -735,6 +735,45 @@ PCG_DEV void land(double2& v) {
   asm volatile("" : "+v"(v.y));
 }
 
+// stores of one lean tile: the state back in place, observation / reward (non-temporal on request), done flags
+template <class M, int EPL>
+PCG_DEV void store_lean(const StepArgs& A, CDevConst& c, int64_t e0, const Pack<EPL> (&xs)[M::NX],
+                        const LeanOut<M, EPL>& out, bool nt) {
+  using V = typename Vec<EPL>::T;
+  constexpr int NX = M::NX;
+  const int64_t B = A.B;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  const int nso = c.nsp_obs;
+  double tmp[EPL];
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    if (i < nx) {
+      *reinterpret_cast<V*>(A.x + (size_t)i * B + e0) = Vec<EPL>::make(xs[i].v);
+      if (nt) Vec<EPL>::store_nt(A.obs + (size_t)i * B + e0, out.ox[i].v);
+      else *reinterpret_cast<V*>(A.obs + (size_t)i * B + e0) = Vec<EPL>::make(out.ox[i].v);
+    }
+#pragma unroll
+  for (int k = 0; k < PCG_MAX_NSP; ++k)
+    if (k < nso) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) tmp[j] = out.osp[k];
+      if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + k) * B + e0, tmp);
+      else *reinterpret_cast<V*>(A.obs + (size_t)(nx + k) * B + e0) = Vec<EPL>::make(tmp);
+    }
+#pragma unroll
+  for (int k = 0; k < M::NDM; ++k)
+    if (k < c.nd) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) tmp[j] = out.od[k];
+      if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + nso + k) * B + e0, tmp);
+      else *reinterpret_cast<V*>(A.obs + (size_t)(nx + nso + k) * B + e0) = Vec<EPL>::make(tmp);
+    }
+  if (nt) Vec<EPL>::store_nt(A.rew + e0, out.rew.v);
+  else *reinterpret_cast<V*>(A.rew + e0) = Vec<EPL>::make(out.rew.v);
+  if (EPL == 2) *reinterpret_cast<uint16_t*>(A.done + e0) = out.done ? (uint16_t)0x0101u : (uint16_t)0;
+  else A.done[e0] = out.done ? 1 : 0;
+}
+
 template <class M, int INTEG, int EPL, int UNR>
 __global__ __launch_bounds__(BLOCK, (PCG_LEAN_WPE > wpe(M::NX, INTEG, false) ? PCG_LEAN_WPE : wpe(M::NX, INTEG, false)))
 void step_kernel_stream(const StepArgs A) {
@@ -800,34 +839,7 @@ void step_kernel_stream(const StepArgs A) {
           for (int j = 0; j < EPL; ++j) as[i].v[j] = (i < na) ? Vec<EPL>::get(av[u][i], j) : 0.0;
         LeanOut<M, EPL> out;
         env_step_lean<M, EPL>(A, c, t, as, xs, out);
-        double tmp[EPL];
-#pragma unroll
-        for (int i = 0; i < NX; ++i)
-          if (i < nx) {
-            *reinterpret_cast<V*>(A.x + (size_t)i * B + e0) = Vec<EPL>::make(xs[i].v);
-            if (nt) Vec<EPL>::store_nt(A.obs + (size_t)i * B + e0, out.ox[i].v);
-            else *reinterpret_cast<V*>(A.obs + (size_t)i * B + e0) = Vec<EPL>::make(out.ox[i].v);
-          }
-#pragma unroll
-        for (int k = 0; k < PCG_MAX_NSP; ++k)
-          if (k < nso) {
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) tmp[j] = out.osp[k];
-            if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + k) * B + e0, tmp);
-            else *reinterpret_cast<V*>(A.obs + (size_t)(nx + k) * B + e0) = Vec<EPL>::make(tmp);
-          }
-#pragma unroll
-        for (int k = 0; k < M::NDM; ++k)
-          if (k < c.nd) {
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) tmp[j] = out.od[k];
-            if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + nso + k) * B + e0, tmp);
-            else *reinterpret_cast<V*>(A.obs + (size_t)(nx + nso + k) * B + e0) = Vec<EPL>::make(tmp);
-          }
-        if (nt) Vec<EPL>::store_nt(A.rew + e0, out.rew.v);
-        else *reinterpret_cast<V*>(A.rew + e0) = Vec<EPL>::make(out.rew.v);
-        if (EPL == 2) *reinterpret_cast<uint16_t*>(A.done + e0) = out.done ? (uint16_t)0x0101u : (uint16_t)0;
-        else A.done[e0] = out.done ? 1 : 0;
+        store_lean<M, EPL>(A, c, e0, xs, out, nt);
       } else {
       EnvOut<M> out[EPL];
       double xs[EPL][NX];
@@ -945,34 +957,7 @@ __global__ __launch_bounds__(BLOCK, PCG_LEAN_WPE) void step_kernel_pipe(const St
         for (int j = 0; j < EPL; ++j) as[i].v[j] = (i < na) ? Vec<EPL>::get(av[i], j) : 0.0;
       LeanOut<M, EPL> out;
       env_step_lean<M, EPL>(A, c, t, as, xs, out);
-      double tmp[EPL];
-#pragma unroll
-      for (int i = 0; i < NX; ++i)
-        if (i < nx) {
-          *reinterpret_cast<V*>(A.x + (size_t)i * B + e0) = Vec<EPL>::make(xs[i].v);
-          if (nt) Vec<EPL>::store_nt(A.obs + (size_t)i * B + e0, out.ox[i].v);
-          else *reinterpret_cast<V*>(A.obs + (size_t)i * B + e0) = Vec<EPL>::make(out.ox[i].v);
-        }
-#pragma unroll
-      for (int k = 0; k < PCG_MAX_NSP; ++k)
-        if (k < nso) {
-#pragma unroll
-          for (int j = 0; j < EPL; ++j) tmp[j] = out.osp[k];
-          if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + k) * B + e0, tmp);
-          else *reinterpret_cast<V*>(A.obs + (size_t)(nx + k) * B + e0) = Vec<EPL>::make(tmp);
-        }
-#pragma unroll
-      for (int k = 0; k < M::NDM; ++k)
-        if (k < c.nd) {
-#pragma unroll
-          for (int j = 0; j < EPL; ++j) tmp[j] = out.od[k];
-          if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + nso + k) * B + e0, tmp);
-          else *reinterpret_cast<V*>(A.obs + (size_t)(nx + nso + k) * B + e0) = Vec<EPL>::make(tmp);
-        }
-      if (nt) Vec<EPL>::store_nt(A.rew + e0, out.rew.v);
-      else *reinterpret_cast<V*>(A.rew + e0) = Vec<EPL>::make(out.rew.v);
-      if (EPL == 2) *reinterpret_cast<uint16_t*>(A.done + e0) = out.done ? (uint16_t)0x0101u : (uint16_t)0;
-      else A.done[e0] = out.done ? 1 : 0;
+      store_lean<M, EPL>(A, c, e0, xs, out, nt);
     }
     if (itn >= ntile) break;
     it = itn;
