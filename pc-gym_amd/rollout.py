@@ -14,7 +14,7 @@ every array on the GPU in the reference's axis order:
 
 ``reps`` of the reference (independent repetitions of one env) is the env axis B here.
 Closed loop: ``policy(obs (B, Nobs) tensor) -> (B, na)`` (or ``(na, B)``) tensor, one
-kernel launch per step.  Open loop (``actions`` given, lean configuration): the fused
+kernel launch per step.  Open loop (``actions`` given, no constraint rows to record): the fused
 ``pcg_rollout_strided`` kernel writes straight into these layouts, state in registers.
 """
 from __future__ import annotations
@@ -76,13 +76,15 @@ def collect_rollouts(env, policy=None, actions=None):
     g = torch.zeros((s.ncon, N, 1, B), dtype=f64, device=dev) if s.ncon else None
     obs, _ = env.reset()
     x[:, 0] = _denorm_obs(env, env.obs_soa)
-    lean = not ((s.flags() & 0x02E4) or s.ncon)  # no noise / gaussian / a_delta / batch reward / constraints
+    # the fused rollout records observations and rewards, not the constraint rows; per-env parameters need the
+    # per-step kernel; the 20-state DOPRI5 rollout kernel is slower than stepping (tools/rollout_probe.py)
+    fused_ok = not s.ncon and not s.nunc and (s.integrator == "rk4" or s.nx <= 10)
     if actions is not None:
         actions = actions.to(device=dev, dtype=f64)
         if actions.shape != (N, s.na, B):
             raise ValueError(f"actions must have shape ({N},{s.na},{B})")
         u[:] = _denorm_act(env, actions.permute(1, 0, 2))
-        if lean and s.integrator == "rk4" and B % 2 == 0:
+        if fused_ok:
             # fused: the kernel writes normalised obs rows directly into x[:, 1:, :] / r[0, 1:, :]
             a = actions.contiguous()
             rc = env._lib.pcg_rollout_strided(

@@ -1054,7 +1054,10 @@ def test_affine_model_superposition():
     assert ((got - want).abs() / (1 + want.abs())).max().item() <= 1e-8
 
 
-@pytest.mark.parametrize("name", ["cstr_canonical", "four_tank_canonical", "cstr_cons_pen_raw"])
+# (crystallisation is left out: its o_space spans 1e20, and the reference's own rollout loses the moments when it
+# de-normalises the normalised observation, policy_evaluation.py:92-94,105-107 -- so does this one, faithfully)
+@pytest.mark.parametrize("name", ["cstr_canonical", "four_tank_canonical", "cstr_cons_pen_raw", "cstr_paper_reward",
+                                  "me_canonical"])
 def test_collect_rollouts_reference_axis_order(name):
     """row f-1: batched counterpart of policy_eval.rollout/get_rollouts (policy_evaluation.py:71-197):
     r (1,N,B), x (Nx,N,B), u (na,N,B), g (ncon,N,1,B) -- against the reference make_env recordings
