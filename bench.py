@@ -8,8 +8,8 @@ Workload (config.workload = "cstr_b2^20_rk4_fp64"):
   x0 ~ [U(0.7,1.0), U(310,334)] drawn in the reset kernel (Philox), actions ~ U(-1,1)
   pre-generated on the device (no policy cost), lock-stepped batch.
 A "step" = ONE pcg_step() launch over the whole batch (one env step for every env),
-episodes are 59 steps long, the reset kernel that ends each episode is inside the
-timed region.  value = total env-steps / wall time (max over ranks), whole job.
+episodes are 59 steps long; the reset that ends each episode is inside the timed region (fused into the
+episode's last step launch, pcg_step_autoreset).  value = total env-steps / wall time (max over ranks), whole job.
 
 Multi-GPU: the env batch shards embarrassingly (weak scaling, B per GPU fixed); no
 collective on the hot path -- torch.distributed (RCCL) is used only for the barrier
@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat-ms", type=float, default=100.0,
                     help="untimed GPU clock pre-heat before the warm-up steps (0 = off)")
+    ap.add_argument("--separate-reset", action="store_true",
+                    help="end each episode with a separate pcg_reset launch instead of the fused pcg_step_autoreset (A/B)")
     ap.add_argument("--graph", action="store_true",
                     help="replay whole episodes as one HIP graph (pcg_graph_*) instead of eager launches; "
                          "measured within 1 %% of eager once the GPU is warm, so eager stays the default")
@@ -214,7 +216,7 @@ def main():
     def run(n, timed):
         i = 0
         while i < n:
-            m = min(last_t - env.t, n - i)
+            m = min(last_t - env.t, n - i)  # steps left in this episode
             if timed:
                 eb = torch.cuda.Event(enable_timing=True)
                 ee = torch.cuda.Event(enable_timing=True)
@@ -224,7 +226,15 @@ def main():
             else:
                 for j in range(m):
                     buf.a = acts[(env.t) % n_act].data_ptr()
-                    rc = step_fn(plan, bufp, env.t, env._episode_seed(), sptr)
+                    if env.t == last_t - 1 and not args.separate_reset:
+                        # last step of the episode: the reset of the (lock-stepped) batch happens inside the same
+                        # launch (pcg_step_autoreset), with the next episode's RNG key
+                        seed = env._episode_seed()
+                        env.episode += 1
+                        rc = lib.pcg_step_autoreset(plan, bufp, env.t, seed, env._episode_seed(), sptr)
+                        env.t = -1
+                    else:
+                        rc = step_fn(plan, bufp, env.t, env._episode_seed(), sptr)
                     if rc:
                         _lib.check(rc, "pcg_step")
                     env.t += 1
@@ -232,7 +242,7 @@ def main():
                 ee.record(stream)
                 brackets.append((eb, ee, m))
             i += m
-            if env.t == last_t:
+            if env.t == last_t:  # after a graph replay or with --separate-reset
                 env.reset()
 
     # Clock pre-heat (untimed, before the W warm-up steps): an idle MI355X needs ~50 ms of work to reach

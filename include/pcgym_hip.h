@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 3
+#define PCG_ABI_VERSION 4
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -327,8 +327,11 @@ PCG_API int pcg_rollout_strided(pcg_plan* plan, const pcg_buffers* io, int32_t t
  * auto-reset: rew / done / viol are those of the finished step; x, obs, t, a_save and the per-env parameters are
  * those of the new episode, drawn with `reset_seed`).  Equivalent to pcg_step + pcg_reset(mask = io->done,
  * seed = reset_seed) -- the reference has no counterpart (its callers loop "if done: env.reset()",
- * policy_evaluation.py:86-128) -- but one launch instead of two.  Needs per-env step counters (io->t). */
-PCG_API int pcg_step_autoreset(pcg_plan* plan, const pcg_buffers* io, uint64_t seed, uint64_t reset_seed, void* stream);
+ * policy_evaluation.py:86-128) -- but one launch instead of two.  With per-env step counters (io->t) `t` is
+ * ignored; for a lock-stepped batch `t` is the shared counter and the caller restarts it at 0 after the call
+ * that returns done (t == N-2, or a constraint violation with PCG_F_DONE_ON_CONS ends single envs early). */
+PCG_API int pcg_step_autoreset(pcg_plan* plan, const pcg_buffers* io, int32_t t, uint64_t seed, uint64_t reset_seed,
+                               void* stream);
 
 /* Step graph: T consecutive pcg_step launches (t = t0 .. t0+T-1, optionally preceded by a full pcg_reset)
  * recorded once as a HIP graph and replayed with ONE host call.  This is the on-device form of the

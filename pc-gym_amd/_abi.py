@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PCG_ABI_VERSION = 3
+PCG_ABI_VERSION = 4
 PCG_MAX_NX = 24
 PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
@@ -201,7 +201,7 @@ def declare(lib):
     lib.pcg_rollout_strided.argtypes = [vp, C.POINTER(pcg_buffers), C.c_int32, C.c_int32, vp, C.c_int64, C.c_int64,
                                         vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_uint64, vp]
     lib.pcg_step_autoreset.restype = C.c_int
-    lib.pcg_step_autoreset.argtypes = [vp, C.POINTER(pcg_buffers), C.c_uint64, C.c_uint64, vp]
+    lib.pcg_step_autoreset.argtypes = [vp, C.POINTER(pcg_buffers), C.c_int32, C.c_uint64, C.c_uint64, vp]
     lib.pcg_graph_create.restype = C.c_int
     lib.pcg_graph_create.argtypes = [C.POINTER(vp), vp, C.POINTER(pcg_buffers), C.POINTER(vp), C.POINTER(vp),
                                      C.c_int32, C.c_int32, C.c_uint64, C.c_int]

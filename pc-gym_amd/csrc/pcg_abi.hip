@@ -69,7 +69,7 @@ struct pcg_plan {
   int nt_stores;     // PCG_OPT_NT_STORES
   int num_cus;
   int stream_occ[2]; // resident workgroups per CU of the stream kernels [EPL-1] (0 = not queried yet)
-  int pipe_occ[2];
+  int pipe_occ[2][2];  // [auto-reset instantiation][EPL-1]
   int64_t env_offset;
   DevConst hc;       // host copy
   DevConst* dC;      // device copy
@@ -354,7 +354,7 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   p->nt_stores = 1;  // measured: 20.3 -> 18.7 us per launch on the cstr workload (profiles/)
   p->num_cus = 0;
   p->stream_occ[0] = p->stream_occ[1] = 0;
-  p->pipe_occ[0] = p->pipe_occ[1] = 0;
+  p->pipe_occ[0][0] = p->pipe_occ[0][1] = p->pipe_occ[1][0] = p->pipe_occ[1][1] = 0;
   p->env_offset = 0;
   p->dC = nullptr;
   p->dsched = nullptr;
@@ -474,10 +474,10 @@ static int resident_blocks(StepFn fn) {
 static int warm_occupancy(pcg_plan* p) {
   const Kernels& k = kernels(p->kid);
   for (int e = 0; e < 2; ++e) {
-    if (p->integrator_id == PCG_INT_RK4 && k.pipe[e] && p->pipe_occ[e] == 0) {
+    if (p->integrator_id == PCG_INT_RK4 && k.pipe[e] && p->pipe_occ[0][e] == 0) {
       const int q = resident_blocks(k.pipe[e]);
       if (q < 0) return -q;
-      p->pipe_occ[e] = q;
+      p->pipe_occ[0][e] = q;
     }
     if (k.stream[p->integrator_id][e] && p->stream_occ[e] == 0) {
       const int q = resident_blocks(k.stream[p->integrator_id][e]);
@@ -539,7 +539,9 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   // lanes take different numbers of steps, and a persistent grid fixes each wave's share of the batch up front,
   // whereas the dispatcher hands single-wave workgroups to whichever SIMD slot frees first.
   const bool stream_ok = p->integrator_id == PCG_INT_RK4 || p->variant == 2 || p->variant == 3;
-  if (!per_env_t && !extras && !lds_st && !io->viol && p->variant != 1 && stream_ok && k.stream[p->integrator_id][0]) {
+  const bool lean_ar_ok = !auto_reset || ((p->variant == 4 || p->variant == 0) && p->integrator_id == PCG_INT_RK4 && k.pipe[0]);
+  if (!per_env_t && !extras && !lds_st && !io->viol && p->variant != 1 && stream_ok && lean_ar_ok &&
+      k.stream[p->integrator_id][0]) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool epl2_ok = k.stream[p->integrator_id][1] && (io->B % 2 == 0) && al16(io->x) && al16(io->a) &&
                          al16(io->obs) && al16(io->rew) && (reinterpret_cast<uintptr_t>(io->done) & 1u) == 0;
@@ -549,8 +551,8 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
     // auto (0): the software-pipelined kernel where it exists (measured best on the cstr workload:
     // 14.9 us vs 15.0 two-sub-tile streaming vs 16.9 plain streaming vs 21 classic, profiles/r1)
     const bool piped = (p->variant == 4 || p->variant == 0) && p->integrator_id == PCG_INT_RK4 && k.pipe[epl - 1];
-    if (piped) sfn = k.pipe[epl - 1];
-    int& occ = piped ? p->pipe_occ[epl - 1] : p->stream_occ[epl - 1];
+    if (piped) sfn = auto_reset ? k.pipe_ar[epl - 1] : k.pipe[epl - 1];
+    int& occ = piped ? p->pipe_occ[auto_reset ? 1 : 0][epl - 1] : p->stream_occ[epl - 1];
     if (occ == 0) {
       const int q = resident_blocks(sfn);
       if (q < 0) return -q;
@@ -577,10 +579,9 @@ int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void*
   return step_impl(p, io, t, seed, stream, false, 0);
 }
 
-int pcg_step_autoreset(pcg_plan* p, const pcg_buffers* io, uint64_t seed, uint64_t reset_seed, void* stream) {
-  if (io && !io->t && io->B > 0) return PCG_E_UNSUPPORTED;  // a lock-stepped batch resets as a whole: pcg_reset
+int pcg_step_autoreset(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, uint64_t reset_seed, void* stream) {
   if (plan_ok(p) && io && p->hc.nunc > 0 && !io->p_unc) return PCG_E_NULL;
-  return step_impl(p, io, 0, seed, stream, true, reset_seed);
+  return step_impl(p, io, t, seed, stream, true, reset_seed);
 }
 
 int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t T, const double* a_seq,

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG), wpe(M::NX, INTEG, LDS_STAGES
   for (int i = 0; i < NA; ++i) a[i] = (i < na) ? A.a[(size_t)i * B + e] : 0.0;
   EnvOut<M> out;
   env_step<M, INTEG, PER_ENV_T, LDS_STAGES, EXTRAS, UNC>(A, c, sched_l, stage_l, e, t, a, x, out);
-  if (PER_ENV_T && A.auto_reset && out.done) {
+  if (A.auto_reset && out.done) {
     // gymnasium "same-step" auto-reset in the same launch: reward / done / viol of the finished step are kept,
     // state, observation, step counter (and a_delta accumulator, per-env parameters) are those of the new episode
     __builtin_nontemporal_store(out.rew, A.rew + e);
@@ -906,7 +906,11 @@ void step_kernel_stream(const StepArgs A) {
 // compiler can only wait with vmcnt(0) once stores are pending; waiting BEFORE the prefetch is issued
 // keeps the prefetch out of that wait.
 // ---------------------------------------------------------------------------
-template <class M, int EPL>
+// AR: the instantiation launched for the LAST step of a lock-stepped episode with same-launch auto-reset
+// (pcg_step_autoreset).  It is a separate instantiation because the inlined reset path (Philox draws for the x0 /
+// parameter uncertainty) raises the register count of the whole kernel from 75 to 118 (6 -> 4 waves per SIMD);
+// the other N-2 steps of the episode run the lean one.
+template <class M, int EPL, bool AR = false>
 __global__ __launch_bounds__(BLOCK, PCG_LEAN_WPE) void step_kernel_pipe(const StepArgs A) {
   CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA;
@@ -957,7 +961,18 @@ __global__ __launch_bounds__(BLOCK, PCG_LEAN_WPE) void step_kernel_pipe(const St
         for (int j = 0; j < EPL; ++j) as[i].v[j] = (i < na) ? Vec<EPL>::get(av[i], j) : 0.0;
       LeanOut<M, EPL> out;
       env_step_lean<M, EPL>(A, c, t, as, xs, out);
-      store_lean<M, EPL>(A, c, e0, xs, out, nt);
+      if (AR && A.auto_reset && out.done) {
+        // last step of a lock-stepped episode with same-launch auto-reset: reward / done of the finished step,
+        // then the new episode's state and observation instead of the terminal ones (pcg_step_autoreset)
+        if (nt) Vec<EPL>::store_nt(A.rew + e0, out.rew.v);
+        else *reinterpret_cast<V*>(A.rew + e0) = Vec<EPL>::make(out.rew.v);
+        if (EPL == 2) *reinterpret_cast<uint16_t*>(A.done + e0) = (uint16_t)0x0101u;
+        else A.done[e0] = 1;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) reset_env(A, c, e0 + j, A.reset_seed);
+      } else {
+        store_lean<M, EPL>(A, c, e0, xs, out, nt);
+      }
     }
     if (itn >= ntile) break;
     it = itn;
@@ -1173,6 +1188,7 @@ struct Kernels {
   StepFn stream[PCG_INT_COUNT][2];      // persistent streaming kernel [integrator][EPL-1] (entries may be null)
   StepFn step_unc[PCG_INT_COUNT][2]; // per-env parameter uncertainty [integrator][per_env_t] (null for affine)
   StepFn pipe[2];                    // RK4 software-pipelined lean kernel [EPL-1] (may be null)
+  StepFn pipe_ar[2];                 // the same with the same-launch auto-reset path compiled in [EPL-1]
   StepFn roll_lean[2];               // RK4 lean fused rollout [EPL-1] (may be null)
   StepFn rollout[PCG_INT_COUNT][2];  // [integrator][lds_stages]
   RhsKFn rhs;
@@ -1225,6 +1241,8 @@ Kernels make_kernels() {
       k.roll_lean[1] = rollout_kernel_lean<M, 2>;
       k.pipe[0] = step_kernel_pipe<M, 1>;
       k.pipe[1] = step_kernel_pipe<M, 2>;
+      k.pipe_ar[0] = step_kernel_pipe<M, 1, true>;
+      k.pipe_ar[1] = step_kernel_pipe<M, 2, true>;
       k.stream[PCG_INT_RK4][1] = step_kernel_stream<M, PCG_INT_RK4, 2, 1>;
     }
   }

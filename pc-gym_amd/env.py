@@ -219,24 +219,26 @@ class VecEnv:
             self._buf.d = d.data_ptr()
         else:
             self._buf.d = None
-        fused_reset = self.auto_reset and self.per_env_t
-        if fused_reset:  # step + reset of what finished, one launch; every step opens a new RNG epoch for the resets
+        # same-launch auto-reset: every step with per-env counters (envs end at different times), only the last step
+        # of the episode for a lock-stepped batch (all envs end together at t = N-2)
+        fused_reset = self.auto_reset and (self.per_env_t or self.t == self.N - 2)
+        if fused_reset:
             seed = self._episode_seed()
-            self.episode += 1
-            _lib.check(self._lib.pcg_step_autoreset(self._plan, self._bufp, seed, self._episode_seed(), self._stream()),
-                       "pcg_step_autoreset")
+            self.episode += 1  # the resets open the next RNG epoch
+            _lib.check(self._lib.pcg_step_autoreset(self._plan, self._bufp, self.t, seed, self._episode_seed(),
+                                                    self._stream()), "pcg_step_autoreset")
         else:
             _lib.check(self._lib.pcg_step(self._plan, self._bufp, self.t, self._episode_seed(), self._stream()),
                        "pcg_step")
         self.t += 1
+        if fused_reset and not self.per_env_t:
+            self.t = 0  # the new episode started inside the launch
         info = {}
         if s.ncon:
             info["viol"] = self.viol
             info["g"] = self.g
         if self.nsteps is not None:
             info["nsteps"] = self.nsteps
-        if self.auto_reset and not self.per_env_t and self.t == self.N - 1:
-            self.reset()
         return self.obs, self.rew, self.done.view(_torch().bool), False, info
 
     def rollout(self, actions, collect_obs=False, collect_rew=True):

@@ -853,6 +853,48 @@ def test_random_configurations_rollout_equals_stepping(seed):
     e2.close()
 
 
+@pytest.mark.parametrize("name,B", [("cstr_canonical", 4096), ("cstr_canonical", 777), ("four_tank_canonical", 1024),
+                                    ("me_canonical", 300), ("cstr_cons_pen_norm", 512)])
+def test_lock_stepped_auto_reset_in_the_last_step_launch(name, B):
+    """VecEnv(auto_reset=True), lock-stepped: the episode's last step launch also resets the batch
+    (pcg_step_autoreset; lean pipelined kernel for cstr / four_tank with even B, general kernel otherwise) ==
+    oracle step followed by a full reset with the next episode's seed."""
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    p = copy.deepcopy(SC.scenarios()[name]["env_params"])
+    N = 9
+    p["N"], p["tsim"] = N, N * float(p["tsim"]) / p["N"]
+    p["SP"] = {k: list(np.asarray(v, dtype=float)[:N]) for k, v in p["SP"].items()}
+    nx = {"cstr": 2, "four_tank": 4, "multistage_extraction": 10}[p["model"]]
+    p.update(uncertainty_percentages={"x0": [0.02] * nx}, distribution="uniform")
+    env = VecEnv(p, n_envs=B, seed=70, auto_reset=True)
+    orc = O.OracleEnv(env.spec, B, seed=70)
+    env.reset()
+    orc.reset()
+    tol = 1e-8 if env.spec.integrator == "dopri5" else 1e-11
+    for i in range(2 * (N - 1) + 3):
+        a = np.random.default_rng(i).uniform(-1, 1, (env.spec.na, B))
+        if env.spec.model.name.startswith("multistage"):
+            a = 0.3 * a - 0.6
+        og, rg, dg, _, _ = env.step(torch.tensor(a, device=env.device))
+        oc, rc, dc = orc.step(a)
+        rc, dc = rc.copy(), dc.copy()
+        last = orc.t == N - 1
+        if last:
+            orc.reset()  # episode + 1 on both sides
+        assert np.array_equal(dg.cpu().numpy().astype(np.uint8), dc), i
+        assert bool(dc.all()) == last
+        assert np.allclose(rg.cpu().numpy(), rc, rtol=tol * 100, atol=1e-10), i
+        assert np.allclose(env.x.cpu().numpy(), orc.x, rtol=tol, atol=0), i
+        assert np.allclose(og.cpu().numpy().T, orc.obs, rtol=tol * 10, atol=tol * 10), i
+        assert env.t == orc.t and env.episode == orc.episode
+    env.close()
+
+
 # ------------------------------------------------ full-size property tests ---
 def test_full_size_cstr_properties():
     """BASELINE.json configs[1] size (B = 2^20): size-independent properties.
