@@ -316,7 +316,8 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": "step_kernel_pipe<Model<cstr>, EPL=2> (RK4, lean, lock-stepped, software-pipelined)",
+            "kernel": "step_kernel_pipe<Model<cstr>, EPL=2> (RK4, lean, lock-stepped, software-pipelined; 1 launch in 59 is "
+                      "its auto-reset instantiation, which also resets the batch)",
             "kernel_avg_us": kern_avg_s * 1e6,
             "algorithmic_bytes_per_env_step": int(bytes_per_env_step),
             "algorithmic_bytes_per_launch": alg_bytes,
