@@ -774,6 +774,63 @@ PCG_DEV void store_lean(const StepArgs& A, CDevConst& c, int64_t e0, const Pack<
   else A.done[e0] = out.done ? 1 : 0;
 }
 
+// reset of the EPL consecutive envs of one lean lane (lock-stepped batch, no per-env parameters / a_delta: those
+// configurations never reach the lean kernels): same draws as reset_env, stored 16 bytes per lane and row
+template <class M, int EPL>
+PCG_DEV void reset_lean(const StepArgs& A, CDevConst& c, int64_t e0, uint64_t seed, bool nt) {
+  using V = typename Vec<EPL>::T;
+  constexpr int NX = M::NX;
+  const int64_t B = A.B;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  const int nso = c.nsp_obs, nd = c.nd;
+  double tmp[EPL], tob[EPL];
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    if (i < nx) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        double v = c.x0[i];
+        if (c.has_x0_unc && c.x0_unc[i] != 0.0) {  // apply_uncertainties, pcgym.py:255-261
+          const uint64_t env_id = (uint64_t)(A.env_offset + e0 + j);
+          const double pct = c.x0_unc[i];
+          if (c.flags & PCG_F_X0_NORMAL) {
+            double z0, z1;
+            rng_normal2(seed, env_id, 0u, RNG_RESET + (uint32_t)(i >> 1), z0, z1);
+            v = c.x0[i] + pct * c.x0[i] * ((i & 1) ? z1 : z0);
+          } else {
+            double u0, u1;
+            rng_uniform2(seed, env_id, 0u, RNG_RESET + (uint32_t)(i >> 1), u0, u1);
+            v = c.x0[i] * (1 + pct * (2.0 * ((i & 1) ? u1 : u0) - 1.0));
+          }
+        }
+        tmp[j] = v;
+        tob[j] = (v - c.omap[i].lo) * c.omap[i].sc + c.omap[i].off;
+      }
+      *reinterpret_cast<V*>(A.x + (size_t)i * B + e0) = Vec<EPL>::make(tmp);
+      if (nt) Vec<EPL>::store_nt(A.obs + (size_t)i * B + e0, tob);
+      else *reinterpret_cast<V*>(A.obs + (size_t)i * B + e0) = Vec<EPL>::make(tob);
+    }
+#pragma unroll
+  for (int k = 0; k < PCG_MAX_NSP; ++k)
+    if (k < nso) {
+      const double o = (c.x0[nx + k] - c.omap[nx + k].lo) * c.omap[nx + k].sc + c.omap[nx + k].off;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) tob[j] = o;
+      if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + k) * B + e0, tob);
+      else *reinterpret_cast<V*>(A.obs + (size_t)(nx + k) * B + e0) = Vec<EPL>::make(tob);
+    }
+#pragma unroll
+  for (int k = 0; k < M::NDM; ++k)
+    if (k < nd) {  // disturbances[k][0] (pcgym.py:291-298, quirk Q6)
+      const int q = nx + nso + k;
+      const double o = (A.sched[(size_t)(c.nsp + k) * c.N] - c.omap[q].lo) * c.omap[q].sc + c.omap[q].off;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) tob[j] = o;
+      if (nt) Vec<EPL>::store_nt(A.obs + (size_t)q * B + e0, tob);
+      else *reinterpret_cast<V*>(A.obs + (size_t)q * B + e0) = Vec<EPL>::make(tob);
+    }
+}
+
 template <class M, int INTEG, int EPL, int UNR>
 __global__ __launch_bounds__(BLOCK, (PCG_LEAN_WPE > wpe(M::NX, INTEG, false) ? PCG_LEAN_WPE : wpe(M::NX, INTEG, false)))
 void step_kernel_stream(const StepArgs A) {
@@ -968,8 +1025,7 @@ __global__ __launch_bounds__(BLOCK, PCG_LEAN_WPE) void step_kernel_pipe(const St
         else *reinterpret_cast<V*>(A.rew + e0) = Vec<EPL>::make(out.rew.v);
         if (EPL == 2) *reinterpret_cast<uint16_t*>(A.done + e0) = (uint16_t)0x0101u;
         else A.done[e0] = 1;
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) reset_env(A, c, e0 + j, A.reset_seed);
+        reset_lean<M, EPL>(A, c, e0, A.reset_seed, nt);
       } else {
         store_lean<M, EPL>(A, c, e0, xs, out, nt);
       }
