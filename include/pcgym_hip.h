@@ -21,7 +21,8 @@
  *   - every entry point returns an int status: 0 = ok, <0 = PCG_E_* (bad
  *     argument), >0 = a hipError_t.  Nothing throws, nothing calls exit().
  *   - all device buffers are caller-owned (e.g. torch tensors); the library
- *     allocates only the opaque plan (a few KB of device constants).
+ *     allocates only the opaque plan (a few KB of device constants, the schedules and
+ *     sample tables) and, on request, step-graph objects.
  *   - launches are asynchronous on the hipStream_t passed as `stream`
  *     (NULL = the default stream).  One plan may be driven by one host thread at
  *     a time; distinct plans / streams / devices are independent.
