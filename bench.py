@@ -115,10 +115,18 @@ def cpu_baseline(spec, seconds_target=12.0):
         e1.step(a)
         e2.step(a)
         worst = max(worst, float(np.max(np.abs(e1.x - e2.x) / np.abs(e2.x))))
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {
         "value": value,
         "unit": "env-steps/s",
         "cores": cores,
+        "host_cpu": cpu_model,
+        "host_logical_cpus": os.cpu_count(),
         "cores_probe_env_steps_per_s": {str(k): v for k, v in probe.items()},
         "kind": "port",
         "sample": f"{reps} steps x {Bs} envs of the same cstr/RK4 workload, OpenMP over {cores} host threads "
