@@ -178,7 +178,7 @@ PCG_DEV void rng_normal2(uint64_t seed, uint64_t env, uint32_t t, uint32_t strea
   // 1 - u0 is in [2^-53, 1]: the range-restricted log / sqrt of pcg_pack.hpp apply (<= 2 ulp of the library forms)
   const double r = sqrt_pos(-2.0 * log_pos(1.0 - u0));
   double s, c;
-  sincospi(2.0 * u1, &s, &c);  // angle = 2*pi*u1, u1 in [0,1): no large-argument reduction
+  sincospi_unit(2.0 * u1, s, c);  // angle = 2*pi*u1, u1 in [0,1)
   z0 = r * c;
   z1 = r * s;
 }

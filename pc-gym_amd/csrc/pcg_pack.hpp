@@ -151,6 +151,36 @@ PCG_PK Pack<W> log_pos(const Pack<W>& a) {
   for (int i = 0; i < W; ++i) r.v[i] = log_pos(a.v[i]);
   return r;
 }
+// sin(pi x), cos(pi x) for x in [0, 2) (the Box-Muller angle 2 u, u in [0,1)): exact reduction to r in [-1/4, 1/4]
+// by quarter turns, Taylor polynomials of sin / cos in y = pi r (|y| <= pi/4: truncation 5e-17 / 2e-18), quadrant
+// fix-up.  ~35 VALU instructions against ~75 for the library sincospi (which also handles huge / non-finite x).
+PCG_PK void sincospi_unit(double x, double& s, double& c) {
+  const double n = __builtin_rint(x + x);  // quarter-turn index 0..4
+  const double y = __builtin_fma(n, -0.5, x) * 3.14159265358979323846;
+  const double z = y * y;
+  double ps = -1.0 / 1307674368000.0;             // -1/15!
+  ps = __builtin_fma(ps, z, 1.0 / 6227020800.0);  //  1/13!
+  ps = __builtin_fma(ps, z, -1.0 / 39916800.0);   // -1/11!
+  ps = __builtin_fma(ps, z, 1.0 / 362880.0);      //  1/9!
+  ps = __builtin_fma(ps, z, -1.0 / 5040.0);       // -1/7!
+  ps = __builtin_fma(ps, z, 1.0 / 120.0);         //  1/5!
+  ps = __builtin_fma(ps, z, -1.0 / 6.0);          // -1/3!
+  const double sy = __builtin_fma(y * z, ps, y);
+  double pc = 1.0 / 20922789888000.0;             //  1/16!
+  pc = __builtin_fma(pc, z, -1.0 / 87178291200.0);  // -1/14!
+  pc = __builtin_fma(pc, z, 1.0 / 479001600.0);   //  1/12!
+  pc = __builtin_fma(pc, z, -1.0 / 3628800.0);    // -1/10!
+  pc = __builtin_fma(pc, z, 1.0 / 40320.0);       //  1/8!
+  pc = __builtin_fma(pc, z, -1.0 / 720.0);        // -1/6!
+  pc = __builtin_fma(pc, z, 1.0 / 24.0);          //  1/4!
+  pc = __builtin_fma(pc, z, -0.5);
+  const double cy = __builtin_fma(z, pc, 1.0);
+  const int q = (int)n & 3;
+  const double ss = (q & 1) ? cy : sy, cc = (q & 1) ? sy : cy;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // sqrt(x) for x >= 0 in the normal range (exact 0 handled; negative -> NaN like the library): hardware
 // reciprocal-square-root estimate, one coupled Goldschmidt step, two residual corrections.  ~13 VALU instructions
 // against ~25 for the library sqrt(), whose extra work is the 2^+-256 rescaling for huge / denormal arguments.
