@@ -13,8 +13,9 @@ def run(label, extra, per_env_t=False):
     p = BN.workload_params(B); p.update(extra)
     env = VecEnv(p, n_envs=B, seed=1, per_env_t=per_env_t, auto_reset=True); env.reset()
     acts = 2 * torch.rand((16, 1, B), device=env.device, dtype=torch.float64) - 1
-    for i in range(600): env.step(acts[i % 16])
-    torch.cuda.synchronize(); t0 = time.perf_counter(); K = 3000
+    W, K = int(os.environ.get("PROBE_WARM", 600)), int(os.environ.get("PROBE_STEPS", 3000))
+    for i in range(W): env.step(acts[i % 16])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(K): env.step(acts[i % 16])
     torch.cuda.synchronize(); w = time.perf_counter() - t0
     bpe = env.bytes_per_env_step
