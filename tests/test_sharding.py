@@ -74,8 +74,13 @@ def test_world_size_2_gloo_sharded_run_equals_single_device_run(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, PCG_ROOT=ROOT, OMP_NUM_THREADS="1")
+    import socket
+
+    with socket.socket() as sk:  # any free port: a fixed one can still be held by an earlier run
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "SHARD_OK" in r.stdout
