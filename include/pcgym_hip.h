@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 4
+#define PCG_ABI_VERSION 5
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -63,6 +63,14 @@ extern "C" {
 #define PCG_E_VALUE -4       /* invalid scalar (dt<=0, substeps<1, ...)  */
 #define PCG_E_PLAN -5        /* plan handle invalid / wrong device       */
 #define PCG_E_UNSUPPORTED -6 /* combination not built                    */
+
+/* per-env health of a step, written to pcg_buffers.status (the reference's CVODES raises on an integration
+ * failure, integrator.py:90-107; a batched kernel cannot raise per env, so it reports) */
+#define PCG_ST_OK 0         /* the step was integrated over the full [0,dt] and the state is finite        */
+#define PCG_ST_MAX_STEPS 1  /* DOPRI5: step budget (cfg.max_steps) exhausted before dt; state set to NaN    */
+#define PCG_ST_UNDERFLOW 2  /* DOPRI5: step size underflow (blow-up / NaN right-hand side); state NaN      */
+#define PCG_ST_NONFINITE 3  /* the integrator finished but the state is not finite (e.g. fixed-step RK4
+                               outside its stability region, model_classes.py:1313 division by zero)     */
 
 /* model ids: the reference registry keys (pcgym.py:128-148) that are on the hot path */
 enum pcg_model {
@@ -238,6 +246,9 @@ typedef struct pcg_buffers {
                                             leaves it alone, as the reference never clears u_prev              */
   double* p_unc;      /* [nunc][B]  in/out  per-env values of the uncertain parameters: written by
                                             pcg_reset, read by pcg_step (required when nunc > 0)        */
+  uint8_t* status;    /* [B]        out|NULL PCG_ST_* of this step for every env.  An env whose adaptive
+                                            integration fails gets a NaN state (never a silently wrong one)
+                                            whether or not this buffer is given                         */
 } pcg_buffers;
 
 typedef struct pcg_plan pcg_plan; /* opaque */

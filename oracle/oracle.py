@@ -93,6 +93,7 @@ class OracleEnv:
         self.rew = np.zeros(B)
         self.done = np.zeros(B, dtype=np.uint8)
         self.viol = np.zeros(B, dtype=np.uint8)
+        self.status = np.zeros(B, dtype=np.uint8)
         self.slots = np.zeros((max(s.nsp + s.nd + s.nunc, 1), B))
         self.p_unc = np.zeros((s.nunc, B)) if s.nunc else None
         self.a_save = np.zeros((s.na, B)) if s.a_delta else None
@@ -108,6 +109,7 @@ class OracleEnv:
                                                  _p(self.nsteps))
         b.p_unc = _p(self.p_unc)
         b.u_prev = _p(self.u_prev)
+        b.status = _p(self.status)
 
     def _seed(self):
         return (self.seed0 + self.episode) & 0xFFFFFFFFFFFFFFFF

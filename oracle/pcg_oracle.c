@@ -404,6 +404,17 @@ static double rms_scaled(const double* v, const double* y0, const double* y1, in
   return sqrt(s / n);
 }
 
+/* Step-size factors are quantised to 6 mantissa bits (truncation) -- part of the controller's specification
+ * (DESIGN.md "Adaptive stepping"): the grid makes the step-size sequence independent of how E^(-1/5) is evaluated
+ * (this double pow() here, the fp32 log2/exp2 units in the kernels), so both sides take bit-identical steps. */
+static double qtrunc6(double v) {
+  uint64_t b;
+  memcpy(&b, &v, 8);
+  b &= ~((UINT64_C(1) << 46) - 1);
+  memcpy(&v, &b, 8);
+  return v;
+}
+
 static int dopri5(const orc_model* m, double* x, const double* u, double dt, double rtol, double atol,
                   int max_steps, int32_t* nacc, int32_t* nrej) {
   static const double c2 = 1.0 / 5, c3 = 3.0 / 10, c4 = 4.0 / 5, c5 = 8.0 / 9;
@@ -435,8 +446,8 @@ static int dopri5(const orc_model* m, double* x, const double* u, double dt, dou
     for (int i = 0; i < nx; ++i) err[i] = k2[i] - k1[i];
     double d2 = rms_scaled(err, x, x, nx, rtol, atol) / h0;
     double dm = d1 > d2 ? d1 : d2;
-    double h1 = (dm <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / dm, 0.2);
-    h = fmin(100.0 * h0, h1);
+    double h1 = (dm <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : qtrunc6(pow(0.01 / dm, 0.2));
+    h = qtrunc6(fmin(100.0 * h0, h1));
     if (h > dt) h = dt;
   }
   double t = 0.0;
@@ -464,7 +475,7 @@ static int dopri5(const orc_model* m, double* x, const double* u, double dt, dou
       err[i] = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * k7[i]);
     double E = rms_scaled(err, x, ynew, nx, rtol, atol);
     if (E < 1.0) {
-      double f = (E == 0.0) ? 10.0 : fmin(10.0, fmax(0.2, 0.9 * pow(E, -0.2)));
+      double f = (E == 0.0) ? 10.0 : fmin(10.0, fmax(0.2, qtrunc6(0.9 * pow(E, -0.2))));
       if (rejected_last && f > 1.0) f = 1.0;
       t += h;
       h *= f;
@@ -474,7 +485,7 @@ static int dopri5(const orc_model* m, double* x, const double* u, double dt, dou
       if (last) break; /* reached dt */
     } else {
       /* also the NaN path: E is NaN -> comparison false -> shrink hardest */
-      double f = (E == E) ? fmax(0.2, 0.9 * pow(E, -0.2)) : 0.2;
+      double f = (E == E) ? fmax(0.2, qtrunc6(0.9 * pow(E, -0.2))) : 0.2;
       if (f > 1.0) f = 1.0;
       h *= f;
       rejected_last = 1;
@@ -484,6 +495,8 @@ static int dopri5(const orc_model* m, double* x, const double* u, double dt, dou
   }
   if (nacc) *nacc = acc;
   if (nrej) *nrej = rej;
+  if (status != 0) /* gave up at some t < dt: never hand back a partially integrated state (CVODES would raise) */
+    for (int i = 0; i < nx; ++i) x[i] = NAN;
   return status;
 }
 
@@ -595,6 +608,7 @@ typedef struct {
   double* g;      /* [ncon] or NULL */
   double* g_pre;  /* [ncon] or NULL */
   int32_t nacc, nrej;
+  uint8_t status; /* PCG_ST_* */
   double uk[PCG_MAX_NU];
 } orc_out;
 
@@ -650,8 +664,13 @@ static void env_step(const pcg_env_cfg* c, orc_env* e, const double* action_in, 
   /* integrate :423-429 */
   orc_model m = {c->model_id, nx, nu, params}; /* per-env parameters when uncertain (pcgym.py:301-310) */
   o->nacc = o->nrej = 0;
+  int ist = 0;
   if (c->integrator_id == PCG_INT_RK4) rk4(&m, e->state, uk, c->dt, c->substeps);
-  else dopri5(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
+  else ist = dopri5(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
+  if (ist == 0)
+    for (int i = 0; i < nx; ++i)
+      if (!isfinite(e->state[i])) ist = PCG_ST_NONFINITE;
+  o->status = (uint8_t)ist;
   /* SP slot :432-438 uses SP[k][t] with the OLD t (Q5) */
   for (int k = 0; k < c->nsp_obs; ++k) e->state[nx + k] = c->sp[(size_t)k * c->N + tc];
   e->t = t + 1; /* :441 */
@@ -856,6 +875,7 @@ ORC_EXPORT int orc_step(const pcg_env_cfg* c, const pcg_buffers* io, double* slo
     io->rew[b] = o.rew;
     io->done[b] = o.done;
     if (io->viol) io->viol[b] = o.viol;
+    if (io->status) io->status[b] = o.status;
     if (io->g)
       for (int i = 0; i < ncon; ++i) io->g[(size_t)i * B + b] = g[i];
     if (io->g_pre && t_old == 0)

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PCG_ABI_VERSION = 4
+PCG_ABI_VERSION = 5
 PCG_MAX_NX = 24
 PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
@@ -20,6 +20,10 @@ PCG_MAX_NU = PCG_MAX_NA + PCG_MAX_NDM
 PCG_MAX_N = 4096
 
 PCG_OK = 0
+PCG_ST_OK = 0
+PCG_ST_MAX_STEPS = 1
+PCG_ST_UNDERFLOW = 2
+PCG_ST_NONFINITE = 3
 PCG_E_NULL = -1
 PCG_E_MODEL = -2
 PCG_E_DIM = -3
@@ -133,6 +137,7 @@ class pcg_buffers(C.Structure):
         ("nsteps", C.c_void_p),
         ("u_prev", C.c_void_p),
         ("p_unc", C.c_void_p),
+        ("status", C.c_void_p),
     ]
 
 

@@ -2,6 +2,7 @@
 // objects, host-side kernel dispatch, and the model-independent reset kernel.  The kernel templates
 // live in pcg_kernels.hpp; each model's instantiations are compiled in a pcg_inst_*.hip unit.
 #include "pcg_kernels.hpp"
+#include "pcg_step_feat.hpp"
 
 namespace pcg {
 
@@ -70,6 +71,7 @@ struct pcg_plan {
   int num_cus;
   int stream_occ[2]; // resident workgroups per CU of the stream kernels [EPL-1] (0 = not queried yet)
   int pipe_occ[2][2];  // [auto-reset instantiation][EPL-1]
+  int feat_occ[MAX_FEAT];  // resident workgroups per CU of the feature-masked kernels (0 = not queried yet)
   int64_t env_offset;
   DevConst hc;       // host copy
   DevConst* dC;      // device copy
@@ -355,6 +357,7 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   p->num_cus = 0;
   p->stream_occ[0] = p->stream_occ[1] = 0;
   p->pipe_occ[0][0] = p->pipe_occ[0][1] = p->pipe_occ[1][0] = p->pipe_occ[1][1] = 0;
+  for (int i = 0; i < MAX_FEAT; ++i) p->feat_occ[i] = 0;
   p->env_offset = 0;
   p->dC = nullptr;
   p->dsched = nullptr;
@@ -431,6 +434,7 @@ int64_t pcg_plan_bytes_per_env_step(const pcg_plan* p, const pcg_buffers* io) {
   if ((c.flags & PCG_F_A_DELTA) && io->a_save) A += 16 * c.na;
   if ((c.flags & PCG_F_REWARD_TRACK) && io->u_prev) A += 16 * c.na;
   if (io->nsteps) A += 8;
+  if (io->status) A += 1;
   A += 16 * c.nunc;  // per-env parameters read + their observation slots written
   return A;
 }
@@ -446,6 +450,7 @@ static int fill_args(const pcg_plan* p, const pcg_buffers* io, StepArgs* a) {
   a->nsteps = io->nsteps; a->B = io->B; a->env_offset = p->env_offset;
   a->p_unc = io->p_unc;
   a->u_prev = io->u_prev;
+  a->status = io->status;
   return PCG_OK;
 }
 
@@ -485,6 +490,13 @@ static int warm_occupancy(pcg_plan* p) {
       p->stream_occ[e] = q;
     }
   }
+  if (p->integrator_id == PCG_INT_RK4)
+    for (int i = 0; i < k.nfeat; ++i)
+      if (p->feat_occ[i] == 0) {
+        const int q = resident_blocks(k.feat[i].fn);
+        if (q < 0) return -q;
+        p->feat_occ[i] = q;
+      }
   return PCG_OK;
 }
 
@@ -540,11 +552,12 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   // whereas the dispatcher hands single-wave workgroups to whichever SIMD slot frees first.
   const bool stream_ok = p->integrator_id == PCG_INT_RK4 || p->variant == 2 || p->variant == 3;
   const bool lean_ar_ok = !auto_reset || ((p->variant == 4 || p->variant == 0) && p->integrator_id == PCG_INT_RK4 && k.pipe[0]);
-  if (!per_env_t && !extras && !lds_st && !io->viol && p->variant != 1 && stream_ok && lean_ar_ok &&
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+  auto al2 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 1u) == 0; };
+  if (!per_env_t && !extras && !lds_st && !io->viol && !io->status && p->variant != 1 && stream_ok && lean_ar_ok &&
       k.stream[p->integrator_id][0]) {
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool epl2_ok = k.stream[p->integrator_id][1] && (io->B % 2 == 0) && al16(io->x) && al16(io->a) &&
-                         al16(io->obs) && al16(io->rew) && (reinterpret_cast<uintptr_t>(io->done) & 1u) == 0;
+                         al16(io->obs) && al16(io->rew) && al2(io->done);
     int epl = (p->variant == 2) ? 1 : (epl2_ok ? 2 : 1);
     if (p->variant == 3 && !epl2_ok) return PCG_E_UNSUPPORTED;
     StepFn sfn = k.stream[p->integrator_id][epl - 1];
@@ -567,6 +580,48 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
     a.nt_stores = p->nt_stores;
     hipLaunchKernelGGL(sfn, dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
+  }
+  // Feature-masked pipelined kernel (pcg_step_feat.hpp): RK4 plans of the small models with anything beyond the
+  // lean step switched on.  Needs two envs per lane (even B, 16-byte rows); the smallest instantiation whose mask
+  // covers what this launch uses is taken.  PCG_OPT_VARIANT 1 forces the classic one-env-per-lane kernel (A/B).
+  if (p->integrator_id == PCG_INT_RK4 && k.nfeat > 0 && !lds_st && (p->variant == 0 || p->variant == 4)) {
+    unsigned need = 0;
+    if (c.flags & PCG_F_NOISE) need |= FT_NOISE;
+    if ((c.flags & PCG_F_GAUSS_DIST) && c.nd > 0) need |= FT_GAUSS;
+    if (c.ncon > 0) need |= FT_CONS;
+    if (c.flags & PCG_F_A_DELTA) need |= FT_ADELTA;
+    if (c.flags & PCG_F_REWARD_TRACK) need |= FT_TRACK;
+    if (c.flags & PCG_F_REWARD_BATCH) need |= FT_BATCH;
+    if (per_env_t) need |= FT_PER_T;
+    if (io->d) need |= FT_DENV;
+    if (auto_reset) need |= FT_AR;
+    bool ok = (io->B % 2 == 0) && al16(io->x) && al16(io->a) && al16(io->obs) && al16(io->rew) && al2(io->done) &&
+              al2(io->viol) && al2(io->status) && (reinterpret_cast<uintptr_t>(io->t) & 7u) == 0 && al16(io->d) &&
+              al16(io->a_save) && al16(io->u_prev) && al16(io->g) && al16(io->g_pre);
+    int best = -1;
+    for (int i = 0; ok && i < k.nfeat; ++i)
+      if ((k.feat[i].mask & need) == need &&
+          (best < 0 || __builtin_popcount(k.feat[i].mask) < __builtin_popcount(k.feat[best].mask)))
+        best = i;
+    if (best >= 0) {
+      if (p->feat_occ[best] == 0) {
+        const int q = resident_blocks(k.feat[best].fn);
+        if (q < 0) return -q;
+        p->feat_occ[best] = q;
+      }
+      const int64_t tile_envs = (int64_t)BLOCK * 2;
+      const int64_t ntile = (io->B + tile_envs - 1) / tile_envs;
+      int bpc = p->feat_occ[best];
+      if (p->stream_bpc > 0 && p->stream_bpc < bpc) bpc = p->stream_bpc;
+      int64_t grid = (int64_t)p->num_cus * bpc;
+      if (grid > ntile) grid = ntile;
+      a.nt_stores = p->nt_stores;
+      const size_t sh = (per_env_t && a.sched_in_lds) ? sizeof(double) * (size_t)(c.nsp + c.nd) * c.N : 0;
+      if (sh > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k.feat[best].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+      hipLaunchKernelGGL(k.feat[best].fn, dim3((unsigned)grid), dim3(BLOCK), sh, (hipStream_t)stream, a);
+      return (int)hipGetLastError();
+    }
   }
   StepFn fn = k.step[p->integrator_id][per_env_t ? 1 : 0][lds_st ? 1 : 0][extras ? 1 : 0];
   if (shmem > 48 * 1024)
@@ -613,7 +668,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
   const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH | PCG_F_REWARD_TRACK)) ||
                       c.ncon > 0 || io->d != nullptr;
-  if (!extras && p->integrator_id == PCG_INT_RK4 && !io->viol && p->variant != 1 && k.roll_lean[0]) {
+  if (!extras && p->integrator_id == PCG_INT_RK4 && !io->viol && !io->status && p->variant != 1 && k.roll_lean[0]) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool ev = ((a.a_ss | a.a_cs | a.o_ss | a.o_cs | a.r_ss) & 1) == 0;  // 16-byte rows stay 16-byte aligned
     const bool e2 = ev && k.roll_lean[1] && (io->B % 2 == 0) && al16(io->x) && al16(a_seq) && al16(io->obs) &&

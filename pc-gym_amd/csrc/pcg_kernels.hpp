@@ -123,6 +123,7 @@ struct StepArgs {
   int32_t* nsteps;
   double* p_unc;        // [nunc][B] per-env uncertain parameters
   double* u_prev;       // [na][B] previous physical action (PCG_F_REWARD_TRACK)
+  uint8_t* status;      // [B] per-env health of the step (PCG_ST_*), or null
   const uint8_t* mask;  // reset only
   int64_t B;
   int64_t env_offset;
@@ -302,6 +303,7 @@ struct EnvOut {
   double ounc[PCG_MAX_NUNC]; // uncertain-parameter slots
   double rew;
   bool done, viol;
+  uint8_t status;            // PCG_ST_*
 };
 
 // ---------------------------------------------------------------------------
@@ -312,28 +314,49 @@ struct EnvOut {
 // ---------------------------------------------------------------------------
 // integrate one env over [0,dt] with model constants `kp` of any storage class (scalar constants of the
 // plan, or a per-lane struct when parameters are uncertain)
+// A lane whose adaptive integration gave up (step budget exhausted / step-size underflow) stopped at some t < dt:
+// its state is poisoned with NaN so that the failure can never pass for a result (the reference's CVODES raises).
+template <int NX>
+PCG_DEV void poison_if_failed(int status, double (&x)[NX]) {
+  if (status != PCG_ST_OK) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = __builtin_nan("");
+  }
+}
+// PCG_ST_NONFINITE when a step that did not fail in the integrator still left a non-finite state
+template <int NX>
+PCG_DEV int finite_status(int status, const double (&x)[NX], int nx) {
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) ok = ok && (i >= nx || __builtin_fabs(x[i]) < __builtin_inf());
+  return (status == PCG_ST_OK && !ok) ? PCG_ST_NONFINITE : status;
+}
+
 template <class M, int INTEG, bool LDS_STAGES, class K>
-PCG_DEV void integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const double (&u)[M::NA + M::NDM],
-                           double (&x)[M::NX], double* stage_l, int64_t e, int nx) {
+PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const double (&u)[M::NA + M::NDM],
+                          double (&x)[M::NX], double* stage_l, int64_t e, int nx) {
   constexpr int NX = M::NX;
   const typename M::Hold hold = M::hold(kp, u);
   const RhsFn<M, double, K> f{kp, hold};
+  int status = PCG_ST_OK;
   if (INTEG == PCG_INT_RK4) {
     rk4<NX>(f, x, c.h, c.substeps);
   } else {
     int nacc = 0, nrej = 0;
     if (LDS_STAGES) {
       LdsStages<NX, BLOCK_LDS> Kst{stage_l + threadIdx.x};
-      dopri5<NX>(f, Kst, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+      status = dopri5<NX>(f, Kst, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
     } else {
       RegStages<NX> Kst;
-      dopri5<NX>(f, Kst, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+      status = dopri5<NX>(f, Kst, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
     }
     if (A.nsteps) {
       A.nsteps[e] = nacc;
       A.nsteps[A.B + e] = nrej;
     }
+    poison_if_failed<NX>(status, x);
   }
+  return finite_status<NX>(status, x, nx);
 }
 
 template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS, bool UNC = false>
@@ -417,9 +440,9 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
 #pragma unroll
       for (int j = 0; j < NDM; ++j) u[NA + j] = dd[j];
     }
-    integrate_env<M, INTEG, LDS_STAGES>(A, c, kpl, u, x, stage_l, e, nx);
+    out.status = (uint8_t)integrate_env<M, INTEG, LDS_STAGES>(A, c, kpl, u, x, stage_l, e, nx);
   } else {
-    integrate_env<M, INTEG, LDS_STAGES>(A, c, kp, u, x, stage_l, e, nx);
+    out.status = (uint8_t)integrate_env<M, INTEG, LDS_STAGES>(A, c, kp, u, x, stage_l, e, nx);
   }
   // ---- SP slot uses SP[t_old] (pcgym.py:432-438, quirk Q5); t += 1 ----
   double spv[PCG_MAX_NSP] = {0.0, 0.0, 0.0, 0.0};
@@ -573,6 +596,7 @@ PCG_DEV void store_out(const StepArgs& A, CDevConst& c, int64_t e, const EnvOut<
   __builtin_nontemporal_store(out.rew, A.rew + e);
   A.done[e] = out.done ? 1 : 0;
   if (A.viol) A.viol[e] = out.viol ? 1 : 0;
+  if (A.status) A.status[e] = out.status;
 }
 
 // cooperative copy of the schedules into LDS (per-env-t kernels)
@@ -611,6 +635,7 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG), wpe(M::NX, INTEG, LDS_STAGES
     __builtin_nontemporal_store(out.rew, A.rew + e);
     A.done[e] = 1;
     if (A.viol) A.viol[e] = out.viol ? 1 : 0;
+    if (A.status) A.status[e] = out.status;
     reset_env(A, c, e, A.reset_seed);
     return;
   }
@@ -1214,14 +1239,15 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG)) void integrate_kernel(CDevCo
   if (INTEG == PCG_INT_RK4) {
     rk4<NX>(f, x, c.h, c.substeps);
   } else {
-    int nacc = 0, nrej = 0;
+    int nacc = 0, nrej = 0, status;
     if (LDS_STAGES) {
       LdsStages<NX, BLOCK_LDS> K{lds + threadIdx.x};
-      dopri5<NX>(f, K, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+      status = dopri5<NX>(f, K, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
     } else {
       RegStages<NX> K;
-      dopri5<NX>(f, K, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+      status = dopri5<NX>(f, K, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
     }
+    poison_if_failed<NX>(status, x);
     if (nsteps) {
       nsteps[e] = nacc;
       nsteps[B + e] = nrej;
@@ -1239,7 +1265,26 @@ using StepFn = void (*)(const StepArgs);
 using RhsKFn = void (*)(CDevConst*, int64_t, int, const double*, const double*, double*);
 using IntKFn = void (*)(CDevConst*, int64_t, int, double*, const double*, int32_t*);
 
+// one instantiation of the feature-masked small-model kernel (pcg_step_feat.hpp): serves every launch whose
+// needs are a subset of `mask`
+struct FeatEntry {
+  unsigned mask;
+  StepFn fn;
+};
+constexpr int MAX_FEAT = 16;
+// tables of the two small HBM-bound models, built in their own translation unit (pcg_inst_k.hip)
+int feat_fill_cstr(FeatEntry* out, int cap);
+int feat_fill_four_tank(FeatEntry* out, int cap);
+template <int ID>
+inline int feat_fill(FeatEntry*, int) { return 0; }
+template <>
+inline int feat_fill<PCG_MODEL_CSTR>(FeatEntry* o, int cap) { return feat_fill_cstr(o, cap); }
+template <>
+inline int feat_fill<PCG_MODEL_FOUR_TANK>(FeatEntry* o, int cap) { return feat_fill_four_tank(o, cap); }
+
 struct Kernels {
+  FeatEntry feat[MAX_FEAT];          // feature-masked pipelined kernels, 2 envs per lane (RK4, small models)
+  int nfeat;
   StepFn step[PCG_INT_COUNT][2][2][2];  // [integrator][per_env_t][lds_stages][extras]
   StepFn stream[PCG_INT_COUNT][2];      // persistent streaming kernel [integrator][EPL-1] (entries may be null)
   StepFn step_unc[PCG_INT_COUNT][2]; // per-env parameter uncertainty [integrator][per_env_t] (null for affine)
@@ -1312,6 +1357,7 @@ Kernels make_kernels() {
   if (!k.rollout[PCG_INT_DOPRI5][1]) k.rollout[PCG_INT_DOPRI5][1] = k.rollout[PCG_INT_DOPRI5][0];
   k.integ[PCG_INT_RK4][1] = k.integ[PCG_INT_RK4][0];
   if (!k.integ[PCG_INT_DOPRI5][1]) k.integ[PCG_INT_DOPRI5][1] = k.integ[PCG_INT_DOPRI5][0];
+  k.nfeat = feat_fill<ID>(k.feat, MAX_FEAT);
   k.has_lds_stages = M::FULL;
   k.nx = M::NX;
   k.na = M::NA;

@@ -93,11 +93,11 @@ PCG_PK double div_fast(double a, double b) {
   q = __builtin_fma(__builtin_fma(-b, q, a), r, q);
   return q;
 }
-// exp(x) for x in [-745, 700] (clamped below): Cody-Waite reduction by ln2 and a degree-13 Taylor
+// exp(x) for x in [-745, 700] (clamped below; NaN propagates): Cody-Waite reduction by ln2 and a degree-13 Taylor
 // polynomial on |r| <= ln2/2 (truncation 4e-18), ~1-2 ulp.  20 VALU instructions against ~30 for the
 // library exp(), whose extra work is overflow / underflow / NaN selection.
 PCG_PK double exp_bounded(double x) {
-  x = __builtin_fmax(x, -745.0);
+  x = (x < -745.0) ? -745.0 : x;  // compare + select, not fmax: a NaN argument stays NaN (fmax would return -745)
   const double n = __builtin_rint(x * 1.44269504088896338700e+00);
   double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
   r = __builtin_fma(n, -1.90821492927058770002e-10, r);

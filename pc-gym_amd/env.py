@@ -44,10 +44,13 @@ class VecEnv:
                              auto-reset when episodes can end at different times)
     auto_reset : bool        reset finished envs inside step() (gymnasium "same-step" mode)
     env_offset : int         global index of env 0 (multi-GPU sharding: keeps RNG streams disjoint)
+    track_status : bool      keep a per-env health byte of every step (``env.status``: 0 ok, 1 DOPRI5 step budget
+                             exhausted, 2 step-size underflow, 3 non-finite state -- include/pcgym_hip.h PCG_ST_*);
+                             an env whose adaptive integration fails gets a NaN state either way
     """
 
     def __init__(self, env_params, n_envs=1, device=None, seed=0, per_env_t=False, auto_reset=False,
-                 env_offset=0, lds_stages=False, variant=None):
+                 env_offset=0, lds_stages=False, variant=None, track_status=True):
         self.spec = s = EnvSpec(env_params)
         self.env_params = s.env_params
         if s.custom_reward is not None and not getattr(self, "_allow_custom_reward", False):
@@ -114,6 +117,7 @@ class VecEnv:
         self.rew = torch.zeros(B, dtype=f64, device=dev)
         self.done = torch.zeros(B, dtype=torch.uint8, device=dev)
         self.viol = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self.status = torch.zeros(B, dtype=torch.uint8, device=dev) if track_status else None
         self.a_save_t = torch.zeros((s.na, B), dtype=f64, device=dev) if s.a_delta else None
         self.g = torch.zeros((s.ncon, B), dtype=f64, device=dev) if s.ncon else None
         self.g_pre = torch.zeros((s.ncon, B), dtype=f64, device=dev) if s.ncon else None
@@ -138,6 +142,7 @@ class VecEnv:
         b.nsteps = self.nsteps.data_ptr() if self.nsteps is not None else None
         b.p_unc = self.p_unc.data_ptr() if self.p_unc is not None else None
         b.u_prev = self.u_prev.data_ptr() if self.u_prev is not None else None
+        b.status = self.status.data_ptr() if self.status is not None else None
         self._bufp = C.byref(b)
         self._a_hold = None
         self._d_hold = None
@@ -239,6 +244,8 @@ class VecEnv:
             info["g"] = self.g
         if self.nsteps is not None:
             info["nsteps"] = self.nsteps
+        if self.status is not None:
+            info["status"] = self.status
         return self.obs, self.rew, self.done.view(_torch().bool), False, info
 
     def rollout(self, actions, collect_obs=False, collect_rew=True):
@@ -274,26 +281,32 @@ class VecEnv:
             raise ValueError("capture_steps() is lock-stepped only")
         return StepGraph(self, actions, disturbances, with_reset)
 
-    # state_dict for checkpoint/resume of the env batch
+    # state_dict for checkpoint/resume of the env batch: everything a later step() reads or a caller may look at
+    # before the next step -- state, counters, RNG epoch, accumulators, the per-env uncertain parameters sampled at
+    # reset, and the outputs of the last step (the policy's next input is env.obs)
+    _STATE_TENSORS = ("x", "obs_soa", "rew", "done", "viol", "status", "a_save_t", "t_env", "u_prev", "p_unc", "g",
+                      "g_pre", "nsteps")
+
     def state_dict(self):
-        d = {"x": self.x.clone(), "t": self.t, "episode": self.episode, "seed0": self.seed0}
-        if self.a_save_t is not None:
-            d["a_save"] = self.a_save_t.clone()
-        if self.t_env is not None:
-            d["t_env"] = self.t_env.clone()
-        if self.u_prev is not None:
-            d["u_prev"] = self.u_prev.clone()
+        d = {"t": self.t, "episode": self.episode, "seed0": self.seed0}
+        for k in self._STATE_TENSORS:
+            v = getattr(self, k)
+            if v is not None:
+                d[k] = v.clone()
         return d
 
     def load_state_dict(self, d):
-        self.x.copy_(d["x"])
         self.t, self.episode, self.seed0 = int(d["t"]), int(d["episode"]), int(d["seed0"])
-        if self.a_save_t is not None:
-            self.a_save_t.copy_(d["a_save"])
-        if self.t_env is not None:
-            self.t_env.copy_(d["t_env"])
-        if self.u_prev is not None:
-            self.u_prev.copy_(d["u_prev"])
+        for k in self._STATE_TENSORS:
+            v = getattr(self, k)
+            if v is None:
+                continue
+            src = d.get(k, d.get({"a_save_t": "a_save"}.get(k, k)))
+            if src is None:
+                if k in ("x", "p_unc", "a_save_t", "t_env", "u_prev"):
+                    raise KeyError(f"state dict lacks '{k}', which this configuration needs to resume")
+                continue
+            v.copy_(src)
 
 
 class StepGraph:
@@ -378,6 +391,7 @@ class make_env(VecEnv):
         self.obs_np = self.state.copy()
         self.a_save = s.a_0.copy() if s.a_delta else None
         self.a_0 = s.a_0.copy() if s.a_delta else None  # read by callers (tests/environment/test_make_env_delta_u.py:24)
+        self.done_flag = False
 
     # -- host-side mirrors needed only for the callable custom_reward path -------------
     def _host_uk(self, action):
@@ -458,4 +472,7 @@ class make_env(VecEnv):
             self.obs_np = obs_un
             r = self.custom_reward_f(self, obs_un, uk, violated)
         self.info["obs"] = o.copy()
-        return o, r, bool(done[0].item()), False, self.info
+        # the reference's self.done latches once set (a violation with done_on_cons_vio, pcgym.py:613-614) and stays
+        # True until reset()
+        self.done_flag = bool(self.done_flag or done[0].item())
+        return o, r, self.done_flag, False, self.info

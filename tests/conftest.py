@@ -27,6 +27,10 @@ def pytest_collection_modifyitems(config, items):
     # only when deselected by -m "not gpu"; if selected without a GPU they fail loudly.
     if _has_gpu():
         return
+    def _no_gpu(*a, **k):
+        pytest.fail("this test is marked gpu and was selected, but no GPU is visible (torch.cuda.is_available() is "
+                    "False): deselect with -m 'not gpu' on a CPU box", pytrace=False)
+
     for item in items:
         if "gpu" in item.keywords:
-            item.add_marker(pytest.mark.xfail(reason="no GPU visible", run=True, strict=False))
+            item.obj = _no_gpu  # fail loudly: a GPU test must never look green (or xfail-quiet) without a GPU

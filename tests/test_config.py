@@ -142,8 +142,13 @@ def test_registry_shaped_custom_model_reuses_kernel_with_its_parameters():
 
 
 def test_integrator_selection():
-    assert EnvSpec(P("cstr_canonical")).integrator == "rk4"
-    assert EnvSpec(P("cstr_canonical")).substeps == 4          # dt = 26/60
+    # cstr: adaptive by default (the ignition branch inside the canonical o_space is beyond fixed-step RK4);
+    # rk4 is an explicit opt-in and then gets the tuned sub-step count
+    assert EnvSpec(P("cstr_canonical")).integrator == "dopri5"
+    p4 = P("cstr_canonical")
+    p4["integrator"] = "rk4"
+    assert EnvSpec(p4).integrator == "rk4" and EnvSpec(p4).substeps == 4   # dt = 26/60
+    assert EnvSpec(P("four_tank_canonical")).integrator == "rk4"
     assert EnvSpec(P("me_canonical")).integrator == "dopri5"   # stiff: adaptive by default
     p = P("cstr_canonical")
     p["integration_method"] = "jax"                            # reference's adaptive 5(4) path

@@ -99,21 +99,21 @@ def test_integrators_reach_true_solution(fix, model, tol_default, tight, tol_tig
     dt = float(g["dt"])
     nu = g["u"].shape[1]
     scale = np.maximum(np.abs(g["xf"]), 1e-6 * np.max(np.abs(g["xf"]), axis=0, keepdims=True))
-    # default integrator settings: the reference's accuracy class (CVODES reltol 1e-6).
-    # cstr samples that ignite (thermal runaway, T -> 440..480 K, |lambda| dt >> 1) are outside the
-    # stability region of fixed-step RK4 and are excluded here; DOPRI5 below covers them.
-    ok = np.ones(g["x"].shape[0], dtype=bool)
-    if model == "cstr":
-        ok = g["xf"][:, 1] < 360.0
-        assert ok.sum() >= 15
+    # default integrator settings: the reference's accuracy class (CVODES reltol 1e-6) on EVERY sample --
+    # including the cstr samples that ignite (thermal runaway, T -> 440..480 K, |lambda| dt >> 1): the default
+    # for cstr is the adaptive pair precisely because fixed-step RK4 returns finite garbage there.
     s = _spec_for_integration(model, dt, nu)
     xf, _ = O.integrate(s, g["x"].T, g["u"].T)
+    if model == "cstr":
+        assert s.integrator == "dopri5" and (g["xf"][:, 1] > 360.0).sum() >= 3  # the fixture holds igniting samples
     # mixed tolerance, as CVODES' own (reltol 1e-6, abstol 1e-8): small components are held absolutely
-    assert np.all((np.abs(xf.T - g["xf"]) <= tol_default * scale + 3e-8)[ok])
-    if model == "cstr":  # the adaptive pair handles the ignition cases within its tolerance class
-        sa = _spec_for_integration(model, dt, nu, integrator="dopri5")
-        xa, _ = O.integrate(sa, g["x"].T, g["u"].T)
-        assert np.max(np.abs(xa.T - g["xf"]) / scale) <= 1e-5
+    tol = 1e-5 if model == "cstr" else tol_default  # ignition transients: the 1e-8 local tolerance gives ~3e-6 global
+    assert np.all(np.abs(xf.T - g["xf"]) <= tol * scale + 3e-8)
+    if model == "cstr":  # the explicit RK4 opt-in holds its accuracy class on the non-igniting samples
+        ok = g["xf"][:, 1] < 360.0
+        sr = _spec_for_integration(model, dt, nu, integrator="rk4")
+        xr, _ = O.integrate(sr, g["x"].T, g["u"].T)
+        assert ok.sum() >= 15 and np.all((np.abs(xr.T - g["xf"]) <= tol_default * scale + 3e-8)[ok])
     # tight settings converge onto the LSODA(1e-13) answer
     s = _spec_for_integration(model, dt, nu, **tight)
     xf, ns = O.integrate(s, g["x"].T, g["u"].T)
@@ -168,17 +168,15 @@ def test_full_step_tuples_match_reference(name):
     oscale = np.maximum(np.abs(g["obs"]), 1e-9)
     assert np.all(np.abs(obs[:, 0] - g["obs"][0]) <= 1e-12 * np.maximum(1.0, oscale[0]))
     T = sc["steps"]
-    first_done = None
+    latched = False  # the reference's self.done stays True once set (pcgym.py:613-614): compare the whole sequence
     for i in range(T):
         env.step(A[i].reshape(-1, 1))
         want = g["obs"][i + 1]
         err = np.abs(env.obs[:, 0] - want)
         assert np.all(err <= 2e-9 * np.maximum(np.abs(want), 1.0)), (name, i, env.obs[:, 0], want)
         assert abs(env.rew[0] - g["rew"][i]) <= 1e-7 * max(1.0, abs(g["rew"][i])), (name, i)
-        if first_done is None:
-            assert env.done[0] == g["done"][i], (name, i)
-            if g["done"][i]:
-                first_done = i
+        latched = latched or bool(env.done[0])
+        assert latched == bool(g["done"][i]), (name, i)
         if "cons_info" in g.files:
             ci = g["cons_info"]
             if i == 0:
