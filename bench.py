@@ -1,26 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- env-steps/s of the fused HIP step kernel on BASELINE.json configs[1].
+"""bench.py -- env-steps/s of the fused HIP step kernels on BASELINE.json's configurations.
 
-Workload (config.workload = "cstr_b2^20_rk4_fp64"):
-  cstr (2 states), B = 1,048,576 envs PER GPU, classical RK4, one step per dt = 1 s
-  (= 1/60 of the model's time unit, minutes), fp64, normalised actions/observations,
-  SP schedule 0.85 -> 0.9 -> 0.87 (thirds), N = 60, r_scale Ca = 1e3, noise off;
-  x0 ~ [U(0.7,1.0), U(310,334)] drawn in the reset kernel (Philox), actions ~ U(-1,1)
+Default workload (config.workload = "cstr_b2^20_rk4_fp64", BASELINE configs[1], the configuration `metric` is quoted on):
+  cstr (2 states), B = 1,048,576 envs PER GPU, classical RK4, one step per dt = 1 s (= 1/60 of the model's time
+  unit, minutes), fp64, normalised actions/observations, SP schedule 0.85 -> 0.9 -> 0.87 (thirds), N = 60,
+  r_scale Ca = 1e3, noise off; x0 ~ [U(0.7,1.0), U(310,334)] drawn in the reset kernel (Philox), actions ~ U(-1,1)
   pre-generated on the device (no policy cost), lock-stepped batch.
-A "step" = ONE pcg_step() launch over the whole batch (one env step for every env),
-episodes are 59 steps long; the reset that ends each episode is inside the timed region (fused into the
-episode's last step launch, pcg_step_autoreset).  value = total env-steps / wall time (max over ranks), whole job.
+A "step" = ONE pass of the hot path over the whole batch (pcg_step launches: one per model segment); episodes are
+N-1 steps long and the reset that ends each episode is inside the timed region (fused into the episode's last step
+launch, pcg_step_autoreset).  value = total env-steps / wall time (max over ranks), whole job.
 
-Multi-GPU: the env batch shards embarrassingly (weak scaling, B per GPU fixed); no
-collective on the hot path -- torch.distributed (RCCL) is used only for the barrier
-and the max-over-ranks of the elapsed time.
+--workload selects the other BASELINE configurations (parity-test cases made measurable; not the headline):
+  four_tank  four_tank B = 2^20, RK4 x4 per dt = 1000/60 (HBM-bound)
+  me10       configs[2]: multistage_extraction (10 states) B = 262,144, adaptive DOPRI5 rtol = atol = 1e-8, dt = 1,
+             (L, G) per env over the FULL action box [5,10]..[500,1000], x0 = doc ICs x (1 + 0.05 U(-1,1))
+  me20       the 20-state reactive variant, same protocol
+  cryst      configs[3]: crystallization B = 262,144, RK4 x32 per dt = 1, a_delta on
+  mixed      configs[4], one shard: 1,048,572 envs = 349,524 each of cstr + Ti ~ N(350, 2) / four_tank /
+             multistage_extraction + X0 ~ N(0.6, 0.02), set-point step changes, three plans on three streams;
+             --gpus 8 = 8,388,576 envs (weak scaling, global env index keys the RNG)
 
-Extra objects on the JSON line: "roofline" (HBM-bound; algorithmic bytes per launch /
-kernel time from hipEvents on the launch stream) and "cpu_baseline" (the C oracle, same
-algorithm, timed on the host cores on a bounded sample; rank 0, N=1 only).
+Multi-GPU: the env batch shards embarrassingly (weak scaling, B per GPU fixed); no collective on the hot path --
+torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.
+
+Extra objects on the JSON line: "roofline" (dominant kernel: algorithmic bytes or flops per launch / kernel time from
+hipEvents on the launch stream) and "cpu_baseline" (the C oracle timed on the host cores on a bounded sample, plus a
+reference-shaped one-env-at-a-time Python loop; rank 0, N=1 only).
 """
 import argparse
-import ctypes as C
+import copy
 import json
 import os
 import sys
@@ -30,19 +38,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+FP64_PEAK_TFLOPS = 78.6   # fp64 vector peak (no MFMA on this path)
+METRIC = "env-steps/sec at batch 2^20 CSTR, 1/2/4/8 MI355X; achieved HBM GB/s vs peak"
+# algorithmic fp64 flops per right-hand-side evaluation -- for the fp64-bound workloads
+FLOP_PER_RHS = {"multistage_extraction": 65, "multistage_extraction_reactive": 150,
+                "crystallization": 60 + 4 * 25 + 12 + 6 * 10}
 
 
-def workload_params(B):
+def _thirds(n, a, b, c):
+    k = n // 3
+    return [a] * k + [b] * k + [c] * (n - 2 * k)
+
+
+def workload_params(B=None):
+    """BASELINE configs[1] (the headline): see the module docstring."""
     import numpy as np
 
     N = 60
-    k = N // 3
     return {
         "model": "cstr",
         "N": N,
         "tsim": N * (1.0 / 60.0),  # dt = 1 s in a model whose time unit is minutes
-        "SP": {"Ca": [0.85] * k + [0.9] * k + [0.87] * (N - 2 * k)},
+        "SP": {"Ca": _thirds(N, 0.85, 0.9, 0.87)},
         "o_space": {"low": np.array([0.7, 300.0, 0.8]), "high": np.array([1.0, 350.0, 0.9])},
         "a_space": {"low": np.array([295.0]), "high": np.array([302.0])},
         "x0": np.array([0.85, 322.0, 0.85]),
@@ -56,12 +74,72 @@ def workload_params(B):
     }
 
 
-def cpu_baseline(spec, seconds_target=12.0):
-    """Time the CPU oracle (oracle/pcg_oracle.c: same algorithm, plain C + OpenMP) on the host
-    cores, on a bounded sample of the same workload; also report how far one RK4 step is from
-    a tight adaptive solve on that sample (accuracy next to speed)."""
+def mixed_segments(B_shard):
+    """BASELINE configs[4], one shard: floor(B/3) envs each of
+      cstr with Ti ~ N(350, 2) clipped to [320, 360] (set-point thirds 0.85/0.9/0.87, canonical dt = 26/60, RK4 x4),
+      four_tank (set-point step changes h3 0.5 -> 0.1, h4 0.2 -> 0.3, 4tank_train.py:54-57), undisturbed: the model has
+        no disturbance input (model_classes.py:926 lists ["None"]),
+      multistage_extraction with X0 ~ N(0.6, 0.02) clipped to [0.5, 0.8] (X5 0.3 -> 0.4 -> 0.3, adaptive DOPRI5).
+    Returns [(env_params, n_envs)] in the global layout [cstr | four_tank | ME]."""
     import numpy as np
 
+    import scenarios as SC
+
+    S = SC.scenarios()
+    n = (B_shard // 3) & ~1  # even: two envs per lane in the small-model kernels
+    N = 60
+    c = copy.deepcopy(S["cstr_dist_Ti"]["env_params"])
+    c.update(N=N, tsim=26.0, SP={"Ca": _thirds(N, 0.85, 0.9, 0.87)}, disturbances={"Ti": np.full(N, 350.0)},
+             disturbance_bounds={"low": np.array([320.0]), "high": np.array([360.0])},
+             gaussian_disturbances={"Ti": 2.0}, integrator="rk4", substeps=4)
+    f = copy.deepcopy(S["four_tank_canonical"]["env_params"])
+    m = copy.deepcopy(S["me_dist_cons"]["env_params"])
+    for k in ("constraints", "done_on_cons_vio", "r_penalty"):
+        m.pop(k, None)
+    m.update(N=N, tsim=60.0, SP={"X5": _thirds(N, 0.3, 0.4, 0.3)}, disturbances={"X0": np.full(N, 0.6)},
+             disturbance_bounds={"low": np.array([0.5]), "high": np.array([0.8])},
+             gaussian_disturbances={"X0": 0.02}, normalise_a=True, normalise_o=True, integrator="dopri5",
+             rtol=1e-8, atol=1e-8)
+    return [(c, n), (f, n), (m, n)]
+
+
+def single_workload(name):
+    """-> (config.workload string, env_params, default B per GPU, default (steps, warmup), action slabs)"""
+    import numpy as np
+
+    import scenarios as SC
+
+    S = SC.scenarios()
+    if name == "cstr":
+        return "cstr_b2^20_rk4_fp64", workload_params(), 1 << 20, (5900, 590), 64
+    if name == "four_tank":
+        return "four_tank_b2^20_rk4x4_fp64", copy.deepcopy(S["four_tank_canonical"]["env_params"]), 1 << 20, (1180, 118), 16
+    if name in ("me10", "me20"):
+        p = copy.deepcopy(S["me_canonical" if name == "me10" else "me_reactive"]["env_params"])
+        nx = 10 if name == "me10" else 20
+        key = list(p["SP"].keys())[0]
+        p.update(N=60, tsim=60.0, SP={key: _thirds(60, 0.3, 0.4, 0.3)}, integrator="dopri5", rtol=1e-8, atol=1e-8,
+                 uncertainty_percentages={"x0": [0.05] * nx}, distribution="uniform", normalise_a=True,
+                 normalise_o=True)
+        p.pop("noise", None), p.pop("noise_percentage", None)
+        return f"{'multistage_extraction' if name == 'me10' else 'multistage_extraction_reactive'}_b2^18_dopri5_1e-8_fp64", \
+            p, 1 << 18, (118, 12), 8
+    if name == "cryst":
+        p = copy.deepcopy(S["cryst_adelta"]["env_params"])
+        p.update(integrator="rk4", substeps=32)
+        return "crystallization_b2^18_rk4x32_adelta_fp64", p, 1 << 18, (116, 12), 8
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(spec, seconds_target=10.0, threads=None):
+    """The CPU oracle (oracle/pcg_oracle.c: same algorithm, plain C + OpenMP) on the host cores, on a bounded sample of
+    the same workload, with a FIXED thread count; beside it the reference-shaped leg: one env at a time through a
+    Python loop with an adaptive integrator at the reference's CVODES-default tolerance class (pcgym.py:350-500 +
+    integrator.py:90-107 rebuild a solver per step; BASELINE.md section 3.2 measured 207 us/step for the reference
+    itself in the build container)."""
+    import numpy as np
+
+    import scenarios as SC
     from oracle import oracle as O
     from pcgym_amd.config import EnvSpec
 
@@ -70,12 +148,13 @@ def cpu_baseline(spec, seconds_target=12.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    cores = int(threads) if threads else min(16, avail)  # fixed: no probing (round-1 probes were unstable on shared hosts)
     Bs, T = 1 << 18, 8
     rng = np.random.default_rng(0)
-    acts = rng.uniform(-1, 1, (T, 1, Bs))
+    acts = rng.uniform(-1, 1, (T, spec.na, Bs))
 
-    def rate(threads, budget_s):
-        env = O.OracleEnv(spec, Bs, seed=1, n_threads=threads)
+    def rate(nthreads, budget_s):
+        env = O.OracleEnv(spec, Bs, seed=1, n_threads=nthreads)
         env.reset()
         env.step(acts[0])  # warm-up (thread pool, page faults)
         t0 = time.perf_counter()
@@ -91,14 +170,9 @@ def cpu_baseline(spec, seconds_target=12.0):
         dt = time.perf_counter() - t0
         return reps * Bs / dt, reps, dt
 
-    # the container may expose more hardware threads than it is allowed to use: probe a few team
-    # sizes briefly, then spend the budget on the fastest one and report THAT thread count
-    cands = sorted({1, min(8, avail), min(32, avail), min(64, avail), avail})
-    probe = {c: rate(c, 0.5)[0] for c in cands}
-    cores = max(probe, key=probe.get)
+    one, _, _ = rate(1, 2.0)
     value, reps, dt = rate(cores, seconds_target)
-    n = reps * Bs
-    # accuracy of the fixed single RK4 step vs a tight adaptive solve, same starts
+    # accuracy of the workload's integrator setting vs a tight adaptive solve, same starts
     p2 = dict(spec.env_params)
     p2.update(integrator="dopri5", rtol=1e-12, atol=1e-14)
     s2 = EnvSpec(p2)
@@ -108,13 +182,27 @@ def cpu_baseline(spec, seconds_target=12.0):
     e1.reset()
     e2.reset()
     worst = 0.0
-    for i in range(20):
-        a = rng.uniform(-1, 1, (1, nb))
+    for i in range(10):
+        a = rng.uniform(-1, 1, (spec.na, nb))
         e2.x[:] = e1.x
         e2.t = e1.t
         e1.step(a)
         e2.step(a)
-        worst = max(worst, float(np.max(np.abs(e1.x - e2.x) / np.abs(e2.x))))
+        worst = max(worst, float(np.nanmax(np.abs(e1.x - e2.x) / np.maximum(np.abs(e2.x), 1e-9))))
+    # reference-shaped leg: README.md:16-55 quick-start cstr (N = 100, 99 steps per episode), ONE env per Python
+    # call, adaptive 5(4) pair at rtol 1e-6 / atol 1e-8, one core
+    pq = copy.deepcopy(SC.scenarios()["cstr_quickstart"]["env_params"])
+    pq.update(integrator="dopri5", rtol=1e-6, atol=1e-8)
+    sq = EnvSpec(pq)
+    eq = O.OracleEnv(sq, 1, seed=0, n_threads=1)
+    rq = np.random.default_rng(0)
+    n_steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 3.0:
+        eq.reset()
+        for i in range(sq.N - 1):
+            eq.step(rq.uniform(-1, 1, (1, 1)))
+        n_steps += sq.N - 1
+    ref_shaped = n_steps / (time.perf_counter() - t0)
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as fh:
@@ -125,32 +213,69 @@ def cpu_baseline(spec, seconds_target=12.0):
         "value": value,
         "unit": "env-steps/s",
         "cores": cores,
+        "one_thread_env_steps_per_s": one,
         "host_cpu": cpu_model,
         "host_logical_cpus": os.cpu_count(),
-        "cores_probe_env_steps_per_s": {str(k): v for k, v in probe.items()},
         "kind": "port",
-        "sample": f"{reps} steps x {Bs} envs of the same cstr/RK4 workload, OpenMP over {cores} host threads "
+        "sample": f"{reps} steps x {Bs} envs of the same workload, OpenMP over a fixed {cores} host threads "
                   f"({dt:.1f} s of CPU work)",
-        "rk4_step_vs_tight_max_rel_err": worst,
+        "step_vs_tight_max_rel_err": worst,
+        "reference_shaped": {
+            "value": ref_shaped,
+            "unit": "env-steps/s",
+            "cores": 1,
+            "sample": f"{n_steps} steps: README quick-start cstr (99-step episodes), ONE env per Python call into the C "
+                      "oracle, adaptive 5(4) pair at rtol 1e-6 / atol 1e-8 (the reference's CVODES tolerance class)",
+            "context": "the reference's own make_env.step behind stubs + SciPy measured 207 us/step = 4.8e3 env-steps/s "
+                       "on one 2.1 GHz Xeon vCPU of the build container (BASELINE.md section 3.2); it cannot run on the "
+                       "GPU box (pure Python over casadi / jax wheels that are not installed)",
+        },
     }
+
+
+# Normalised actions ~ U(-1,1) over the full action box, except four_tank: pump voltages in the upper 3/4 of the box
+# (U(-0.5,1)) -- with the full box ~0.05 % of the envs drain tank 3 and sqrt(2 g h) of a negative level is NaN, in the
+# reference just the same (model_classes.py:891-913)
+def act_box(spec):
+    return 0.75 if spec.model.name == "four_tank" else 1.0
+
+
+def act_shift(spec):
+    return 0.25 if spec.model.name == "four_tank" else 0.0
+
+
+def clock_preheat(torch, dev, ms):
+    """Untimed, workload-independent GPU busy loop: an idle MI355X needs ~50 ms of work to reach steady clocks.
+    Uses a plain torch matmul, NOT the bench's own launches, so that `warmup` is exactly the warm-up that ran."""
+    if ms <= 0:
+        return 0.0
+    a = torch.randn((2048, 2048), device=dev, dtype=torch.float32)
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(20):
+            a = torch.tanh(a @ a * 1e-3)
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5900)
-    ap.add_argument("--warmup", type=int, default=590)
-    ap.add_argument("--batch", type=int, default=1 << 20, help="envs per GPU")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="cstr", choices=["cstr", "four_tank", "me10", "me20", "cryst", "mixed"])
+    ap.add_argument("--batch", type=int, default=None, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=None, help="fixed OpenMP team of the cpu_baseline leg (default min(16, avail))")
     ap.add_argument("--preheat-ms", type=float, default=100.0,
-                    help="untimed GPU clock pre-heat before the warm-up steps (0 = off)")
+                    help="untimed GPU clock pre-heat (generic matmul loop) before the warm-up steps (0 = off)")
     ap.add_argument("--separate-reset", action="store_true",
                     help="end each episode with a separate pcg_reset launch instead of the fused pcg_step_autoreset (A/B)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay whole episodes as one HIP graph (pcg_graph_*) instead of eager launches; "
-                         "measured within 1 %% of eager once the GPU is warm, so eager stays the default")
-    ap.add_argument("--substeps", type=int, default=1,
-                    help="RK4 sub-steps per env step (1 = the headline workload; other values are probes)")
+                    help="cstr workload: replay whole episodes as one HIP graph (pcg_graph_*) instead of eager launches")
+    ap.add_argument("--substeps", type=int, default=None,
+                    help="cstr workload: RK4 sub-steps per env step (1 = the headline; other values are probes)")
+    ap.add_argument("--status", type=int, default=1, help="write the per-env status byte (0 = off, A/B)")
     args = ap.parse_args()
 
     import numpy as np
@@ -165,104 +290,129 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
                          f"(WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
-    # PCG_BENCH_BACKEND=gloo is a test switch: it lets the N-rank code path run on a box with fewer GPUs than
-    # ranks (ranks share devices); the driver's runs use the default, RCCL with one rank per GPU.
+    # PCG_BENCH_BACKEND=gloo is an explicit TEST switch: it lets the N-rank code path run on a box with fewer GPUs than
+    # ranks (ranks share devices).  The default is RCCL with one rank per GPU; if RCCL cannot initialise the run FAILS
+    # (no silent fallback), and the JSON line records the backend and the rank count the communicator reports.
     backend = os.environ.get("PCG_BENCH_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a node with one GPU per rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    dist = None
+    dist, ranks_seen = None, 1
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            try:
-                dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" == RCCL on ROCm
-                probe = torch.zeros(1, device=dev)
-                dist.all_reduce(probe)  # communicator creation is lazy: fail here, not inside the timed region
-                torch.cuda.synchronize()
-            except Exception as e:  # noqa: BLE001 -- the collectives only carry a barrier and one scalar
-                print(f"[bench] rank {rank}: RCCL unavailable ({type(e).__name__}: {e}); using gloo for the "
-                      f"barrier / max-reduce", file=sys.stderr, flush=True)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-                dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)  # communicator creation is lazy: fail here, not inside the timed region
+            torch.cuda.synchronize()
+            ranks_seen = int(round(float(probe.item())))  # every rank contributed 1: what the communicator spans
         else:
             dist.init_process_group(backend=backend)
+            ranks_seen = dist.get_world_size()
+        if ranks_seen != world:
+            raise SystemExit(f"communicator spans {ranks_seen} ranks, expected {world}")
 
-    B, K, W = args.batch, args.steps, args.warmup
-    params = workload_params(B)
-    params["substeps"] = args.substeps
-    # shard: rank r owns global envs [r*B, (r+1)*B)  (weak scaling; RNG streams keyed by global index)
-    env = VecEnv(params, n_envs=B, device=dev, seed=1234, auto_reset=True, env_offset=rank * B)
     lib = _lib.load()
-    spec = env.spec
-    bytes_per_env_step = env.bytes_per_env_step  # 74 B for this workload
-
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    n_act = 64  # distinct pre-generated action slabs, cycled (512 MiB would be wasteful; 64 x 8 MiB)
-    acts = 2 * torch.rand((n_act, 1, B), generator=gen, device=dev, dtype=torch.float64) - 1
-    env.reset()
-    torch.cuda.synchronize()
-
     stream = torch.cuda.current_stream(dev)
-    plan, bufp, buf, sptr = env._plan, env._bufp, env._buf, stream.cuda_stream
-    step_fn, last_t = lib.pcg_step, env.N - 1
-    # One episode (N-1 = 59 dependent pcg_step launches) is recorded once as a HIP graph (pcg_graph_*) and
-    # replayed with one host call; the reset between episodes and any steps that do not fill a whole
-    # episode (arbitrary --steps / --warmup) are launched eagerly.  Same kernels, same buffers.
-    graph = env.capture_steps([acts[j % n_act] for j in range(last_t)]) if args.graph else None
-    # Kernel timing for the roofline object: hipEvent pairs on the launch stream inside the timed region,
-    # one pair around each run of consecutive step launches of an episode (a graph replay = 59 launches).
-    # A pair around ONE ~14 us launch reads ~3 us high (marker packets + timestamp latency; rocprofv3's
-    # kernel trace is the reference); a bracket / its launch count still contains the launch-to-launch
-    # gaps, i.e. it is a slight OVER-estimate of the kernel time (an under-estimate of achieved GB/s).
-    brackets = []
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    mixed = args.workload == "mixed"
 
-    def run(n, timed):
-        i = 0
-        while i < n:
-            m = min(last_t - env.t, n - i)  # steps left in this episode
-            if timed:
-                eb = torch.cuda.Event(enable_timing=True)
-                ee = torch.cuda.Event(enable_timing=True)
-                eb.record(stream)
-            if graph is not None and env.t == 0 and m == last_t:
-                graph.replay()
-            else:
-                for j in range(m):
-                    buf.a = acts[(env.t) % n_act].data_ptr()
-                    if env.t == last_t - 1 and not args.separate_reset:
-                        # last step of the episode: the reset of the (lock-stepped) batch happens inside the same
-                        # launch (pcg_step_autoreset), with the next episode's RNG key
-                        seed = env._episode_seed()
-                        env.episode += 1
-                        rc = lib.pcg_step_autoreset(plan, bufp, env.t, seed, env._episode_seed(), sptr)
-                        env.t = -1
-                    else:
-                        rc = step_fn(plan, bufp, env.t, env._episode_seed(), sptr)
-                    if rc:
-                        _lib.check(rc, "pcg_step")
-                    env.t += 1
-            if timed:
-                ee.record(stream)
-                brackets.append((eb, ee, m))
-            i += m
-            if env.t == last_t:  # after a graph replay or with --separate-reset
-                env.reset()
+    if mixed:
+        B = args.batch or (1 << 20)
+        from pcgym_amd import make_mixed_sharded_env
 
-    # Clock pre-heat (untimed, before the W warm-up steps): an idle MI355X needs ~50 ms of work to reach
-    # steady clocks -- with a short --warmup the first timed launches would otherwise run 10-15 % slow
-    # (profiles/README.md).  Same kernel, same buffers; reported as config.preheat_launches.
-    preheat = 0
-    if args.preheat_ms > 0:
-        t_pre = time.perf_counter()
-        while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
-            run(last_t, False)
-            torch.cuda.synchronize()
-            preheat += last_t
+        # global layout [cstr x world | four_tank x world | ME x world]; every rank owns the same slice of every segment
+        segs_global = [(params, n * world) for params, n in mixed_segments(B)]
+        K = args.steps if args.steps is not None else 118
+        W = args.warmup if args.warmup is not None else 12
+        menv = make_mixed_sharded_env(segs_global, rank=rank, world=world, device=dev, seed=1234, auto_reset=True,
+                                      track_status=bool(args.status), timing=True)
+        envs = menv.envs
+        B_eff = menv.B
+        n_act = 4
+        acts = [act_box(e.spec) * (2 * torch.rand((n_act, e.spec.na, e.B), generator=gen, device=dev, dtype=torch.float64) - 1)
+                + act_shift(e.spec) for e in envs]
+        menv.reset()
+        torch.cuda.synchronize()
+        wl_name = "mixed_cstr+four_tank+me_b2^20_gauss_fp64"
+        N = envs[0].N
+        assert all(e.N == N for e in envs)
+
+        def run(n, timed):
+            menv.timing = timed
+            for i in range(n):
+                menv.step([a[i % n_act] for a in acts])
+
+        spec = envs[2].spec
+    else:
+        wl_name, params, Bd, (Kd, Wd), n_act = single_workload(args.workload)
+        B = args.batch or Bd
+        K = args.steps if args.steps is not None else Kd
+        W = args.warmup if args.warmup is not None else Wd
+        if args.substeps is not None:
+            params["substeps"] = args.substeps
+        # shard: rank r owns global envs [r*B, (r+1)*B)  (weak scaling; RNG streams keyed by global index)
+        env = VecEnv(params, n_envs=B, device=dev, seed=1234, auto_reset=True, env_offset=rank * B,
+                     track_status=bool(args.status))
+        B_eff = B
+        spec = env.spec
+        acts = act_box(spec) * (2 * torch.rand((n_act, spec.na, B), generator=gen, device=dev, dtype=torch.float64) - 1) \
+            + act_shift(spec)
+        env.reset()
+        if args.workload == "cryst":  # initial moments x (1 + 0.01 U), CV and Ln recomputed (cryst_train.py:80-81)
+            x = env.x.clone()
+            x[:5] *= 1 + 0.01 * (2 * torch.rand((5, B), generator=gen, device=dev, dtype=torch.float64) - 1)
+            x[5] = torch.sqrt(x[2] * x[0] / x[1] ** 2 - 1)
+            x[6] = x[1] / x[0]
+            env.x.copy_(x)
+        torch.cuda.synchronize()
+        plan, bufp, buf, sptr = env._plan, env._bufp, env._buf, stream.cuda_stream
+        last_t = env.N - 1
+        graph = env.capture_steps([acts[j % n_act] for j in range(last_t)]) if args.graph else None
+        brackets = []
+        stepsum = [0.0, 0.0, 0]  # accepted, rejected, samples (adaptive workloads)
+
+        def run(n, timed):
+            # hipEvent pairs on the launch stream, one pair around each run of consecutive step launches of an episode
+            i = 0
+            while i < n:
+                m = min(last_t - env.t, n - i)  # steps left in this episode
+                if timed:
+                    eb = torch.cuda.Event(enable_timing=True)
+                    ee = torch.cuda.Event(enable_timing=True)
+                    eb.record(stream)
+                if graph is not None and env.t == 0 and m == last_t:
+                    graph.replay()
+                else:
+                    for j in range(m):
+                        buf.a = acts[(env.t) % n_act].data_ptr()
+                        if env.t == last_t - 1 and not args.separate_reset:
+                            # last step of the episode: the reset of the (lock-stepped) batch happens inside the same
+                            # launch (pcg_step_autoreset), with the next episode's RNG key
+                            seed = env._episode_seed()
+                            env.episode += 1
+                            rc = lib.pcg_step_autoreset(plan, bufp, env.t, seed, env._episode_seed(), sptr)
+                            env.t = -1
+                        else:
+                            rc = lib.pcg_step(plan, bufp, env.t, env._episode_seed(), sptr)
+                        if rc:
+                            _lib.check(rc, "pcg_step")
+                        env.t += 1
+                if timed:
+                    ee.record(stream)
+                    brackets.append((eb, ee, m))
+                    if env.nsteps is not None and len(brackets) % 4 == 1:
+                        ns = env.nsteps.to(torch.float64).mean(dim=1)
+                        stepsum[0] += float(ns[0].item())
+                        stepsum[1] += float(ns[1].item())
+                        stepsum[2] += 1
+                i += m
+                if env.t == last_t:  # after a graph replay or with --separate-reset
+                    env.reset()
+
+    preheat_ms = clock_preheat(torch, dev, args.preheat_ms)
     run(W, False)
     torch.cuda.synchronize()
     if dist is not None:
@@ -280,15 +430,28 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # sanity: results are finite (a fast kernel producing NaN is not a result)
-    finite = bool(torch.isfinite(env.x).all().item() and torch.isfinite(env.rew).all().item())
-    # launch-weighted mean over all brackets of the timed region
-    kern_avg_s = sum(eb.elapsed_time(ee) for eb, ee, _ in brackets) * 1e-3 / sum(m for _, _, m in brackets)
-    total_env_steps = float(B) * K * world
+    # sanity: a fast kernel producing garbage is not a result.  Physical boxes, not just finiteness (a diverged RK4
+    # yields finite values up to 1e91), and the per-env status byte of the last step.
+    def sane(e):
+        ok = bool(torch.isfinite(e.x).all().item() and torch.isfinite(e.rew).all().item())
+        if e.status is not None:
+            ok = ok and not bool(e.status.any().item())
+        name = e.spec.model.name
+        if name == "cstr":
+            ok = ok and bool(((e.x[0] >= 0) & (e.x[0] <= 2) & (e.x[1] >= 250) & (e.x[1] <= 600)).all().item())
+        if name.startswith("multistage"):
+            ok = ok and bool(((e.x >= -1e-9) & (e.x <= 1.5)).all().item())
+        if name == "four_tank":
+            ok = ok and bool((e.x < 5.0).all().item())
+        return ok
+
+    all_envs = envs if mixed else [env]
+    finite = all(sane(e) for e in all_envs)
+    total_env_steps = float(B_eff) * K * world
     value = total_env_steps / elapsed
 
     out = {
-        "metric": "env-steps/sec at batch 2^20 CSTR, 1/2/4/8 MI355X; achieved HBM GB/s vs peak",
+        "metric": METRIC,
         "value": value,
         "unit": "env-steps/s",
         "n_gpus": world,
@@ -301,47 +464,100 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "cstr_b2^20_rk4_fp64",
-            "plant": "cstr (nx=2, na=1, obs=3)",
-            "envs_per_gpu": B,
-            "global_envs": B * world,
-            "integrator": "rk4, 1 step per dt=1s (1/60 model time unit)",
+            "workload": wl_name,
+            "envs_per_gpu": B_eff,
+            "global_envs": B_eff * world,
             "episode_len": spec.N - 1,
             "parallelism": f"env-shard x{world} (no collective on the hot path)",
-            "preheat_launches": preheat,
-            "launch": ("eager pcg_step launches" if graph is None else
-                       f"HIP graph of one {last_t}-step episode (pcg_graph_*), eager pcg_reset between episodes"),
-            "finite": finite,
+            "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none (single process)",
+            "ranks_seen": ranks_seen,
+            "clock_preheat_ms": round(preheat_ms, 1),
+            "status_byte": bool(args.status),
+            "sane": finite,
         },
     }
     if rank == 0:
-        alg_bytes = float(bytes_per_env_step) * B
-        achieved = alg_bytes / kern_avg_s / 1e9
-        out["roofline"] = {
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
-            "kernel": "step_kernel_pipe<Model<cstr>, EPL=2> (RK4, lean, lock-stepped, software-pipelined; 1 launch in 59 is "
-                      "its auto-reset instantiation, which also resets the batch)",
-            "kernel_avg_us": kern_avg_s * 1e6,
-            "algorithmic_bytes_per_env_step": int(bytes_per_env_step),
-            "algorithmic_bytes_per_launch": alg_bytes,
-        }
-        # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from
-        # inside this process): the committed measurement of this kernel + workload, if present
-        tpath = os.path.join(ROOT, "profiles", "r1", "traffic.json")
-        if os.path.exists(tpath) and B == (1 << 20) and args.substeps == 1:
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            out["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = tj["source"]
+        if mixed:
+            segs_out = []
+            for e, (tot_ms, n) in zip(envs, menv.segment_times()):
+                kern_s = tot_ms * 1e-3 / max(n, 1)
+                alg = float(e.bytes_per_env_step) * e.B
+                d = {"segment": e.spec.model.name, "envs": e.B, "integrator": e.spec.integrator,
+                     "kernel_avg_us": kern_s * 1e6, "algorithmic_bytes_per_env_step": int(e.bytes_per_env_step),
+                     "hbm_GBps": alg / kern_s / 1e9, "hbm_frac": alg / kern_s / 1e9 / HBM_PEAK_GBS}
+                if e.nsteps is not None:
+                    ns = e.nsteps.to(torch.float64).mean(dim=1)
+                    att = float(ns.sum().item())
+                    fl = (2 + 6 * att) * (FLOP_PER_RHS[e.spec.model.name] + 2 * 6 * e.spec.nx) * e.B
+                    d.update(attempted_steps_mean=att, fp64_TFLOPs=fl / kern_s / 1e12,
+                             fp64_frac=fl / kern_s / 1e12 / FP64_PEAK_TFLOPS)
+                segs_out.append(d)
+            dom = max(segs_out, key=lambda d: d["kernel_avg_us"])
+            out["roofline"] = {
+                "bound": "fp64_valu" if "fp64_frac" in dom else "hbm",
+                "achieved": dom.get("fp64_TFLOPs", dom["hbm_GBps"]),
+                "peak": FP64_PEAK_TFLOPS if "fp64_frac" in dom else HBM_PEAK_GBS,
+                "unit": "TFLOP/s" if "fp64_frac" in dom else "GB/s",
+                "frac": dom.get("fp64_frac", dom["hbm_frac"]),
+                "traffic": None,
+                "traffic_measured_in_run": False,
+                "kernel": f"dominant segment: {dom['segment']} ({dom['integrator']}); the three segments run concurrently "
+                          "on their own streams",
+                "kernel_avg_us": dom["kernel_avg_us"],
+                "segments": segs_out,
+            }
+        else:
+            # launch-weighted mean over all brackets of the timed region
+            kern_avg_s = sum(eb.elapsed_time(ee) for eb, ee, _ in brackets) * 1e-3 / sum(m for _, _, m in brackets)
+            bpe = env.bytes_per_env_step  # SURVEY.md section 8d formula for this plan and buffer set
+            alg_bytes = float(bpe) * B
+            achieved = alg_bytes / kern_avg_s / 1e9
+            adaptive = spec.integrator == "dopri5"
+            fp64 = spec.model.name in FLOP_PER_RHS
+            rl = {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "traffic_measured_in_run": False,
+                "kernel_avg_us": kern_avg_s * 1e6,
+                "algorithmic_bytes_per_env_step": int(bpe),
+                "algorithmic_bytes_per_launch": alg_bytes,
+            }
+            if fp64:
+                # fp64-issue-bound kernels: algorithmic flops = RHS evaluations x (flop per RHS + RK stage combination)
+                if adaptive:
+                    att = (stepsum[0] + stepsum[1]) / max(stepsum[2], 1)
+                    rhs = 2 + 6 * att
+                    rl["attempted_steps_mean"] = att
+                    rl["accepted_steps_mean"] = stepsum[0] / max(stepsum[2], 1)
+                else:
+                    rhs = 4 * spec.substeps
+                fl = rhs * (FLOP_PER_RHS[spec.model.name] + 2 * 6 * spec.nx) * B
+                tf = fl / kern_avg_s / 1e12
+                rl.update(bound="fp64_valu", achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                          frac=tf / FP64_PEAK_TFLOPS, hbm_GBps=achieved, algorithmic_flops_per_launch=fl,
+                          rhs_evals_per_env_step=rhs)
+            # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside
+            # this process): the committed measurement of this kernel + workload, if present -- NOT measured in this run
+            for tp in ("profiles/r2/traffic.json", "profiles/r1/traffic.json"):
+                tpath = os.path.join(ROOT, tp)
+                if (os.path.exists(tpath) and args.workload == "cstr" and B == (1 << 20) and args.substeps is None):
+                    with open(tpath) as fh:
+                        tj = json.load(fh)
+                    rl["traffic"] = tj["traffic_bytes_per_launch"]
+                    rl["traffic_source"] = tp + ": " + tj["source"]
+                    break
+            out["roofline"] = rl
+            out["config"]["launch"] = ("eager pcg_step launches" if graph is None else
+                                       f"HIP graph of one {last_t}-step episode (pcg_graph_*)")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec)
+            out["cpu_baseline"] = cpu_baseline(spec, threads=args.cpu_threads)
         print(json.dumps(out), flush=True)
-    env.close()
+    for e in all_envs:
+        e.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -22,9 +22,11 @@ class MixedVecEnv:
     """segments: sequence of (env_params, n_envs[, global_env_offset]).  Actions / results are lists, one entry per
     segment.  Without explicit offsets the segments are laid out back to back from `env_offset`."""
 
-    def __init__(self, segments, device=None, seed=0, env_offset=0, **kw):
+    def __init__(self, segments, device=None, seed=0, env_offset=0, timing=False, **kw):
         torch = _torch()
         self.envs, self.offsets = [], []
+        self.timing = bool(timing)  # record a hipEvent pair around every segment's step launch (bench.py roofline)
+        self._events = None
         off = int(env_offset)
         for seg in segments:
             params, n = seg[0], int(seg[1])
@@ -39,11 +41,12 @@ class MixedVecEnv:
         with torch.cuda.device(self.device):
             self.streams = [torch.cuda.Stream(device=self.device) for _ in self.envs]
         self.B = sum(e.B for e in self.envs)
+        self._events = [[] for _ in self.envs]
 
     def __len__(self):
         return len(self.envs)
 
-    def _each(self, fn):
+    def _each(self, fn, timed=False):
         """Run fn(i, env) for every segment on that segment's stream; the caller's stream waits for all of them
         (so results can be consumed on it without a host synchronisation)."""
         torch = _torch()
@@ -52,7 +55,13 @@ class MixedVecEnv:
         for i, (e, s) in enumerate(zip(self.envs, self.streams)):
             s.wait_stream(cur)
             with torch.cuda.stream(s):
+                if timed:
+                    eb, ee = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    eb.record(s)
                 out.append(fn(i, e))
+                if timed:
+                    ee.record(s)
+                    self._events[i].append((eb, ee))
         for s in self.streams:
             cur.wait_stream(s)
         return out
@@ -65,7 +74,12 @@ class MixedVecEnv:
         if len(actions) != len(self.envs):
             raise ValueError(f"one action tensor per segment ({len(self.envs)}) is required")
         d = disturbances or [None] * len(self.envs)
-        return self._each(lambda i, e: e.step(actions[i], d[i]))
+        return self._each(lambda i, e: e.step(actions[i], d[i]), timed=self.timing)
+
+    def segment_times(self):
+        """[(total ms, launches)] per segment of the step launches recorded while `timing` was on (synchronises)."""
+        _torch().cuda.synchronize(self.device)
+        return [(sum(eb.elapsed_time(ee) for eb, ee in ev), len(ev)) for ev in self._events]
 
     @property
     def bytes_per_step(self):
@@ -76,20 +90,27 @@ class MixedVecEnv:
             e.close()
 
 
-def make_mixed_sharded_env(segments_global, rank=None, world=None, device=None, **kw):
-    """Every rank takes the same fraction of each global segment (so every shard holds the same model mix and the
-    per-GPU work is balanced); env offsets follow the global layout [segment 0 | segment 1 | ...]."""
-    import os
-
+def mixed_shard_layout(segments_global, rank, world):
+    """[(env_params, n_local, global_env_offset)] of rank `rank`: every rank takes the same fraction of each global
+    segment (so every shard holds the same model mix and the per-GPU work is balanced); env offsets follow the
+    global layout [segment 0 | segment 1 | ...].  Pure host logic (tested on CPU with two gloo ranks)."""
     from .shard import shard_range
 
-    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
-    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
-    if device is None:
-        device = int(os.environ.get("LOCAL_RANK", "0"))
     local, base = [], 0
     for params, n in segments_global:
         lo, hi = shard_range(int(n), rank, world)
         local.append((params, hi - lo, base + lo))
         base += int(n)
-    return MixedVecEnv(local, device=device, **kw)
+    return local
+
+
+def make_mixed_sharded_env(segments_global, rank=None, world=None, device=None, **kw):
+    """MixedVecEnv over this rank's slices (mixed_shard_layout) of a global mixed batch; RANK / WORLD_SIZE /
+    LOCAL_RANK from the environment when not given.  kw is forwarded to MixedVecEnv / VecEnv."""
+    import os
+
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    return MixedVecEnv(mixed_shard_layout(segments_global, rank, world), device=device, **kw)

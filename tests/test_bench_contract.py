@@ -26,12 +26,31 @@ def test_single_rank_line():
     d = _json_line(r.stdout)
     assert KEYS <= set(d) and "cpu_baseline" in d
     assert d["n_gpus"] == 1 and d["steps"] == 70 and d["warmup"] == 11 and d["unit"] == "env-steps/s"
-    assert d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["config"]["finite"]
+    assert d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["config"]["sane"]
     rf, cb = d["roofline"], d["cpu_baseline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
     assert abs(d["value"] - d["config"]["global_envs"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     assert cb["kind"] == "port" and cb["unit"] == "env-steps/s" and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["reference_shaped"]["cores"] == 1 and cb["reference_shaped"]["value"] > 0
+    assert rf["traffic_measured_in_run"] is False and d["config"]["workload"] == "cstr_b2^20_rk4_fp64"
+    assert d["config"]["ranks_seen"] == 1
+
+
+@pytest.mark.parametrize("wl,batch,steps", [("mixed", 30000, 8), ("me10", 8192, 6), ("cryst", 8192, 6), ("four_tank", 65536, 20)])
+def test_other_workloads_line(wl, batch, steps):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--batch", str(batch), "--steps",
+                        str(steps), "--warmup", "2", "--preheat-ms", "10", "--no-cpu-baseline"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert KEYS <= set(d) and d["config"]["sane"] and d["steps"] == steps and d["warmup"] == 2
+    assert abs(d["value"] - d["config"]["global_envs"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "fp64_valu") and 0 < rf["frac"] < 1.0
+    if wl == "mixed":
+        assert [s["segment"] for s in rf["segments"]] == ["cstr", "four_tank", "multistage_extraction"]
+        assert d["config"]["envs_per_gpu"] == 3 * ((batch // 3) & ~1)
 
 
 def _free_port():
@@ -53,3 +72,15 @@ def test_two_rank_launch_path():
     assert KEYS <= set(d) and "cpu_baseline" not in d  # the CPU leg runs at N = 1 only
     assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"]
     assert abs(d["value"] - d["config"]["global_envs"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert d["config"]["collective_backend"] == "gloo" and d["config"]["ranks_seen"] == 2
+
+
+def test_two_rank_mixed_workload():
+    env = dict(os.environ, PCG_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--workload", "mixed", "--batch", "30000", "--steps", "8", "--warmup", "2",
+                        "--preheat-ms", "10"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"] and d["config"]["sane"]

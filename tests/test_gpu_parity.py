@@ -173,6 +173,10 @@ INT_CASES = [
 ]
 
 
+# GPU vs oracle on the adaptive path, identical step sequences: round-off only (growing modes amplify ulps)
+ADAPTIVE_TOL = {"biofilm_reactor": 1e-9, "batch": 1e-10, "polymerisation_reactor": 1e-10}
+
+
 @pytest.mark.parametrize("fix,model,kw,tol", INT_CASES)
 @pytest.mark.parametrize("lds_stages", [False, True])
 def test_integrate_vs_oracle(fix, model, kw, tol, lds_stages):
@@ -204,11 +208,14 @@ def test_integrate_vs_oracle(fix, model, kw, tol, lds_stages):
     want, ns_o = O.integrate(spec, xs, us)
     scale = np.maximum(np.abs(want), 1e-6 * np.max(np.abs(want), axis=1, keepdims=True))
     err = np.max(np.abs(got - want) / scale)
-    assert err <= tol, err
     if kw["integrator"] == "dopri5":
-        ns_g = ns.cpu().numpy()
-        # same controller: accepted/rejected counts agree except for razor-edge decisions
-        assert np.mean(ns_g == ns_o) >= 0.9
+        # the quantised step-size controller (DESIGN.md "Adaptive stepping") makes both sides take the SAME
+        # sequence of steps: accepted / rejected counts are identical for every sample and the states agree like
+        # the fixed-step ones
+        assert np.array_equal(ns.cpu().numpy(), ns_o), np.mean(ns.cpu().numpy() == ns_o)
+        assert err <= ADAPTIVE_TOL.get(fix, 1e-11), err
+    else:
+        assert err <= tol, err
     # and against the LSODA(1e-13) truth, in the integrator's accuracy class
     t = g["xf"][ok].T
     assert np.all(np.abs(got - t) <= 1e-5 * np.abs(t) + 1e-7)
@@ -274,24 +281,36 @@ def test_reference_kat_custom_linear_model_on_gpu():
 
 
 # ------------------------------------------- batched vs oracle, same algorithm
+RK = dict(integrator="rk4")  # cstr defaults to the adaptive pair; the fixed-step kernels are an explicit opt-in
 BATCH_CASES = [
-    ("cstr_canonical", {}, 1e-12),
-    ("cstr_cons_pen_norm", {}, 1e-12),
-    ("cstr_cons_done_raw", {}, 1e-12),
-    ("cstr_dist_both", {}, 1e-12),
+    ("cstr_canonical", RK, 1e-12),
+    ("cstr_canonical", {}, 1e-11),
+    ("cstr_cons_pen_norm", RK, 1e-12),
+    ("cstr_cons_pen_norm", {}, 1e-11),
+    ("cstr_cons_done_raw", RK, 1e-12),
+    ("cstr_dist_both", RK, 1e-12),
     ("four_tank_canonical", {}, 1e-12),
     ("me_canonical", dict(integrator="rk4", substeps=64), 1e-11),
-    ("me_canonical", {}, 1e-9),
-    ("me_dist_cons", {}, 1e-9),
+    ("me_canonical", {}, 1e-11),
+    ("me_dist_cons", {}, 1e-11),
     ("cryst_adelta", {}, 1e-10),
     ("me_reactive", dict(integrator="rk4", substeps=32), 1e-11),
-    ("cstr_batch_reward", {}, 1e-12),
-    ("cstr_paper_reward", {}, 1e-12),
+    ("cstr_batch_reward", RK, 1e-12),
+    ("cstr_paper_reward", RK, 1e-12),
+    ("cstr_paper_reward", {}, 1e-11),
     ("four_tank_paper_reward", {}, 1e-12),
-    ("cstr_con_reward", {}, 1e-12),
+    ("cstr_con_reward", RK, 1e-12),
     ("cryst_paper_reward", {}, 1e-10),
-    ("cstr_partial_obs", {}, 1e-12),
+    ("cstr_partial_obs", RK, 1e-12),
 ]
+
+
+def _rk4_if_cstr(p):
+    """cstr defaults to the adaptive pair (config.py); the tests that exercise the fixed-step kernels' mechanics
+    (lean / feature-masked pipelined kernels, fused rollout, step graphs) opt into RK4 explicitly."""
+    if p.get("model") == "cstr" and "integrator" not in p and p.get("integration_method", "hip") != "jax":
+        p["integrator"] = "rk4"
+    return p
 
 
 def _rand_actions(spec, T, B, seed):
@@ -315,15 +334,10 @@ def test_batched_step_vs_oracle(name, kw, tol, per_env_t, B):
     sc = SC.scenarios()[name]
     p = copy.deepcopy(sc["env_params"])
     p.update(kw)
-    # keep the ME cases in a moderately stiff regime so the CPU oracle finishes in seconds
     env = VecEnv(p, n_envs=B, seed=5, per_env_t=per_env_t)
     spec = env.spec
     orc = O.OracleEnv(spec, B, seed=5, per_env_t=per_env_t)
-    acts = _rand_actions(spec, T, B, 3)
-    if spec.model.name.startswith("multistage"):  # low-flow range: |lambda| dt of a few tens
-        lo, hi = spec.a_low[None, :, None], spec.a_high[None, :, None]
-        frac = np.random.default_rng(3).uniform(0.02, 0.2, (T, spec.na, B))
-        acts = (2 * frac - 1) if spec.normalise_a else lo + frac * (hi - lo)
+    acts = _rand_actions(spec, T, B, 3)  # the FULL action box (ME: L up to 500, G up to 1000, |lambda| dt ~ 240)
     adaptive = spec.integrator == "dopri5"
     o_g, _ = env.reset()
     o_c = orc.reset()
@@ -347,13 +361,14 @@ def test_batched_step_vs_oracle(name, kw, tol, per_env_t, B):
         eo = np.max(np.abs(og - oc) / sc_o, axis=0)
         er = np.abs(rg - rc) / np.maximum(np.abs(rc), 1.0)
         if adaptive:
-            # same controller on both sides: identical step sequences give ~1e-13 agreement; an env whose
-            # accept/reject decision lands within an ulp of E == 1 takes a different (equally valid) step
-            # sequence and then agrees only to the integrator tolerance (rtol = atol = 1e-8)
-            assert np.mean(ex <= tol) >= 0.97 and np.max(ex) <= 1e-6, (name, i, np.mean(ex <= tol), np.max(ex))
-            assert np.mean(eo <= tol * 10) >= 0.97 and np.max(eo) <= 1e-5, (name, i)
-            assert np.max(er) <= 1e-4, (name, i)
-            env.x.copy_(torch.tensor(orc.x, device=env.device))  # re-sync: every step is a one-step test
+            # quantised controller: both sides take the same step sequence for EVERY env, so the adaptive path is
+            # held to round-off like the fixed-step one, over the whole 12-step trajectory (no re-synchronisation)
+            ta = max(tol, 1e-11)
+            assert np.array_equal(env.nsteps.cpu().numpy(), orc.nsteps), (name, i)
+            assert np.max(ex) <= ta, (name, i, np.max(ex))
+            assert np.max(eo) <= ta * 10, (name, i, np.max(eo))
+            assert np.max(er) <= max(ta * 1e3, 1e-9), (name, i)
+            assert not env.status.any()
         else:
             assert np.max(eo) <= tol * 10, (name, i)
             assert np.max(ex) <= tol, (name, i)
@@ -382,6 +397,7 @@ def test_observation_noise_vs_oracle(name, B):
     from pcgym_amd import VecEnv
 
     p = copy.deepcopy(SC.scenarios()[name]["env_params"])
+    _rk4_if_cstr(p)
     p.update(noise=True, noise_percentage=0.02)
     env = VecEnv(p, n_envs=B, seed=13, env_offset=7 * 10**9)
     gen = VecEnv(p, n_envs=B, seed=13, env_offset=7 * 10**9, variant=1)  # the general kernel, forced
@@ -417,6 +433,7 @@ def test_noise_and_gaussian_disturbance_vs_oracle():
 
     sc = SC.scenarios()["cstr_dist_Ti"]
     p = copy.deepcopy(sc["env_params"])
+    _rk4_if_cstr(p)
     p.update(noise=True, noise_percentage=0.01, gaussian_disturbances={"Ti": 2.0})
     B = 1000
     env = VecEnv(p, n_envs=B, seed=77, env_offset=123456789012)
@@ -447,6 +464,7 @@ def test_reset_uncertainty_and_masked_reset():
     sc = SC.scenarios()["cstr_canonical"]
     for dist in ("uniform", "normal"):
         p = copy.deepcopy(sc["env_params"])
+        _rk4_if_cstr(p)
         p.update(uncertainty_percentages={"x0": [0.05, 0.01]}, distribution=dist,
                  uncertainty_bounds={"low": np.zeros(0), "high": np.zeros(0)})
         B = 4096
@@ -482,8 +500,8 @@ def test_rollout_equals_stepping():
     for name in ("cstr_canonical", "four_tank_canonical", "cstr_paper_reward"):
         sc = SC.scenarios()[name]
         B, T = 1000, 20
-        e1 = VecEnv(copy.deepcopy(sc["env_params"]), n_envs=B)
-        e2 = VecEnv(copy.deepcopy(sc["env_params"]), n_envs=B)
+        e1 = VecEnv(_rk4_if_cstr(copy.deepcopy(sc["env_params"])), n_envs=B)
+        e2 = VecEnv(_rk4_if_cstr(copy.deepcopy(sc["env_params"])), n_envs=B)
         acts = torch.tensor(_rand_actions(e1.spec, T, B, 4), device=e1.device)
         e1.reset()
         e2.reset()
@@ -512,8 +530,8 @@ def test_step_graph_equals_stepping():
     # (a) lean path (the headline kernel), steps only, recorded mid-episode
     sc = SC.scenarios()["cstr_canonical"]
     B, T = 4096, 12
-    e1 = VecEnv(copy.deepcopy(sc["env_params"]), n_envs=B)
-    e2 = VecEnv(copy.deepcopy(sc["env_params"]), n_envs=B)
+    e1 = VecEnv(_rk4_if_cstr(copy.deepcopy(sc["env_params"])), n_envs=B)
+    e2 = VecEnv(_rk4_if_cstr(copy.deepcopy(sc["env_params"])), n_envs=B)
     acts = torch.tensor(_rand_actions(e1.spec, T + 3, B, 9), device=e1.device)
     e1.reset()
     e2.reset()
@@ -538,6 +556,7 @@ def test_step_graph_equals_stepping():
     # (b) noisy path with reset inside the graph, two episodes: the second replay must use seed + 2
     sc = SC.scenarios()["cstr_dist_Ti"]
     p = copy.deepcopy(sc["env_params"])
+    _rk4_if_cstr(p)
     p.update(noise=True, noise_percentage=0.01, gaussian_disturbances={"Ti": 2.0})
     B = 1000
     e1 = VecEnv(copy.deepcopy(p), n_envs=B, seed=5)
@@ -611,6 +630,7 @@ def test_maximum_episode_length_schedules():
     N = abi.PCG_MAX_N
     rng = np.random.default_rng(4096)
     base = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+    _rk4_if_cstr(base)
     base.update(N=N, tsim=N / 60.0, SP={"Ca": (0.85 + 0.05 * rng.uniform(-1, 1, N)).tolist()})
     big = copy.deepcopy(base)
     big.update(disturbances={"Ti": 350.0 + 3.0 * rng.uniform(-1, 1, N), "Caf": 1.0 + 0.05 * rng.uniform(-1, 1, N)},
@@ -675,6 +695,7 @@ def test_tracking_reward_u_prev_survives_reset_like_the_reference():
     from pcgym_amd import VecEnv
 
     p = copy.deepcopy(SC.scenarios()["cstr_paper_reward"]["env_params"])
+    _rk4_if_cstr(p)
     B = 257
     env = VecEnv(p, n_envs=B, seed=2)
     orc = O.OracleEnv(env.spec, B, seed=2)
@@ -704,6 +725,7 @@ def test_fused_auto_reset_equals_step_then_masked_reset():
     from pcgym_amd import VecEnv
 
     p = copy.deepcopy(SC.scenarios()["cstr_cons_done_raw"]["env_params"])
+    _rk4_if_cstr(p)
     p.update(N=12, tsim=12 * 26.0 / 60.0, SP={"Ca": [0.85] * 12}, uncertainty_percentages={"x0": [0.1, 0.02]},
              distribution="uniform")
     B = 3000
@@ -739,9 +761,12 @@ def test_mixed_model_batch_segments_match_single_model_envs():
     from pcgym_amd import MixedVecEnv, VecEnv, make_mixed_sharded_env
 
     p0 = copy.deepcopy(SC.scenarios()["cstr_dist_Ti"]["env_params"])
+    _rk4_if_cstr(p0)
     p0.update(gaussian_disturbances={"Ti": 2.0})
     p1 = copy.deepcopy(SC.scenarios()["four_tank_canonical"]["env_params"])
+    _rk4_if_cstr(p1)
     p2 = copy.deepcopy(SC.scenarios()["me_canonical"]["env_params"])
+    _rk4_if_cstr(p2)
     sizes = [700, 500, 300]
     mixed = MixedVecEnv(list(zip([p0, p1, p2], sizes)), seed=8, env_offset=1000)
     assert mixed.B == sum(sizes) and mixed.offsets == [1000, 1700, 2200]
@@ -751,7 +776,7 @@ def test_mixed_model_batch_segments_match_single_model_envs():
         e.reset()
     gen = torch.Generator(device=mixed.device).manual_seed(3)
     for i in range(6):
-        acts = [0.3 * (2 * torch.rand((e.spec.na, e.B), generator=gen, device=e.device, dtype=torch.float64) - 1) - 0.5
+        acts = [2 * torch.rand((e.spec.na, e.B), generator=gen, device=e.device, dtype=torch.float64) - 1
                 for e in singles]
         outs = mixed.step(acts)
         for e, a, (o, r, d, _, _) in zip(singles, acts, outs):
@@ -780,6 +805,8 @@ def test_random_configurations_vs_oracle(seed):
 
     rng = np.random.default_rng(5000 + seed)
     p = _random_params(rng)
+    if p["model"] == "cstr" and seed % 3:  # two thirds on the fixed-step (feature-masked) kernels, one third adaptive
+        p["integrator"] = "rk4"
     per_env_t = bool(rng.integers(0, 2))
     B = int(rng.choice([255, 256, 770]))
     try:
@@ -793,8 +820,6 @@ def test_random_configurations_vs_oracle(seed):
     adaptive = spec.integrator == "dopri5"
     for i in range(spec.N - 1):
         a = rng.uniform(-1, 1, (spec.na, B))
-        if spec.model.name.startswith("multistage"):
-            a = 0.3 * a - 0.6
         if not spec.normalise_a:
             a = (a + 1) * (spec.a_high - spec.a_low)[:, None] / 2 + spec.a_low[:, None]
         og, rg, dg, _, _ = env.step(torch.tensor(a, device=env.device))
@@ -802,9 +827,8 @@ def test_random_configurations_vs_oracle(seed):
         xs = np.maximum(np.abs(orc.x), 1e-6 * np.max(np.abs(orc.x), axis=1, keepdims=True))
         ex = np.max(np.abs(env.x.cpu().numpy() - orc.x) / xs, axis=0)
         if adaptive:
-            assert np.mean(ex <= 1e-9) >= 0.97 and np.max(ex) <= 1e-6, (seed, i)
-            env.x.copy_(torch.tensor(orc.x, device=env.device))
-        else:
+            assert np.array_equal(env.nsteps.cpu().numpy(), orc.nsteps), (seed, i, spec.model.name)
+        if True:
             assert np.max(ex) <= 1e-10, (seed, i, spec.model.name)
             assert np.max(np.abs(og.cpu().numpy().T - oc) / np.maximum(np.abs(oc), 1e-3)) <= 1e-9, (seed, i)
             assert np.allclose(rg.cpu().numpy(), rc, rtol=1e-8, atol=1e-9), (seed, i)
@@ -825,6 +849,8 @@ def test_random_configurations_rollout_equals_stepping(seed):
 
     rng = np.random.default_rng(7000 + seed)
     p = _random_params(rng)
+    if p["model"] == "cstr" and seed % 2:
+        p["integrator"] = "rk4"
     B = int(rng.choice([254, 511]))
     try:
         e1 = VecEnv(copy.deepcopy(p), n_envs=B, seed=seed)
@@ -834,15 +860,13 @@ def test_random_configurations_rollout_equals_stepping(seed):
     spec = e1.spec
     T = spec.N - 1
     a = rng.uniform(-1, 1, (T, spec.na, B))
-    if spec.model.name.startswith("multistage"):
-        a = 0.3 * a - 0.6
     if not spec.normalise_a:
         a = (a + 1) * (spec.a_high - spec.a_low)[None, :, None] / 2 + spec.a_low[None, :, None]
     acts = torch.tensor(a, device=e1.device)
     e1.reset()
     e2.reset()
     obs_seq, rew_seq = e2.rollout(acts, collect_obs=True, collect_rew=True)
-    tol = 1e-6 if spec.integrator == "dopri5" else 1e-11
+    tol = 1e-11  # adaptive plans included: same per-env step sequences in both kernels
     for i in range(T):
         o, r, d, _, _ = e1.step(acts[i])
         assert torch.allclose(o.t().contiguous(), obs_seq[i], rtol=tol, atol=tol), (seed, i, spec.model.name)
@@ -866,6 +890,7 @@ def test_lock_stepped_auto_reset_in_the_last_step_launch(name, B):
     from pcgym_amd import VecEnv
 
     p = copy.deepcopy(SC.scenarios()[name]["env_params"])
+    _rk4_if_cstr(p)
     N = 9
     p["N"], p["tsim"] = N, N * float(p["tsim"]) / p["N"]
     p["SP"] = {k: list(np.asarray(v, dtype=float)[:N]) for k, v in p["SP"].items()}
@@ -875,11 +900,9 @@ def test_lock_stepped_auto_reset_in_the_last_step_launch(name, B):
     orc = O.OracleEnv(env.spec, B, seed=70)
     env.reset()
     orc.reset()
-    tol = 1e-8 if env.spec.integrator == "dopri5" else 1e-11
+    tol = 1e-10 if env.spec.integrator == "dopri5" else 1e-11
     for i in range(2 * (N - 1) + 3):
         a = np.random.default_rng(i).uniform(-1, 1, (env.spec.na, B))
-        if env.spec.model.name.startswith("multistage"):
-            a = 0.3 * a - 0.6
         og, rg, dg, _, _ = env.step(torch.tensor(a, device=env.device))
         oc, rc, dc = orc.step(a)
         rc, dc = rc.copy(), dc.copy()
@@ -910,6 +933,7 @@ def test_full_size_cstr_properties():
     B = 1 << 20
     sc = SC.scenarios()["cstr_canonical"]
     p = copy.deepcopy(sc["env_params"])
+    _rk4_if_cstr(p)
     # the bench workload: dt = 1 s (1/60 model time unit), one RK4 step; x0 box inside the basin of the
     # cold steady state (T0 < 334 K: no thermal runaway under any Tc in [295,302])
     p.update(integrator="rk4", substeps=1, tsim=1.0)
@@ -1007,6 +1031,7 @@ def test_full_size_me_and_cryst_properties():
     gen = torch.Generator(device="cuda").manual_seed(99)
     # ---- multistage extraction --------------------------------------------------------------
     p = copy.deepcopy(SC.scenarios()["me_canonical"]["env_params"])
+    _rk4_if_cstr(p)
     p.update(integrator="dopri5", N=200, tsim=200.0, SP={"X5": [0.3] * 200})
     env, env2 = VecEnv(p, n_envs=B), VecEnv(p, n_envs=B)
     env.reset()
@@ -1015,7 +1040,7 @@ def test_full_size_me_and_cryst_properties():
     perm = torch.randperm(B, generator=gen, device="cuda")
     env.x.copy_(x0)
     env2.x.copy_(x0[:, perm])
-    a = 0.3 * torch.rand((2, B), generator=gen, device="cuda", dtype=torch.float64) - 0.95  # low..moderate flows
+    a = 2 * torch.rand((2, B), generator=gen, device="cuda", dtype=torch.float64) - 1  # the full (L, G) box of configs[2]
     n_or = 2048
     orc = O.OracleEnv(env.spec, n_or)
     orc.reset()
@@ -1026,7 +1051,8 @@ def test_full_size_me_and_cryst_properties():
         orc.step(a[:, :n_or].cpu().numpy())
     assert torch.equal(env.x[:, perm], env2.x) and torch.equal(env.rew[perm], env2.rew)
     ex = np.abs(env.x[:, :n_or].cpu().numpy() - orc.x) / np.maximum(np.abs(orc.x), 1e-6)
-    assert np.mean(ex.max(axis=0) <= 1e-9) >= 0.97 and ex.max() <= 1e-5
+    assert ex.max() <= 1e-10, ex.max()  # every env of the slice: identical step sequences on both sides
+    assert np.array_equal(env.nsteps[:, :n_or].cpu().numpy(), orc.nsteps)
     for i in range(150):  # hold the input: the cascade settles (time constants of a few model time units)
         env.step(a)
     assert torch.isfinite(env.x).all()
@@ -1040,6 +1066,7 @@ def test_full_size_me_and_cryst_properties():
     env2.close()
     # ---- crystallisation ---------------------------------------------------------------------
     p = copy.deepcopy(SC.scenarios()["cryst_adelta"]["env_params"])
+    _rk4_if_cstr(p)
     p.update(integrator="rk4", substeps=32)
     env = VecEnv(p, n_envs=B)
     env.reset()
@@ -1071,6 +1098,7 @@ def test_affine_model_superposition():
 
     B = 1 << 18
     p = copy.deepcopy(SC.scenarios()["custom_linear_kat"]["env_params"])
+    _rk4_if_cstr(p)
     p.update(normalise_a=False, normalise_o=False)
     gen = torch.Generator(device="cuda").manual_seed(5)
     xs = [torch.randn((2, B), generator=gen, device="cuda", dtype=torch.float64) for _ in range(2)]
@@ -1113,6 +1141,7 @@ def test_collect_rollouts_reference_axis_order(name):
     g = H.gold("step_" + name)
     sc = SC.scenarios()[name]
     p = copy.deepcopy(sc["env_params"])
+    _rk4_if_cstr(p)
     p.update(H.tight_for(p))
     A = SC.actions_for(name, sc)                 # (T, na) scripted actions, T = N-1
     B, N = 64, p["N"]
@@ -1176,10 +1205,12 @@ def test_parameter_uncertainty_vs_oracle():
          "integrator": "rk4", "substeps": 16}
     cases.append((p, 1e-11))
     p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+    _rk4_if_cstr(p)
     p.update(uncertainty_percentages={"UA": 0.1, "x0": [0.02, 0.01], "Caf": 0.05}, distribution="uniform",
              uncertainty_bounds={"low": np.array([4e4, 0.9]), "high": np.array([6e4, 1.1])})
     cases.append((p, 1e-12))
     p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])  # empirical_distribution (pcgym.py:311-316)
+    _rk4_if_cstr(p)
     p.update(empirical_distribution={"UA": np.linspace(4.5e4, 5.5e4, 7), "Caf": np.array([0.95, 1.0, 1.05])},
              uncertainty_bounds={"low": np.array([4e4, 0.9]), "high": np.array([6e4, 1.1])})
     cases.append((p, 1e-10))  # UA down to 4.5e4 puts some envs close to ignition: rounding differences grow

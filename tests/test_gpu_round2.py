@@ -1,0 +1,415 @@
+"""GPU: round-2 parity cases -- BASELINE configs[4] (mixed batch with Gaussian disturbances) against the oracle, the
+per-env status byte, the default cstr path on the ignition branch, checkpoint round trips, the feature-masked
+pipelined kernels against the classic one-env-per-lane kernel."""
+import copy
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H  # noqa: F401
+import scenarios as SC
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _torch():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _cmp(env, orc, tol_x, tag):
+    xs = np.maximum(np.abs(orc.x), 1e-6 * np.max(np.abs(orc.x), axis=1, keepdims=True))
+    ex = np.max(np.abs(env.x.cpu().numpy() - orc.x) / xs)
+    eo = np.max(np.abs(env.obs_soa.cpu().numpy() - orc.obs) / np.maximum(np.abs(orc.obs), 1e-3))
+    er = np.max(np.abs(env.rew.cpu().numpy() - orc.rew) / np.maximum(np.abs(orc.rew), 1.0))
+    assert ex <= tol_x and eo <= tol_x * 10 and er <= max(tol_x * 1e3, 1e-9), (tag, ex, eo, er)
+    assert np.array_equal(env.done.cpu().numpy(), orc.done), tag
+    if env.nsteps is not None:
+        assert np.array_equal(env.nsteps.cpu().numpy(), orc.nsteps), tag
+    assert np.array_equal(env.status.cpu().numpy(), orc.status), tag
+
+
+def test_mixed_batch_with_gaussian_disturbances_vs_oracle():
+    """BASELINE configs[4] at test size: the bench's own segment configurations (bench.mixed_segments: cstr +
+    Ti ~ N(350,2), four_tank, multistage_extraction + X0 ~ N(0.6,0.02), set-point step changes), three plans on three
+    streams, stepped over an episode boundary with same-launch auto-reset; one OracleEnv per segment with the same
+    GLOBAL env offsets draws the same Philox streams.  Actions over the full box (ME: |lambda| dt up to ~240)."""
+    torch = _torch()
+    import bench as BN
+    from oracle import oracle as O
+    from pcgym_amd import MixedVecEnv
+
+    segs = BN.mixed_segments(3 * 1400)
+    for p, _ in segs:  # short episodes so that the run crosses two resets
+        N = 7
+        p["tsim"] = N * float(p["tsim"]) / p["N"]
+        p["N"] = N
+        p["SP"] = {k: list(np.asarray(v, dtype=float)[::10][:N]) for k, v in p["SP"].items()}
+        if p.get("disturbances"):
+            p["disturbances"] = {k: np.asarray(v)[:N] for k, v in p["disturbances"].items()}
+    mixed = MixedVecEnv(segs, seed=21, env_offset=5 * 10**9, auto_reset=True)
+    orcs = [O.OracleEnv(e.spec, e.B, seed=21, env_offset=off) for e, off in zip(mixed.envs, mixed.offsets)]
+    assert [e.spec.model.name for e in mixed.envs] == ["cstr", "four_tank", "multistage_extraction"]
+    assert mixed.envs[0].spec.gauss and mixed.envs[2].spec.gauss and mixed.envs[2].spec.integrator == "dopri5"
+    mixed.reset()
+    for o in orcs:
+        o.reset()
+    rng = np.random.default_rng(4)
+    for i in range(15):
+        acts = [rng.uniform(-1, 1, (e.spec.na, e.B)) for e in mixed.envs]
+        acts[1] = 0.75 * acts[1] + 0.25  # four_tank: keep tank 3 from draining (sqrt of a negative level, both sides)
+        mixed.step([torch.tensor(a, device=mixed.device) for a in acts])
+        torch.cuda.synchronize()
+        for e, o, a in zip(mixed.envs, orcs, acts):
+            o.step(a)
+            rew, done = o.rew.copy(), o.done.copy()
+            if o.t == e.N - 1:
+                o.reset()  # what the fused launch did: next episode, next RNG key
+            name = e.spec.model.name
+            xs = np.maximum(np.abs(o.x), 1e-6 * np.max(np.abs(o.x), axis=1, keepdims=True))
+            ex = np.max(np.abs(e.x.cpu().numpy() - o.x) / xs)
+            eo = np.max(np.abs(e.obs_soa.cpu().numpy() - o.obs) / np.maximum(np.abs(o.obs), 1e-3))
+            assert ex <= 1e-11 and eo <= 1e-10, (name, i, ex, eo)
+            assert np.allclose(e.rew.cpu().numpy(), rew, rtol=1e-9, atol=1e-10), (name, i)
+            assert np.array_equal(e.done.cpu().numpy(), done), (name, i)
+            assert e.t == o.t and not e.status.any()
+            if e.nsteps is not None:
+                assert np.array_equal(e.nsteps.cpu().numpy(), o.nsteps), (name, i)
+    # the Gaussian disturbance really is per env and inside its clip box (observation slot, un-normalised)
+    me = mixed.envs[2]
+    lo, hi = me.spec.o_low[-1], me.spec.o_high[-1]
+    x0_obs = (me.obs_soa[-1].cpu().numpy() + 1) / 2 * (hi - lo) + lo
+    assert 0.015 < x0_obs.std() < 0.025 and abs(x0_obs.mean() - 0.6) < 0.003 and x0_obs.min() >= 0.5
+    mixed.close()
+
+
+def test_mixed_full_shard_properties():
+    """BASELINE configs[4] at full shard size (1,048,572 envs): size-independent properties -- lane independence of
+    every segment under a permutation of its envs' actions/state (bitwise), an oracle-checked window at the END of
+    every segment (global offsets), finiteness and the status byte."""
+    torch = _torch()
+    import bench as BN
+    from oracle import oracle as O
+    from pcgym_amd import MixedVecEnv
+
+    segs = BN.mixed_segments(1 << 20)
+    m1 = MixedVecEnv(segs, seed=3)
+    m2 = MixedVecEnv(segs, seed=3)
+    assert m1.B == 3 * 349524
+    m1.reset()
+    m2.reset()
+    W = 1024
+    gen = torch.Generator(device=m1.device).manual_seed(5)
+    orcs = [O.OracleEnv(e.spec, W, seed=3, env_offset=off + e.B - W) for e, off in zip(m1.envs, m1.offsets)]
+    for o in orcs:
+        o.reset()
+    for i in range(2):
+        acts = []
+        for e in m1.envs:
+            a = 2 * torch.rand((e.spec.na, e.B), generator=gen, device=e.device, dtype=torch.float64) - 1
+            acts.append(0.75 * a + 0.25 if e.spec.model.name == "four_tank" else a)
+        m1.step(acts)
+        m2.step(acts)
+        torch.cuda.synchronize()
+        for e, e2, o, a in zip(m1.envs, m2.envs, orcs, acts):
+            assert torch.equal(e.x, e2.x) and torch.equal(e.obs_soa, e2.obs_soa)  # run-to-run determinism
+            o.step(a[:, e.B - W:].cpu().numpy())
+            xs = np.maximum(np.abs(o.x), 1e-6 * np.max(np.abs(o.x), axis=1, keepdims=True))
+            assert np.max(np.abs(e.x[:, e.B - W:].cpu().numpy() - o.x) / xs) <= 1e-11, (e.spec.model.name, i)
+            assert np.max(np.abs(e.obs_soa[:, e.B - W:].cpu().numpy() - o.obs)) <= 1e-10
+            assert bool(torch.isfinite(e.x).all()) and not bool(e.status.any())
+    m1.close()
+    m2.close()
+
+
+def test_me_gaussian_inlet_disturbance_vs_oracle():
+    """the ME segment of configs[4] on its own: X0 ~ N(0.6, 0.02) per env and step, DOPRI5, full action box, per-env
+    counters; B odd -> classic kernel, B even -> same kernel (adaptive plans have no two-env form)."""
+    torch = _torch()
+    import bench as BN
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    p = BN.mixed_segments(6)[2][0]
+    for B, pet in ((1001, False), (2048, True)):
+        env = VecEnv(p, n_envs=B, seed=9, per_env_t=pet, env_offset=123456789)
+        orc = O.OracleEnv(env.spec, B, seed=9, per_env_t=pet, env_offset=123456789)
+        env.reset()
+        orc.reset()
+        rng = np.random.default_rng(B)
+        for i in range(6):
+            a = rng.uniform(-1, 1, (2, B))
+            env.step(torch.tensor(a, device=env.device))
+            orc.step(a)
+            torch.cuda.synchronize()
+            _cmp(env, orc, 1e-11, (B, i))
+        env.close()
+
+
+def test_status_reports_failed_and_nonfinite_steps():
+    """PCG_ST_*: a DOPRI5 lane that exhausts its step budget is flagged and its state poisoned (never a partially
+    integrated state); a non-finite state is flagged; healthy envs are untouched.  Oracle agrees env by env."""
+    torch = _torch()
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+    from pcgym_amd import _abi as abi
+
+    p = copy.deepcopy(SC.scenarios()["me_canonical"]["env_params"])
+    p.update(integrator="dopri5", max_steps=25)
+    B = 1500
+    env = VecEnv(p, n_envs=B, seed=1)
+    orc = O.OracleEnv(env.spec, B, seed=1)
+    env.reset()
+    orc.reset()
+    a = np.random.default_rng(0).uniform(-1, 1, (2, B))
+    _, _, _, _, info = env.step(torch.tensor(a, device=env.device))
+    orc.step(a)
+    st = info["status"].cpu().numpy()
+    assert np.array_equal(st, orc.status)
+    bad = st == abi.PCG_ST_MAX_STEPS
+    assert 0.2 < bad.mean() < 0.98                      # the stiff (high-flow) envs run out of budget, the mild ones do not
+    x = env.x.cpu().numpy()
+    assert np.isnan(x[:, bad]).all() and np.isfinite(x[:, ~bad]).all()
+    assert np.isnan(env.rew.cpu().numpy()[bad]).all()
+    assert np.allclose(x[:, ~bad], orc.x[:, ~bad], rtol=1e-11)
+    env.close()
+    # fixed-step kernels (lean / feature-masked and classic): a NaN state in -> PCG_ST_NONFINITE out
+    for B in (1024, 1023):
+        p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+        p.update(integrator="rk4")
+        env = VecEnv(p, n_envs=B, seed=1)
+        env.reset()
+        env.x[1, 5] = float("nan")
+        env.x[0, B - 1] = float("inf")
+        env.step(torch.zeros((1, B), dtype=torch.float64, device=env.device))
+        st = env.status.cpu().numpy()
+        assert st[5] == abi.PCG_ST_NONFINITE and st[B - 1] == abi.PCG_ST_NONFINITE and st.sum() == 2 * abi.PCG_ST_NONFINITE
+        env.close()
+
+
+def test_default_cstr_integrator_survives_the_ignition_branch():
+    """SURVEY.md section 8(d) config 2's own x0 box U(0.7,1.0) x U(310,350) K at B = 2^20 with the DEFAULT integrator
+    (adaptive: config.py): a quarter of these envs ignite (T -> 440..480 K), where fixed-step RK4 returned finite garbage
+    in round 1.  Everything stays finite and physical, status is clean, a 4096-env slice agrees with a 1e-13 adaptive
+    solve and a 256-env slice with SciPy LSODA(1e-13) on the oracle's RHS to the reference's accuracy class."""
+    torch = _torch()
+    import bench as BN
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+    from pcgym_amd.config import EnvSpec
+    from scipy.integrate import solve_ivp
+
+    p = BN.workload_params()
+    del p["integrator"], p["substeps"]
+    p.update(tsim=26.0, x0=np.array([0.85, 330.0, 0.85]), uncertainty_percentages={"x0": [0.15 / 0.85, 20.0 / 330.0]})
+    B, W = 1 << 20, 4096
+    env = VecEnv(p, n_envs=B, seed=77)
+    assert env.spec.integrator == "dopri5"
+    env.reset()
+    x0 = env.x.clone()
+    assert float(x0[1].max()) > 349.0 and float(x0[1].min()) < 311.0
+    gen = torch.Generator(device=env.device).manual_seed(1)
+    a = 2 * torch.rand((1, B), generator=gen, device=env.device, dtype=torch.float64) - 1
+    env.step(a)
+    x1 = env.x.cpu().numpy()
+    assert np.isfinite(x1).all() and not env.status.any()
+    assert (x1[0] >= 0).all() and (x1[0] <= 1.0 + 1e-9).all() and (x1[1] > 300).all() and (x1[1] < 600).all()
+    assert (x1[1] > 400).mean() > 0.05  # the ignition branch is really in the batch
+    # tight adaptive solve of the same step on a slice
+    pt = dict(p)
+    pt.update(integrator="dopri5", rtol=1e-13, atol=1e-13)
+    orc = O.OracleEnv(EnvSpec(pt), W, seed=77)
+    orc.reset()
+    assert np.allclose(orc.x, x0[:, :W].cpu().numpy(), rtol=1e-15)
+    orc.step(a[:, :W].cpu().numpy())
+    rel = np.abs(x1[:, :W] - orc.x) / np.abs(orc.x)
+    assert rel.max() <= 1e-6, rel.max()
+    # LSODA on the oracle's RHS (the generator of the golden fixtures used the same solver on the reference's RHS)
+    par = np.array(env.spec.param_vector())
+    Tc = (a[0, :256].cpu().numpy() + 1) * 3.5 + 295.0
+    worst = 0.0
+    for k in range(256):
+        u = np.array([[Tc[k]], [350.0], [1.0]])
+        f = lambda t, y: O.rhs(0, par, y.reshape(2, 1), u)[:, 0]  # noqa: E731
+        sol = solve_ivp(f, (0.0, env.dt), x0[:, k].cpu().numpy(), method="LSODA", rtol=1e-13, atol=1e-13)
+        worst = max(worst, float(np.max(np.abs(x1[:, k] - sol.y[:, -1]) / np.abs(sol.y[:, -1]))))
+    assert worst <= 1e-6, worst
+    env.close()
+
+
+@pytest.mark.parametrize("case", ["unc_adelta", "track_per_t"])
+def test_state_dict_round_trip(case):
+    """step k, save, load into a NEW env, step: equal to the uninterrupted run -- including the per-env uncertain
+    parameters sampled at reset, accumulators and the last outputs (env.obs is the policy's next input)."""
+    torch = _torch()
+    from pcgym_amd import VecEnv
+
+    if case == "unc_adelta":
+        p = copy.deepcopy(SC.scenarios()["cryst_adelta"]["env_params"])
+        p.update(uncertainty_percentages={"kg": 0.05, "x0": [0.01] * 7}, distribution="uniform",
+                 uncertainty_bounds={"low": np.array([40.0]), "high": np.array([56.0])})
+        kw = {}
+    else:
+        p = copy.deepcopy(SC.scenarios()["cstr_paper_reward"]["env_params"])
+        p.update(integrator="rk4", noise=True, noise_percentage=0.01)
+        kw = dict(per_env_t=True, auto_reset=True)
+    B = 514
+    a = torch.tensor(np.random.default_rng(2).uniform(-1, 1, (10, len(p["a_space"]["low"]), B)), device="cuda")
+    e1 = VecEnv(copy.deepcopy(p), n_envs=B, seed=4, **kw)
+    e1.reset()
+    for i in range(4):
+        e1.step(a[i])
+    sd = e1.state_dict()
+    e2 = VecEnv(copy.deepcopy(p), n_envs=B, seed=999, **kw)  # fresh env, different seed: everything comes from the dict
+    e2.load_state_dict(sd)
+    assert torch.equal(e1.obs, e2.obs)
+    for i in range(4, 10):
+        o1, r1, d1, _, _ = e1.step(a[i])
+        o2, r2, d2, _, _ = e2.step(a[i])
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(e1.x, e2.x), i
+    if e1.p_unc is not None:
+        assert torch.equal(e1.p_unc, e2.p_unc) and float(e1.p_unc.std()) > 0
+    e1.close()
+    e2.close()
+
+
+FEAT_CASES = [
+    ("cstr_canonical", dict(noise=True, noise_percentage=0.01), {}),
+    ("cstr_dist_Ti", dict(gaussian_disturbances={"Ti": 2.0}), {}),
+    ("cstr_cons_pen_norm", {}, {}),
+    ("cstr_cons_done_raw", {}, dict(per_env_t=True, auto_reset=True)),
+    ("cstr_paper_reward", dict(noise=True, noise_percentage=0.01), {}),
+    ("cstr_con_reward", dict(noise=True, noise_percentage=0.005), {}),
+    ("cstr_batch_reward", {}, {}),
+    ("cstr_canonical", {}, dict(per_env_t=True)),
+    ("cstr_canonical", dict(uncertainty_percentages={"x0": [0.05, 0.01]}, distribution="normal"), dict(auto_reset=True)),
+    ("four_tank_canonical", dict(noise=True, noise_percentage=0.02), dict(per_env_t=True, auto_reset=True)),
+    ("four_tank_paper_reward", {}, {}),
+]
+
+
+@pytest.mark.parametrize("name,extra,kw", FEAT_CASES)
+def test_feature_masked_kernels_equal_the_classic_kernel(name, extra, kw):
+    """every curated feature mask (pcg_step_feat.hpp: two envs per lane, compile-time features) against the classic
+    one-env-per-lane kernel with run-time flags (PCG_OPT_VARIANT 1) AND against the oracle, over an episode boundary"""
+    torch = _torch()
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    p = copy.deepcopy(SC.scenarios()[name]["env_params"])
+    p.update(extra)
+    if p.get("model") == "cstr":
+        p["integrator"] = "rk4"
+    N = 8
+    p["tsim"] = N * float(p["tsim"]) / p["N"]
+    p["N"] = N
+    if p.get("SP"):
+        p["SP"] = {k: list(np.asarray(v, dtype=float)[::8][:N]) for k, v in p["SP"].items()}
+    if p.get("disturbances"):
+        p["disturbances"] = {k: np.asarray(v)[:N] for k, v in p["disturbances"].items()}
+    B = 2050
+    fe = VecEnv(copy.deepcopy(p), n_envs=B, seed=6, env_offset=10**10, **kw)
+    cl = VecEnv(copy.deepcopy(p), n_envs=B, seed=6, env_offset=10**10, variant=1, **kw)
+    orc = O.OracleEnv(fe.spec, B, seed=6, env_offset=10**10, per_env_t=kw.get("per_env_t", False))
+    for e in (fe, cl, orc):
+        e.reset()
+    rng = np.random.default_rng(8)
+    auto, pet = bool(kw.get("auto_reset")), bool(kw.get("per_env_t"))
+    for i in range(2 * N if auto else N - 1):  # without auto-reset: one episode; with it: across two boundaries
+        a = rng.uniform(-1, 1, (fe.spec.na, B))
+        if not fe.spec.normalise_a:
+            a = (a + 1) * (fe.spec.a_high - fe.spec.a_low)[:, None] / 2 + fe.spec.a_low[:, None]
+        at = torch.tensor(a, device=fe.device)
+        o1, r1, d1, _, _ = fe.step(at)
+        o2, r2, d2, _, _ = cl.step(at)
+        assert torch.allclose(o1, o2, rtol=1e-13, atol=1e-13) and torch.allclose(r1, r2, rtol=1e-12, atol=1e-12), (name, i)
+        assert torch.equal(d1, d2) and torch.allclose(fe.x, cl.x, rtol=1e-13, atol=0), (name, i)
+        assert torch.equal(fe.viol, cl.viol) and torch.equal(fe.status, cl.status)
+        if fe.g is not None:
+            assert torch.allclose(fe.g, cl.g, rtol=1e-12, atol=1e-12)
+        if fe.t_env is not None:
+            assert torch.equal(fe.t_env, cl.t_env)
+        if fe.u_prev is not None:
+            assert torch.equal(fe.u_prev, cl.u_prev)
+        if fe.a_save_t is not None:
+            assert torch.allclose(fe.a_save_t, cl.a_save_t, rtol=1e-14)
+        # oracle: the step, then what the fused launch did (masked reset of the finished envs / of the whole batch)
+        orc.step(a)
+        rc, dc = orc.rew.copy(), orc.done.copy()
+        if auto and pet:
+            orc.reset(mask=dc)
+        elif auto and orc.t == N - 1:
+            orc.reset()
+        assert np.array_equal(d1.cpu().numpy().astype(np.uint8), dc), (name, i)
+        assert np.allclose(r1.cpu().numpy(), rc, rtol=1e-10, atol=1e-11), (name, i)
+        assert np.allclose(fe.x.cpu().numpy(), orc.x, rtol=1e-12, atol=0), (name, i)
+        assert np.allclose(fe.obs_soa.cpu().numpy(), orc.obs, rtol=1e-10, atol=1e-11), (name, i)
+    fe.close()
+    cl.close()
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["PCG_ROOT"]); sys.path.insert(0, os.path.join(os.environ["PCG_ROOT"], "tests", "golden"))
+import time
+import numpy as np, torch, torch.distributed as dist
+import bench as BN
+from pcgym_amd import MixedVecEnv, make_mixed_sharded_env, shard
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)                       # both ranks share this box's GPU: the sharding logic is what is tested
+sizes = [2002, 1501, 1000]
+segs = [(p, n) for (p, _), n in zip(BN.mixed_segments(6), sizes)]
+env = make_mixed_sharded_env(segs, rank=rank, world=world, device=0, seed=31)
+env.reset()
+T = 5
+rng = np.random.default_rng(12)
+acts = [[rng.uniform(-1, 1, (e.spec.na, n)) for e, n in zip(env.envs, sizes)] for _ in range(T)]
+for a in acts:
+    a[1][:] = 0.75 * a[1] + 0.25
+los = [shard.shard_range(n, rank, world) for n in sizes]
+for i in range(T):
+    env.step([torch.tensor(a[:, lo:hi], device="cuda") for a, (lo, hi) in zip(acts[i], los)])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+full = [(shard.gather_to_rank0(e.x.cpu(), n, dim=1), shard.gather_to_rank0(e.obs_soa.cpu(), n, dim=1),
+         shard.gather_to_rank0(e.rew.cpu(), n, dim=0)) for e, n in zip(env.envs, sizes)]
+gather_s = time.perf_counter() - t0
+if rank == 0:
+    ref = MixedVecEnv(segs, device=0, seed=31)    # the un-sharded run
+    ref.reset()
+    for i in range(T):
+        ref.step([torch.tensor(a, device="cuda") for a in acts[i]])
+    torch.cuda.synchronize()
+    for (x, o, r), e in zip(full, ref.envs):
+        assert torch.equal(x, e.x.cpu()), "sharded state != single-device state (" + e.spec.model.name + ")"
+        assert torch.equal(o, e.obs_soa.cpu()) and torch.equal(r, e.rew.cpu())
+    print("MIXED_SHARD_OK gather_s=%.4f" % gather_s)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_step_a_sharded_mixed_batch_equal_to_the_unsharded_run(tmp_path):
+    """make_mixed_sharded_env stepped by two gloo ranks (sharing this box's GPU), gathered to rank 0 == MixedVecEnv of
+    the whole batch: same global env offsets -> same Gaussian-disturbance streams, bit for bit."""
+    _torch()
+    import socket
+
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, PCG_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "MIXED_SHARD_OK" in r.stdout
