@@ -487,8 +487,9 @@ PCG_DEV void store_feat(const StepArgs& A, CDevConst& c, int64_t e0, const Pack<
     store8(A.viol, z);
   }
   if (A.status) store8(A.status, out.status);
-  if constexpr ((FT & FT_PER_T) != 0)
-    *reinterpret_cast<typename VecI<W>::T*>(A.t + e0) = VecI<W>::make(out.t_new);
+  if constexpr ((FT & FT_PER_T) != 0) {
+    if (A.t) *reinterpret_cast<typename VecI<W>::T*>(A.t + e0) = VecI<W>::make(out.t_new);
+  }
   if constexpr ((FT & FT_ADELTA) != 0) {
     if (c.flags & PCG_F_A_DELTA) {
 #pragma unroll
@@ -525,7 +526,9 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel_feat(const StepArgs A) {
     for (int i = 0; i < NX; ++i) q.x[i] = *reinterpret_cast<const V*>(A.x + (size_t)i * B + ee);
 #pragma unroll
     for (int i = 0; i < NA; ++i) q.a[i] = *reinterpret_cast<const V*>(A.a + (size_t)i * B + ee);
-    if constexpr (PER_T) q.t = *reinterpret_cast<const typename VecI<W>::T*>(A.t + ee);
+    if constexpr (PER_T) {
+      if (A.t) q.t = *reinterpret_cast<const typename VecI<W>::T*>(A.t + ee);  // a PER_T instantiation also serves lock-stepped launches
+    }
     if constexpr (ADELTA) {
       if (ld_as) {
 #pragma unroll
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel_feat(const StepArgs A) {
         }
 #pragma unroll
         for (int k = 0; k < In::ND; ++k) dd[k].v[j] = DENV ? Vec<W>::get(cur.d[k], j) : 0.0;
-        tv[j] = PER_T ? VecI<W>::get(cur.t, j) : A.t_scalar;
+        tv[j] = (PER_T && A.t) ? VecI<W>::get(cur.t, j) : A.t_scalar;
       }
       FeatOut<M, W> out;
       env_step_feat<M, W, FT>(A, c, lds, e0, tv, as, sv, up, dd, xs, out);

@@ -53,3 +53,36 @@ TIGHT = {
 
 def tight_for(env_params):
     return TIGHT[env_params.get("model")]
+
+
+# ---- adaptive (DOPRI5) parity -------------------------------------------------------------------------------------
+# The step-size controller is quantised (DESIGN.md "Adaptive stepping"), so the GPU and the oracle take IDENTICAL step
+# sequences -- every env, checked as equality of the accepted / rejected counts, states to round-off -- whenever the
+# step size is set by ACCURACY.  Measured on the GPU (tools/parity_probe.py, profiles/r2/parity_probe.txt): 100 % of
+# 4096 envs for cstr, the 20-state reactive extraction model and every other registry model.
+# The 10-state extraction model over its full action box is the exception: at |lambda| dt ~ 240 and rtol = 1e-8 the
+# explicit pair runs at its STABILITY limit, where the embedded error estimate is round-off amplified by the marginally
+# stable high-frequency modes (~1e8 x): a last-bit difference of one RHS evaluation (FMA contraction on the GPU) changes
+# E by O(1) a few steps later.  There the two sides take different -- equally valid -- sequences for a few % of the
+# envs, and the comparison is: every env within the integrator's own tolerance class of the other side AND of a
+# 1e-12 solve, most envs still on identical counts.
+STABILITY_LIMITED = ("multistage_extraction",)
+
+
+def adaptive_check(model_name, x_gpu, x_orc, ns_gpu, ns_orc, tag, tol=1e-11, x_truth=None):
+    """x_* (nx, B); ns_* (2, B) accepted / rejected counts."""
+    xs = np.maximum(np.abs(x_orc), 1e-6 * np.max(np.abs(x_orc), axis=1, keepdims=True))
+    ex = np.max(np.abs(x_gpu - x_orc) / xs, axis=0)
+    same = np.all(ns_gpu == ns_orc, axis=0)
+    if model_name in STABILITY_LIMITED:
+        assert same.mean() >= 0.85, (tag, "identical step counts", same.mean())
+        assert ex.max() <= 2e-6, (tag, ex.max())
+        assert np.mean(ex <= 1e-9) >= 0.5, (tag, np.mean(ex <= 1e-9))
+        if x_truth is not None:
+            et = np.max(np.abs(x_gpu - x_truth) / xs, axis=0)
+            eo = np.max(np.abs(x_orc - x_truth) / xs, axis=0)
+            assert et.max() <= 3e-6 and et.max() <= 3 * max(eo.max(), 1e-7), (tag, "vs 1e-12 solve", et.max(), eo.max())
+    else:
+        assert same.all(), (tag, "identical step counts", same.mean())
+        assert ex.max() <= tol, (tag, ex.max())
+    return ex

@@ -33,7 +33,7 @@ def test_plain_c_host_matches_python_host(tmp_path):
          "o_space": {"low": np.array([0.7, 300.0, 0.8]), "high": np.array([1.0, 350.0, 0.9])},
          "a_space": {"low": np.array([295.0]), "high": np.array([302.0])}, "x0": np.array([0.8, 330.0, 0.8]),
          "r_scale": {"Ca": 1e3}, "normalise_a": True, "normalise_o": True, "integrator": "rk4", "substeps": 4}
-    env = VecEnv(p, n_envs=B, seed=1)
+    env = VecEnv(p, n_envs=B, seed=1, track_status=False)  # the C demo passes no status buffer
     assert got["bytes_per_env_step"][0] == env.bytes_per_env_step == 73
     env.reset()
     e = np.arange(B)
