@@ -522,7 +522,7 @@ ORC_EXPORT void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], 
 /* RNG contract shared with the kernels (DESIGN.md "RNG"):
  *   key = (seed_lo, seed_hi); ctr = (env_lo, env_hi, t, purpose + pair_index)
  *   purpose: 0x100 obs noise, 0x200 Gaussian disturbance, 0x300 reset uncertainty
- *   one block -> two uniforms (53-bit) -> one Box-Muller pair (z0 for even index, z1 odd) */
+ *   uniforms: one block -> two 53-bit uniforms;  normals (v2): one block -> two fp32 Box-Muller pairs */
 #define ORC_RNG_NOISE 0x100u
 #define ORC_RNG_DIST 0x200u
 #define ORC_RNG_RESET 0x300u
@@ -536,12 +536,57 @@ static void rng_uniform2(uint64_t seed, uint64_t env, uint32_t t, uint32_t strea
   *u1 = (double)(((uint64_t)(o[2] >> 5) << 26) | (uint64_t)(o[3] >> 6)) * (1.0 / 9007199254740992.0);
 }
 
+/* Box-Muller in fp32: the exact IEEE-754 single-precision operation sequence of box_muller_f32 in
+ * pc-gym_amd/csrc/pcg_kernels.hpp (DESIGN.md "RNG", contract v2) -- fmaf where the kernel has fmaf, no contraction
+ * elsewhere (-ffp-contract=off), correctly rounded divide / sqrtf / rintf: bit-identical variates on both sides. */
+static void box_muller_f32(uint32_t w0, uint32_t w1, float* z0, float* z1) {
+  const float u0 = (float)(((w0 >> 9) << 1) | 1u) * 0x1p-24f;
+  const float u1 = (float)(w1 >> 8) * 0x1p-24f;
+  int e;
+  float m = frexpf(u0, &e); /* [0.5, 1) */
+  if (m < 0.70710678f) { m = m + m; e = e - 1; }
+  const float s = (m - 1.0f) / (m + 1.0f);
+  const float q = s * s;
+  float p = 0.22222222f;
+  p = fmaf(p, q, 0.28571429f);
+  p = fmaf(p, q, 0.4f);
+  p = fmaf(p, q, 0.66666667f);
+  const float lm = fmaf(s * q, p, s + s);
+  const float fe = (float)e;
+  const float ln = fmaf(fe, 0.693359375f, fmaf(fe, -2.12194440e-4f, lm));
+  float arg = -2.0f * ln;
+  if (!(arg > 0.0f)) arg = 0.0f;
+  const float r = sqrtf(arg);
+  const float x = u1 + u1;
+  const float n = rintf(x + x);
+  const float a = fmaf(n, -0.5f, x) * 3.14159274f;
+  const float a2 = a * a;
+  float ps = 2.7557319e-6f;
+  ps = fmaf(ps, a2, -1.9841270e-4f);
+  ps = fmaf(ps, a2, 8.3333333e-3f);
+  ps = fmaf(ps, a2, -0.16666667f);
+  const float sy = fmaf(a * a2, ps, a);
+  float pc = 2.4801587e-5f;
+  pc = fmaf(pc, a2, -1.3888889e-3f);
+  pc = fmaf(pc, a2, 4.1666667e-2f);
+  pc = fmaf(pc, a2, -0.5f);
+  const float cy = fmaf(a2, pc, 1.0f);
+  const int qd = (int)n & 3;
+  const float ss = (qd & 1) ? cy : sy, cc = (qd & 1) ? sy : cy;
+  *z1 = r * ((qd & 2) ? -ss : ss);
+  *z0 = r * (((qd + 1) & 2) ? -cc : cc);
+}
+
+/* variate idx of a purpose: pair idx/2 lives in Philox block (purpose + idx/4), words (0,1) / (2,3) */
 static double rng_normal(uint64_t seed, uint64_t env, uint32_t t, uint32_t purpose, int idx) {
-  double u0, u1;
-  rng_uniform2(seed, env, t, purpose + (uint32_t)(idx >> 1), &u0, &u1);
-  double r = sqrt(-2.0 * log(1.0 - u0));
-  double th = 6.283185307179586476925286766559 * u1;
-  return (idx & 1) ? r * sin(th) : r * cos(th);
+  uint32_t pair = (uint32_t)(idx >> 1);
+  uint32_t ctr[4] = {(uint32_t)env, (uint32_t)(env >> 32), t, purpose + (pair >> 1)};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t o[4];
+  orc_philox4x32_10(ctr, key, o);
+  float z0, z1;
+  box_muller_f32((pair & 1u) ? o[2] : o[0], (pair & 1u) ? o[3] : o[1], &z0, &z1);
+  return (double)((idx & 1) ? z1 : z0);
 }
 
 static double rng_uniform(uint64_t seed, uint64_t env, uint32_t t, uint32_t purpose, int idx) {

@@ -587,16 +587,16 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   if (p->integrator_id == PCG_INT_RK4 && k.nfeat > 0 && !lds_st && (p->variant == 0 || p->variant == 4)) {
     unsigned need = 0;
     if (c.flags & PCG_F_NOISE) need |= FT_NOISE;
-    if ((c.flags & PCG_F_GAUSS_DIST) && c.nd > 0) need |= FT_GAUSS;
     if (c.ncon > 0) need |= FT_CONS;
     if (c.flags & PCG_F_A_DELTA) need |= FT_ADELTA;
     if (c.flags & PCG_F_REWARD_TRACK) need |= FT_TRACK;
     if (c.flags & PCG_F_REWARD_BATCH) need |= FT_BATCH;
-    if (per_env_t) need |= FT_PER_T;
-    if (io->d) need |= FT_DENV;
     if (auto_reset) need |= FT_AR;
-    bool ok = (io->B % 2 == 0) && al16(io->x) && al16(io->a) && al16(io->obs) && al16(io->rew) && al2(io->done) &&
-              al2(io->viol) && al2(io->status) && (reinterpret_cast<uintptr_t>(io->t) & 7u) == 0 && al16(io->d) &&
+    // per-env step counters, per-env / Gaussian disturbances: the classic kernel is the faster one (measured), and a
+    // lock-stepped same-launch reset needs every env to end together
+    bool ok = !per_env_t && !io->d && !((c.flags & PCG_F_GAUSS_DIST) && c.nd > 0) &&
+              !(auto_reset && (c.flags & PCG_F_DONE_ON_CONS) && c.ncon > 0) && (io->B % 2 == 0) && al16(io->x) &&
+              al16(io->a) && al16(io->obs) && al16(io->rew) && al2(io->done) && al2(io->viol) && al2(io->status) &&
               al16(io->a_save) && al16(io->u_prev) && al16(io->g) && al16(io->g_pre);
     int best = -1;
     for (int i = 0; ok && i < k.nfeat; ++i)
@@ -616,10 +616,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       int64_t grid = (int64_t)p->num_cus * bpc;
       if (grid > ntile) grid = ntile;
       a.nt_stores = p->nt_stores;
-      const size_t sh = (per_env_t && a.sched_in_lds) ? sizeof(double) * (size_t)(c.nsp + c.nd) * c.N : 0;
-      if (sh > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)k.feat[best].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-      hipLaunchKernelGGL(k.feat[best].fn, dim3((unsigned)grid), dim3(BLOCK), sh, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(k.feat[best].fn, dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
       return (int)hipGetLastError();
     }
   }

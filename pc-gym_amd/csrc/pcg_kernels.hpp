@@ -145,7 +145,7 @@ struct StepArgs {
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11).  RNG contract:
 //   key = (seed_lo, seed_hi); ctr = (env_lo, env_hi, t, purpose + pair index)
-//   one block -> two 53-bit uniforms -> one Box-Muller pair.
+//   uniform draws: one block -> two 53-bit uniforms;  normal draws: one block -> four fp32 Box-Muller variates (v2).
 // ---------------------------------------------------------------------------
 constexpr uint32_t RNG_NOISE = 0x100u, RNG_DIST = 0x200u, RNG_RESET = 0x300u;
 
@@ -173,15 +173,64 @@ PCG_DEV void rng_uniform2(uint64_t seed, uint64_t env, uint32_t t, uint32_t stre
   u1 = (double)(((uint64_t)(o[2] >> 5) << 26) | (uint64_t)(o[3] >> 6)) * (1.0 / 9007199254740992.0);
 }
 
+// Box-Muller in fp32, as an explicit sequence of IEEE-754 single-precision operations (no contraction, fmaf where
+// written, correctly rounded divide and square root) -- DESIGN.md "RNG", contract v2.  Every operation is exactly
+// specified, so the oracle's C twin (fmaf / sqrtf / rintf) produces the SAME BITS, and the variate costs ~65 fp32
+// instructions for two normals instead of ~100 fp64 ones at half the issue rate (the fp64 log / sqrt / sincospi of
+// round 1 made observation noise cost more VALU time than the whole RK4 step: profiles/r1/exploration.md).  A 24-bit
+// uniform and ~1e-7 relative accuracy are far beyond what a noise sample needs (the reference draws np.random.normal).
+//   u0 = odd 24-bit integer * 2^-24 in (0,1),  u1 = 24-bit integer * 2^-24 in [0,1)
+//   ln u0 = e ln2 + 2 atanh(s), s = (m-1)/(m+1), m in [sqrt(1/2), sqrt(2));   r = sqrt(-2 ln u0)
+//   angle 2 pi u1 by quarter turns, Taylor polynomials on [-pi/4, pi/4];   z0 = r cos, z1 = r sin
+PCG_DEV void box_muller_f32(uint32_t w0, uint32_t w1, float& z0, float& z1) {
+#pragma clang fp contract(off)
+  const float u0 = (float)(((w0 >> 9) << 1) | 1u) * 0x1p-24f;
+  const float u1 = (float)(w1 >> 8) * 0x1p-24f;
+  float m = __builtin_amdgcn_frexp_mantf(u0);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_expf(u0);
+  const bool lo = m < 0.70710678f;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const float s = (m - 1.0f) / (m + 1.0f);
+  const float q = s * s;
+  float p = 0.22222222f;
+  p = __builtin_fmaf(p, q, 0.28571429f);
+  p = __builtin_fmaf(p, q, 0.4f);
+  p = __builtin_fmaf(p, q, 0.66666667f);
+  const float lm = __builtin_fmaf(s * q, p, s + s);
+  const float fe = (float)e;
+  const float ln = __builtin_fmaf(fe, 0.693359375f, __builtin_fmaf(fe, -2.12194440e-4f, lm));
+  const float r = __builtin_sqrtf(__builtin_fmaxf(-2.0f * ln, 0.0f));
+  const float x = u1 + u1;  // [0, 2)
+  const float n = __builtin_rintf(x + x);  // quarter-turn index 0..4
+  const float a = __builtin_fmaf(n, -0.5f, x) * 3.14159274f;  // [-pi/4, pi/4]
+  const float a2 = a * a;
+  float ps = 2.7557319e-6f;
+  ps = __builtin_fmaf(ps, a2, -1.9841270e-4f);
+  ps = __builtin_fmaf(ps, a2, 8.3333333e-3f);
+  ps = __builtin_fmaf(ps, a2, -0.16666667f);
+  const float sy = __builtin_fmaf(a * a2, ps, a);
+  float pc = 2.4801587e-5f;
+  pc = __builtin_fmaf(pc, a2, -1.3888889e-3f);
+  pc = __builtin_fmaf(pc, a2, 4.1666667e-2f);
+  pc = __builtin_fmaf(pc, a2, -0.5f);
+  const float cy = __builtin_fmaf(a2, pc, 1.0f);
+  const int qd = (int)n & 3;
+  const float ss = (qd & 1) ? cy : sy, cc = (qd & 1) ? sy : cy;
+  z1 = r * ((qd & 2) ? -ss : ss);
+  z0 = r * (((qd + 1) & 2) ? -cc : cc);
+}
+
+// `stream` = purpose + pair index p (p = variate index / 2): pair p lives in Philox block (purpose + p/2), words
+// (0,1) for even p and (2,3) for odd p -- one block serves four normal variates.
 PCG_DEV void rng_normal2(uint64_t seed, uint64_t env, uint32_t t, uint32_t stream, double& z0, double& z1) {
-  double u0, u1;
-  rng_uniform2(seed, env, t, stream, u0, u1);
-  // 1 - u0 is in [2^-53, 1]: the range-restricted log / sqrt of pcg_pack.hpp apply (<= 2 ulp of the library forms)
-  const double r = sqrt_pos(-2.0 * log_pos(1.0 - u0));
-  double s, c;
-  sincospi_unit(2.0 * u1, s, c);  // angle = 2*pi*u1, u1 in [0,1)
-  z0 = r * c;
-  z1 = r * s;
+  const uint32_t pair = stream & 0xFFu, purpose = stream & ~0xFFu;
+  uint32_t o[4];
+  philox4x32_10((uint32_t)env, (uint32_t)(env >> 32), t, purpose + (pair >> 1), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  float f0, f1;
+  box_muller_f32((pair & 1u) ? o[2] : o[0], (pair & 1u) ? o[3] : o[1], f0, f1);
+  z0 = (double)f0;
+  z1 = (double)f1;
 }
 
 // value at runtime index `idx` of a register array, without dynamic register indexing

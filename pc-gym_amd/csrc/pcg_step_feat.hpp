@@ -12,10 +12,14 @@
 //     mask costs neither scalar branches nor registers; a feature in the mask is still gated by cfg.flags, so an
 //     instantiation serves every configuration whose needs are a SUBSET of its mask;
 //   * step_kernel_feat<M, W, FT>: the software-pipelined persistent kernel of step_kernel_pipe with the feature's
-//     extra per-env rows (step counter, a_delta accumulator, previous action, explicit disturbance) riding in the
-//     same prefetch, 16 bytes per lane and row;
+//     extra per-env rows (a_delta accumulator, previous action) riding in the same prefetch, 16 bytes per lane and row;
 //   * feat_table<M>(): the curated list of masks built for a model (the single features, the pairs the paper
 //     configurations use, "everything"); the host picks the smallest superset of what a launch needs.
+//
+// Measured (profiles/r2/extras_probe.txt, cstr B = 2^20): this shape wins for constraint rows (16.4 vs 18.2 us) and
+// observation noise (16.1 vs 16.7), ties for the tracking reward, and LOSES to the classic one-env-per-lane kernel
+// for per-env step counters (16.0 vs 14.9), Gaussian / per-env disturbances (18.0 vs 17.2) -- so those three stay
+// on the classic kernel and are not features here (first cut had them: removed with the data).
 //
 // Statement order follows make_env.step (reference src/pcgym/pcgym.py:350-500) exactly as env_step does; both are
 // checked against the same oracle recordings.  Only RK4 plans of the small HBM-bound models (NX <= 4) come here:
@@ -26,36 +30,13 @@ namespace pcg {
 
 enum : unsigned {
   FT_NOISE = 1u,    // PCG_F_NOISE                      pcgym.py:453-466
-  FT_GAUSS = 2u,    // PCG_F_GAUSS_DIST                 (extension, BASELINE configs[4])
   FT_CONS = 4u,     // constraint rows, penalty, done-on-violation   pcgym.py:414-420, 443-446, 560-615
   FT_ADELTA = 8u,   // PCG_F_A_DELTA                    pcgym.py:376-383
   FT_TRACK = 16u,   // PCG_F_REWARD_TRACK               pc-gym_paper/.../custom_reward.py
   FT_BATCH = 32u,   // PCG_F_REWARD_BATCH               pcgym.py:502-532
-  FT_PER_T = 64u,   // per-env step counters (io->t)
-  FT_DENV = 128u,   // per-env explicit disturbances (io->d)
-  FT_AR = 256u,     // same-launch auto-reset (pcg_step_autoreset)
-  FT_ALL = 511u
+  FT_AR = 256u,     // same-launch auto-reset of a lock-stepped batch (pcg_step_autoreset)
+  FT_ALL = FT_NOISE | FT_CONS | FT_ADELTA | FT_TRACK | FT_BATCH | FT_AR
 };
-
-template <int W>
-struct VecI;
-template <>
-struct VecI<1> {
-  using T = int32_t;
-  PCG_DEV static int get(const T& v, int) { return v; }
-  PCG_DEV static T make(const int (&s)[1]) { return s[0]; }
-};
-template <>
-struct VecI<2> {
-  using T = int2;
-  PCG_DEV static int get(const T& v, int j) { return j ? v.y : v.x; }
-  PCG_DEV static T make(const int (&s)[2]) { return make_int2(s[0], s[1]); }
-};
-PCG_DEV void land(int32_t& v) { asm volatile("" : "+v"(v)); }
-PCG_DEV void land(int2& v) {
-  asm volatile("" : "+v"(v.x));
-  asm volatile("" : "+v"(v.y));
-}
 
 template <int W>
 PCG_DEV Pack<W> pk_clamp(const Pack<W>& a, double lo, double hi) {
@@ -64,57 +45,47 @@ PCG_DEV Pack<W> pk_clamp(const Pack<W>& a, double lo, double hi) {
   for (int j = 0; j < W; ++j) r.v[j] = fmin(fmax(a.v[j], lo), hi);
   return r;
 }
-PCG_DEV double pk_lane(double s, int) { return s; }
-template <int W>
-PCG_DEV double pk_lane(const Pack<W>& s, int j) { return s.v[j]; }
-
 // what one tile's lane holds on arrival: the W envs' state and action, plus the rows the features need
 template <class M, int W, unsigned FT>
 struct FeatIn {
   using V = typename Vec<W>::T;
-  static constexpr int ND = M::NDM > 0 ? M::NDM : 1;
-  V x[M::NX], a[M::NA], asave[M::NA], uprev[M::NA], d[ND];
-  typename VecI<W>::T t;
+  V x[M::NX], a[M::NA], asave[M::NA], uprev[M::NA];
 };
 
 template <class M, int W>
 struct FeatOut {
   static constexpr int ND = M::NDM > 0 ? M::NDM : 1;
-  Pack<W> ox[M::NX], osp[PCG_MAX_NSP], od[ND], rew, asave[M::NA];
-  int t_new[W];
+  Pack<W> ox[M::NX], rew, asave[M::NA];
+  double osp[PCG_MAX_NSP], od[ND];  // wave-uniform (lock-stepped batch, shared schedules)
   bool done[W], viol[W];
   uint8_t status[W];
+  bool reset;  // this lane's envs were reset in the launch (FT_AR)
 };
 
 // constraint rows g = A.[x|sp|d|u] - b for the W envs of a lane (affine form of the reference's callable,
-// pcgym.py:560-577).  store: 0 = nowhere, 1 = all W envs as one 16-byte store per row, 2 = only the envs with
-// sel[j] (8-byte stores; the t == 0 pre-step check of a batch whose envs carry their own counters).
-template <class M, int W, class S>
-PCG_DEV void constraint_rows_w(CDevConst& c, const Pack<W> (&x)[M::NX], const S (&spv)[PCG_MAX_NSP],
-                               const Pack<W> (&dv)[FeatOut<M, W>::ND], const Pack<W> (&u)[M::NA + M::NDM], double* gout,
-                               int store, const bool (&sel)[W], int64_t B, int64_t e0, bool (&violated)[W]) {
+// pcgym.py:560-577); rows go to gout (16-byte store per row) when it is non-null.
+template <class M, int W>
+PCG_DEV void constraint_rows_w(CDevConst& c, const Pack<W> (&x)[M::NX], const double (&spv)[PCG_MAX_NSP],
+                               const double (&dv)[FeatOut<M, W>::ND], const Pack<W> (&u)[M::NA + M::NDM], double* gout,
+                               int64_t B, int64_t e0, bool (&violated)[W]) {
 #pragma unroll
   for (int j = 0; j < W; ++j) violated[j] = false;
   for (int r = 0; r < c.ncon; ++r) {
     const PCG_CONSTANT double* row = c.con_A[r];
-    Pack<W> g(-c.con_b[r]);
+    double gu = -c.con_b[r];  // the wave-uniform part of the row first (scalar unit)
+#pragma unroll
+    for (int k = 0; k < PCG_MAX_NSP; ++k) gu += row[PCG_MAX_NX + k] * spv[k];
+#pragma unroll
+    for (int k = 0; k < M::NDM; ++k) gu += row[PCG_MAX_NX + PCG_MAX_NSP + k] * dv[k];
+    Pack<W> g(gu);
 #pragma unroll
     for (int i = 0; i < M::NX; ++i) g = g + row[i] * x[i];
-#pragma unroll
-    for (int k = 0; k < PCG_MAX_NSP; ++k) g = g + row[PCG_MAX_NX + k] * spv[k];
-#pragma unroll
-    for (int k = 0; k < M::NDM; ++k) g = g + row[PCG_MAX_NX + PCG_MAX_NSP + k] * dv[k];
 #pragma unroll
     for (int j = 0; j < M::NA; ++j) g = g + row[PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + j] * u[j];
 #pragma unroll
     for (int j = 0; j < M::NDM; ++j)
       g = g + row[PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + PCG_MAX_NA + j] * u[M::NA + j];
-    if (gout && store == 1) Vec<W>::store_nt(gout + (size_t)r * B + e0, g.v);
-    if (gout && store == 2) {
-#pragma unroll
-      for (int j = 0; j < W; ++j)
-        if (sel[j]) gout[(size_t)r * B + e0 + j] = g.v[j];
-    }
+    if (gout) Vec<W>::store_nt(gout + (size_t)r * B + e0, g.v);
 #pragma unroll
     for (int j = 0; j < W; ++j) violated[j] |= (g.v[j] > 0.0);
   }
@@ -146,41 +117,24 @@ PCG_DEV void reset_vals(const StepArgs& A, CDevConst& c, uint64_t env_id, uint64
 }
 
 // ---------------------------------------------------------------------------
-// One env step for the W envs of a lane, features by compile-time mask.
+// One env step for the W envs of a lane, features by compile-time mask.  The batch is lock-stepped: the step
+// counter, the schedule values, the SP / disturbance slots are wave-uniform scalars.
 // ---------------------------------------------------------------------------
 template <class M, int W, unsigned FT>
-PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, const double* sched_l, int64_t e0, const int (&tv)[W],
-                           const Pack<W> (&a_in)[M::NA], const Pack<W> (&asave_in)[M::NA],
-                           const Pack<W> (&uprev_in)[M::NA], const Pack<W> (&d_in)[FeatOut<M, W>::ND],
-                           Pack<W> (&x)[M::NX], FeatOut<M, W>& out) {
+PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, int64_t e0, int t, const Pack<W> (&a_in)[M::NA],
+                           const Pack<W> (&asave_in)[M::NA], const Pack<W> (&uprev_in)[M::NA], Pack<W> (&x)[M::NX],
+                           FeatOut<M, W>& out) {
   static_assert(!M::DYNAMIC, "the feature kernels are built for the fixed-size models");
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM, ND = FeatOut<M, W>::ND;
-  constexpr bool NOISE = FT & FT_NOISE, GAUSS = FT & FT_GAUSS, CONS = FT & FT_CONS, ADELTA = FT & FT_ADELTA,
-                 TRACK = FT & FT_TRACK, BATCH = FT & FT_BATCH, PER_T = FT & FT_PER_T, DENV = FT & FT_DENV,
-                 AR = FT & FT_AR;
+  constexpr bool NOISE = FT & FT_NOISE, CONS = FT & FT_CONS, ADELTA = FT & FT_ADELTA, TRACK = FT & FT_TRACK,
+                 BATCH = FT & FT_BATCH, AR = FT & FT_AR;
   using R = Pack<W>;
-  using S = typename std::conditional<PER_T, R, double>::type;  // values that depend on the step counter only
   const int64_t B = A.B;
   const uint32_t flags = c.flags;
   const int N = c.N, nsp = c.nsp, nso = c.nsp_obs, nd = c.nd;
   typename M::CKP& kp = *(typename M::CKP*)c.kp;
-  int tn[W], tc[W];
-#pragma unroll
-  for (int j = 0; j < W; ++j) {
-    tn[j] = min(tv[j] + 1, N - 1);  // schedule index clamp (the reference would IndexError)
-    tc[j] = min(tv[j], N - 1);
-  }
-  auto sched = [&](int row, const int(&idx)[W]) -> S {
-    if constexpr (PER_T) {
-      R r;
-#pragma unroll
-      for (int j = 0; j < W; ++j)
-        r.v[j] = A.sched_in_lds ? sched_l[row * N + idx[j]] : A.sched[(size_t)row * N + idx[j]];
-      return r;
-    } else {
-      return A.sched[(size_t)row * N + idx[0]];
-    }
-  };
+  const int tn = min(t + 1, N - 1);  // schedule index clamp (the reference would IndexError)
+  const int tc = min(t, N - 1);
   // ---- action map (pcgym.py:371-383) ----
   R u[NA + NDM];
 #pragma unroll
@@ -194,69 +148,36 @@ PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, const double* sched_
     }
     u[i] = av;
   }
-  // ---- disturbance injection (pcgym.py:386-412) ----
-  R dv[ND];
+  // ---- disturbance injection from the shared schedule (pcgym.py:386-412) ----
+  double dv[ND], ud[ND];
 #pragma unroll
-  for (int k = 0; k < ND; ++k) dv[k] = R(0.0);
+  for (int k = 0; k < ND; ++k) dv[k] = 0.0;
 #pragma unroll
-  for (int j = 0; j < NDM; ++j) u[NA + j] = R(c.d_default[j]);
-  if (NDM > 0 && nd > 0) {
+  for (int j = 0; j < NDM; ++j) ud[j] = c.d_default[j];
 #pragma unroll
-    for (int k = 0; k < NDM; ++k)
-      if (k < nd) {
-        R v(0.0);
-        bool from_env = false;
-        if constexpr (DENV) {
-          if (A.d) {
-            v = d_in[k];
-            from_env = true;
-          }
-        }
-        if (!from_env) {
-          const S sv = sched(nsp + k, tn);  // Q6: index t+1
+  for (int k = 0; k < NDM; ++k)
+    if (k < nd) {
+      const double v = A.sched[(size_t)(nsp + k) * N + tn];  // Q6: index t+1
+      dv[k] = v;
+      const int slot = c.d_slot[k];
 #pragma unroll
-          for (int j = 0; j < W; ++j) v.v[j] = pk_lane(sv, j);
-        }
-        if constexpr (GAUSS) {
-          if (flags & PCG_F_GAUSS_DIST) {
+      for (int j = 0; j < NDM; ++j) ud[j] = (j == slot) ? v : ud[j];
+    }
 #pragma unroll
-            for (int j = 0; j < W; ++j) {
-              double z0, z1;
-              rng_normal2(A.seed, (uint64_t)(A.env_offset + e0 + j), (uint32_t)tv[j], RNG_DIST + (uint32_t)(k >> 1), z0, z1);
-              v.v[j] += c.d_sigma[k] * ((k & 1) ? z1 : z0);
-              v.v[j] = fmin(fmax(v.v[j], c.d_lo[k]), c.d_hi[k]);
-            }
-          }
-        }
-        dv[k] = v;
-        const int slot = c.d_slot[k];
-#pragma unroll
-        for (int j = 0; j < NDM; ++j)
-#pragma unroll
-          for (int w = 0; w < W; ++w) u[NA + j].v[w] = (j == slot) ? v.v[w] : u[NA + j].v[w];
-      }
-  }
+  for (int j = 0; j < NDM; ++j) u[NA + j] = R(ud[j]);
   // ---- pre-step constraint check at t == 0 (pcgym.py:414-420) ----
   bool done[W], violated[W];
 #pragma unroll
   for (int j = 0; j < W; ++j) done[j] = violated[j] = false;
   if constexpr (CONS) {
-    if (c.ncon > 0) {
-      bool at0[W], any0 = false;
+    if (c.ncon > 0 && t == 0) {
+      double sp0[PCG_MAX_NSP];
 #pragma unroll
-      for (int j = 0; j < W; ++j) {
-        at0[j] = tv[j] == 0;
-        any0 |= at0[j];
-      }
-      if (any0) {
-        double sp0[PCG_MAX_NSP];
+      for (int k = 0; k < PCG_MAX_NSP; ++k) sp0[k] = (k < nso) ? c.x0[NX + k] : 0.0;
+      bool v0[W];
+      constraint_rows_w<M, W>(c, x, sp0, dv, u, A.g_pre, B, e0, v0);
 #pragma unroll
-        for (int k = 0; k < PCG_MAX_NSP; ++k) sp0[k] = (k < nso) ? c.x0[NX + k] : 0.0;
-        bool v0[W];
-        constraint_rows_w<M, W, double>(c, x, sp0, dv, u, A.g_pre, PER_T ? 2 : 1, at0, B, e0, v0);
-#pragma unroll
-        for (int j = 0; j < W; ++j) done[j] = at0[j] && v0[j] && (flags & PCG_F_DONE_ON_CONS);
-      }
+      for (int j = 0; j < W; ++j) done[j] = v0[j] && (flags & PCG_F_DONE_ON_CONS);
     }
   }
   // ---- integrate over [0, dt], u held (pcgym.py:423-429, integrator.py:90-107,163-182) ----
@@ -266,32 +187,24 @@ PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, const double* sched_
     rk4<NX>(f, x, c.h, c.substeps);
   }
   // ---- SP slot uses SP[t_old] (pcgym.py:432-438, quirk Q5); t += 1 ----
-  S spv[PCG_MAX_NSP], spn[PCG_MAX_NSP];
+  double spv[PCG_MAX_NSP], spn[PCG_MAX_NSP];
 #pragma unroll
   for (int k = 0; k < PCG_MAX_NSP; ++k) {
-    spv[k] = S(0.0);
-    spn[k] = S(0.0);
-    if (k < nsp) {
-      spv[k] = sched(k, tc);
-      spn[k] = sched(k, tn);
-    }
+    spv[k] = (k < nsp) ? A.sched[(size_t)k * N + tc] : 0.0;
+    spn[k] = (k < nsp) ? A.sched[(size_t)k * N + tn] : 0.0;
   }
-#pragma unroll
-  for (int j = 0; j < W; ++j) out.t_new[j] = tv[j] + 1;
+  const int t_new = t + 1;
   // ---- post-step constraints (pcgym.py:443-446) ----
   if constexpr (CONS) {
     if (c.ncon > 0) {
-      bool all[W];
-#pragma unroll
-      for (int j = 0; j < W; ++j) all[j] = true;
-      constraint_rows_w<M, W, S>(c, x, spv, dv, u, A.g, 1, all, B, e0, violated);
+      constraint_rows_w<M, W>(c, x, spv, dv, u, A.g, B, e0, violated);
 #pragma unroll
       for (int j = 0; j < W; ++j) done[j] |= violated[j] && (flags & PCG_F_DONE_ON_CONS);
     }
   }
 #pragma unroll
   for (int j = 0; j < W; ++j) {
-    done[j] |= (out.t_new[j] == N - 1);  // pcgym.py:448-449
+    done[j] |= (t_new == N - 1);  // pcgym.py:448-449
     out.done[j] = done[j];
     out.viol[j] = violated[j];
   }
@@ -300,16 +213,17 @@ PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, const double* sched_
   bool batch = false;
   if constexpr (BATCH) batch = (flags & PCG_F_REWARD_BATCH) != 0;
   if (batch) {  // pcgym.py:502-532
-    R rb(0.0);
-    for (int k = 0; k < c.nrew; ++k) {
-      const R v = pick<NX, W>(x, c.rew_index[k]) * c.r_scale[k];
-      rb = (flags & PCG_F_MAXIMISE) ? rb + v : rb - v;
-    }
+    if (t_new == N - 1) {
+      for (int k = 0; k < c.nrew; ++k) {
+        const R v = pick<NX, W>(x, c.rew_index[k]) * c.r_scale[k];
+        r = (flags & PCG_F_MAXIMISE) ? r + v : r - v;
+      }
+      if constexpr (CONS) {
+        if (flags & PCG_F_R_PENALTY) {
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
-      double v = rb.v[j];
-      if (CONS && (flags & PCG_F_R_PENALTY) && violated[j]) v -= 1000.0;
-      r.v[j] = (out.t_new[j] == N - 1) ? v : 0.0;
+          for (int j = 0; j < W; ++j) r.v[j] -= violated[j] ? 1000.0 : 0.0;
+        }
+      }
     }
   } else {  // pcgym.py:535-558
 #pragma unroll
@@ -336,7 +250,7 @@ PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, const double* sched_
 #pragma unroll
         for (int j = 0; j < W; ++j) {
           double z0, z1;
-          rng_normal2(A.seed, (uint64_t)(A.env_offset + e0 + j), (uint32_t)tv[j], RNG_NOISE + (uint32_t)(i >> 1), z0, z1);
+          rng_normal2(A.seed, (uint64_t)(A.env_offset + e0 + j), (uint32_t)t, RNG_NOISE + (uint32_t)(i >> 1), z0, z1);
           on[i].v[j] += z0 * x[i].v[j] * c.noise_pct[i];
           if (i + 1 < NX) on[i + 1].v[j] += z1 * x[i + 1].v[j] * c.noise_pct[i + 1];
         }
@@ -353,7 +267,7 @@ PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, const double* sched_
       for (int k = 0; k < PCG_MAX_NSP; ++k)
         if (k < nsp) {
           const R xn = (pick<NX, W>(on, c.sp_index[k]) - c.trk_lo[k]) * c.trk_inv[k];
-          const S sn = (spn[k] - c.trk_lo[k]) * c.trk_inv[k];
+          const double sn = (spn[k] - c.trk_lo[k]) * c.trk_inv[k];
           cost = cost + ((xn - sn) * (xn - sn)) * c.r_scale[k];
         }
 #pragma unroll
@@ -384,11 +298,7 @@ PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, const double* sched_
   out.rew = r;
 #pragma unroll
   for (int k = 0; k < PCG_MAX_NSP; ++k)
-    if (k < nso) {
-      const S o = (spv[k] - c.omap[NX + k].lo) * c.omap[NX + k].sc + c.omap[NX + k].off;
-#pragma unroll
-      for (int j = 0; j < W; ++j) out.osp[k].v[j] = pk_lane(o, j);
-    }
+    if (k < nso) out.osp[k] = (spv[k] - c.omap[NX + k].lo) * c.omap[NX + k].sc + c.omap[NX + k].off;
 #pragma unroll
   for (int k = 0; k < NDM; ++k)
     if (k < nd) out.od[k] = (dv[k] - c.omap[NX + nso + k].lo) * c.omap[NX + nso + k].sc + c.omap[NX + nso + k].off;
@@ -401,12 +311,14 @@ PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, const double* sched_
     out.status[j] = ok ? PCG_ST_OK : PCG_ST_NONFINITE;
   }
   // ---- same-launch auto-reset (pcg_step_autoreset): reward / done / viol / status of the finished step stay,
-  //      state, observation, step counter and a_delta accumulator become those of the new episode ----
+  //      state, observation and a_delta accumulator become those of the new episode ----
+  out.reset = false;
   if constexpr (AR) {
     bool any = false;
 #pragma unroll
     for (int j = 0; j < W; ++j) any |= done[j];
     if (A.auto_reset && any) {
+      out.reset = true;
 #pragma unroll
       for (int j = 0; j < W; ++j) {
         double xv[NX], ov[NX];
@@ -417,22 +329,23 @@ PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, const double* sched_
             x[i].v[j] = xv[i];
             out.ox[i].v[j] = ov[i];
           }
-#pragma unroll
-          for (int k = 0; k < PCG_MAX_NSP; ++k)
-            if (k < nso) out.osp[k].v[j] = (c.x0[NX + k] - c.omap[NX + k].lo) * c.omap[NX + k].sc + c.omap[NX + k].off;
-#pragma unroll
-          for (int k = 0; k < NDM; ++k)
-            if (k < nd) {  // disturbances[k][0] (pcgym.py:291-298, quirk Q6)
-              const int q = NX + nso + k;
-              out.od[k].v[j] = (A.sched[(size_t)(nsp + k) * N] - c.omap[q].lo) * c.omap[q].sc + c.omap[q].off;
-            }
           if constexpr (ADELTA) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) out.asave[i].v[j] = c.a_0[i];
           }
-          out.t_new[j] = 0;
         }
       }
+      // the SP / disturbance slots of a reset observation (pcgym.py:291-298, quirk Q6: disturbances[k][0]); a
+      // lock-stepped batch without done-on-violation ends for every env at once, so they stay wave-uniform
+#pragma unroll
+      for (int k = 0; k < PCG_MAX_NSP; ++k)
+        if (k < nso) out.osp[k] = (c.x0[NX + k] - c.omap[NX + k].lo) * c.omap[NX + k].sc + c.omap[NX + k].off;
+#pragma unroll
+      for (int k = 0; k < NDM; ++k)
+        if (k < nd) {
+          const int q = NX + nso + k;
+          out.od[k] = (A.sched[(size_t)(nsp + k) * N] - c.omap[q].lo) * c.omap[q].sc + c.omap[q].off;
+        }
     }
   }
 }
@@ -444,34 +357,33 @@ PCG_DEV void store_feat(const StepArgs& A, CDevConst& c, int64_t e0, const Pack<
   constexpr int NX = M::NX;
   const int64_t B = A.B;
   const int nso = c.nsp_obs, nd = c.nd;
+  auto put = [&](double* p, const double(&v)[W]) {
+    if (nt) Vec<W>::store_nt(p, v);
+    else *reinterpret_cast<V*>(p) = Vec<W>::make(v);
+  };
+  double tmp[W];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     *reinterpret_cast<V*>(A.x + (size_t)i * B + e0) = Vec<W>::make(x[i].v);
-    if (nt) Vec<W>::store_nt(A.obs + (size_t)i * B + e0, out.ox[i].v);
-    else *reinterpret_cast<V*>(A.obs + (size_t)i * B + e0) = Vec<W>::make(out.ox[i].v);
+    put(A.obs + (size_t)i * B + e0, out.ox[i].v);
   }
 #pragma unroll
   for (int k = 0; k < PCG_MAX_NSP; ++k)
     if (k < nso) {
-      if (nt) Vec<W>::store_nt(A.obs + (size_t)(NX + k) * B + e0, out.osp[k].v);
-      else *reinterpret_cast<V*>(A.obs + (size_t)(NX + k) * B + e0) = Vec<W>::make(out.osp[k].v);
+#pragma unroll
+      for (int j = 0; j < W; ++j) tmp[j] = out.osp[k];
+      put(A.obs + (size_t)(NX + k) * B + e0, tmp);
     }
 #pragma unroll
   for (int k = 0; k < M::NDM; ++k)
     if (k < nd) {
-      if (nt) Vec<W>::store_nt(A.obs + (size_t)(NX + nso + k) * B + e0, out.od[k].v);
-      else *reinterpret_cast<V*>(A.obs + (size_t)(NX + nso + k) * B + e0) = Vec<W>::make(out.od[k].v);
-    }
-  if (nt) Vec<W>::store_nt(A.rew + e0, out.rew.v);
-  else *reinterpret_cast<V*>(A.rew + e0) = Vec<W>::make(out.rew.v);
-  auto pack8 = [](const uint8_t(&b)[W]) {
-    uint32_t v = 0;
 #pragma unroll
-    for (int j = 0; j < W; ++j) v |= (uint32_t)b[j] << (8 * j);
-    return v;
-  };
+      for (int j = 0; j < W; ++j) tmp[j] = out.od[k];
+      put(A.obs + (size_t)(NX + nso + k) * B + e0, tmp);
+    }
+  put(A.rew + e0, out.rew.v);
   auto store8 = [&](uint8_t* p, const uint8_t(&b)[W]) {
-    if (W == 2) *reinterpret_cast<uint16_t*>(p + e0) = (uint16_t)pack8(b);
+    if (W == 2) *reinterpret_cast<uint16_t*>(p + e0) = (uint16_t)((uint32_t)b[0] | ((uint32_t)b[W - 1] << 8));
     else p[e0] = b[0];
   };
   uint8_t bd[W], bv[W];
@@ -481,15 +393,8 @@ PCG_DEV void store_feat(const StepArgs& A, CDevConst& c, int64_t e0, const Pack<
     bv[j] = out.viol[j] ? 1 : 0;
   }
   store8(A.done, bd);
-  if ((FT & FT_CONS) && A.viol) store8(A.viol, bv);
-  if (!(FT & FT_CONS) && A.viol) {
-    const uint8_t z[W] = {};
-    store8(A.viol, z);
-  }
+  if (A.viol) store8(A.viol, bv);
   if (A.status) store8(A.status, out.status);
-  if constexpr ((FT & FT_PER_T) != 0) {
-    if (A.t) *reinterpret_cast<typename VecI<W>::T*>(A.t + e0) = VecI<W>::make(out.t_new);
-  }
   if constexpr ((FT & FT_ADELTA) != 0) {
     if (c.flags & PCG_F_A_DELTA) {
 #pragma unroll
@@ -505,30 +410,24 @@ PCG_DEV void store_feat(const StepArgs& A, CDevConst& c, int64_t e0, const Pack<
 // ---------------------------------------------------------------------------
 template <class M, int W, unsigned FT>
 __global__ __launch_bounds__(BLOCK, 1) void step_kernel_feat(const StepArgs A) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
   CDevConst& c = *A.C;
-  constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
-  constexpr bool ADELTA = FT & FT_ADELTA, TRACK = FT & FT_TRACK, PER_T = FT & FT_PER_T, DENV = FT & FT_DENV;
+  constexpr int NX = M::NX, NA = M::NA;
+  constexpr bool ADELTA = FT & FT_ADELTA, TRACK = FT & FT_TRACK;
   using V = typename Vec<W>::T;
   using In = FeatIn<M, W, FT>;
   const int64_t B = A.B;
   const uint32_t flags = c.flags;
   const bool nt = A.nt_stores != 0;
-  if (PER_T) stage_schedules(A, c, lds);
   constexpr int64_t TILE = (int64_t)BLOCK * W;
   const int64_t ntile = (B + TILE - 1) / TILE;
   int64_t it = blockIdx.x;
   if (it >= ntile) return;
   const bool ld_as = ADELTA && (flags & PCG_F_A_DELTA), ld_up = TRACK && (flags & PCG_F_REWARD_TRACK);
-  const bool ld_d = DENV && A.d != nullptr;
   auto load = [&](int64_t ee, In& q) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) q.x[i] = *reinterpret_cast<const V*>(A.x + (size_t)i * B + ee);
 #pragma unroll
     for (int i = 0; i < NA; ++i) q.a[i] = *reinterpret_cast<const V*>(A.a + (size_t)i * B + ee);
-    if constexpr (PER_T) {
-      if (A.t) q.t = *reinterpret_cast<const typename VecI<W>::T*>(A.t + ee);  // a PER_T instantiation also serves lock-stepped launches
-    }
     if constexpr (ADELTA) {
       if (ld_as) {
 #pragma unroll
@@ -541,20 +440,12 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel_feat(const StepArgs A) {
         for (int i = 0; i < NA; ++i) q.uprev[i] = *reinterpret_cast<const V*>(A.u_prev + (size_t)i * B + ee);
       }
     }
-    if constexpr (DENV) {
-      if (ld_d) {
-#pragma unroll
-        for (int k = 0; k < NDM; ++k)
-          if (k < c.nd) q.d[k] = *reinterpret_cast<const V*>(A.d + (size_t)k * B + ee);
-      }
-    }
   };
   auto landall = [&](In& q) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) land(q.x[i]);
 #pragma unroll
     for (int i = 0; i < NA; ++i) land(q.a[i]);
-    if constexpr (PER_T) land(q.t);
     if constexpr (ADELTA) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) land(q.asave[i]);
@@ -562,10 +453,6 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel_feat(const StepArgs A) {
     if constexpr (TRACK) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) land(q.uprev[i]);
-    }
-    if constexpr (DENV) {
-#pragma unroll
-      for (int k = 0; k < NDM; ++k) land(q.d[k]);
     }
   };
   In cur = {};
@@ -582,8 +469,7 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel_feat(const StepArgs A) {
     if (live_n) load(e1, nxt);
     asm volatile("" ::: "memory");
     if (live) {
-      Pack<W> xs[NX], as[NA], sv[NA], up[NA], dd[In::ND];
-      int tv[W];
+      Pack<W> xs[NX], as[NA], sv[NA], up[NA];
 #pragma unroll
       for (int j = 0; j < W; ++j) {
 #pragma unroll
@@ -594,12 +480,9 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel_feat(const StepArgs A) {
           sv[i].v[j] = ADELTA ? Vec<W>::get(cur.asave[i], j) : 0.0;
           up[i].v[j] = TRACK ? Vec<W>::get(cur.uprev[i], j) : 0.0;
         }
-#pragma unroll
-        for (int k = 0; k < In::ND; ++k) dd[k].v[j] = DENV ? Vec<W>::get(cur.d[k], j) : 0.0;
-        tv[j] = (PER_T && A.t) ? VecI<W>::get(cur.t, j) : A.t_scalar;
       }
       FeatOut<M, W> out;
-      env_step_feat<M, W, FT>(A, c, lds, e0, tv, as, sv, up, dd, xs, out);
+      env_step_feat<M, W, FT>(A, c, e0, A.t_scalar, as, sv, up, xs, out);
       store_feat<M, W, FT>(A, c, e0, xs, out, nt);
     }
     if (itn >= ntile) break;
@@ -611,8 +494,8 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel_feat(const StepArgs A) {
 }
 
 // The masks built for every small model: each single feature, the combinations the reference's paper
-// configurations use (noise + tracking reward; noise + constraints; a_delta + tracking), per-env counters with
-// same-launch auto-reset, and "everything".  Mask 0 is the lean step with the status output.
+// configurations use (noise + tracking reward; noise + constraints; all three), the auto-reset launch of a
+// lock-stepped episode, and "everything".  Mask 0 is the lean step with the viol / status outputs.
 template <class M>
 inline int feat_table(FeatEntry* out, int cap) {
   int n = 0;
@@ -622,15 +505,11 @@ inline int feat_table(FeatEntry* out, int cap) {
   add(0u, step_kernel_feat<M, 2, 0u>);
   add(FT_AR, step_kernel_feat<M, 2, FT_AR>);
   add(FT_NOISE, step_kernel_feat<M, 2, FT_NOISE>);
-  add(FT_GAUSS, step_kernel_feat<M, 2, FT_GAUSS>);
   add(FT_CONS, step_kernel_feat<M, 2, FT_CONS>);
   add(FT_TRACK, step_kernel_feat<M, 2, FT_TRACK>);
-  add(FT_PER_T, step_kernel_feat<M, 2, FT_PER_T>);
-  add(FT_PER_T | FT_AR, step_kernel_feat<M, 2, FT_PER_T | FT_AR>);
   add(FT_NOISE | FT_TRACK, step_kernel_feat<M, 2, FT_NOISE | FT_TRACK>);
   add(FT_NOISE | FT_CONS, step_kernel_feat<M, 2, FT_NOISE | FT_CONS>);
   add(FT_NOISE | FT_CONS | FT_TRACK, step_kernel_feat<M, 2, FT_NOISE | FT_CONS | FT_TRACK>);
-  add(FT_NOISE | FT_CONS | FT_PER_T | FT_AR, step_kernel_feat<M, 2, FT_NOISE | FT_CONS | FT_PER_T | FT_AR>);
   add(FT_ALL, step_kernel_feat<M, 2, FT_ALL>);
   return n;
 }
