@@ -72,6 +72,8 @@ struct pcg_plan {
   int stream_occ[2]; // resident workgroups per CU of the stream kernels [EPL-1] (0 = not queried yet)
   int pipe_occ[2][2];  // [auto-reset instantiation][EPL-1]
   int feat_occ[MAX_FEAT];  // resident workgroups per CU of the feature-masked kernels (0 = not queried yet)
+  int q_bpc[2], q_tile[2]; // work-queue kernel [per_env_t]: resident workgroups per CU, tile slots (0 = not chosen yet,
+                           // -1 = does not fit)
   int64_t env_offset;
   DevConst hc;       // host copy
   DevConst* dC;      // device copy
@@ -358,6 +360,7 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   p->stream_occ[0] = p->stream_occ[1] = 0;
   p->pipe_occ[0][0] = p->pipe_occ[0][1] = p->pipe_occ[1][0] = p->pipe_occ[1][1] = 0;
   for (int i = 0; i < MAX_FEAT; ++i) p->feat_occ[i] = 0;
+  p->q_bpc[0] = p->q_bpc[1] = p->q_tile[0] = p->q_tile[1] = 0;
   p->env_offset = 0;
   p->dC = nullptr;
   p->dsched = nullptr;
@@ -474,6 +477,39 @@ static int resident_blocks(StepFn fn) {
   return nb > 0 ? nb : 1;
 }
 
+// Launch geometry of the DOPRI5 work-queue kernel (pcg_step_queue.hpp): resident 256-thread workgroups per CU by the
+// register allocation (= waves per SIMD), the largest tile (<= 512 slots, two per lane) whose LDS fits that many
+// workgroups in 160 KB.
+static int queue_geometry(pcg_plan* p, const Kernels& k, int pe, size_t sched_bytes) {
+  if (p->q_tile[pe] != 0) return PCG_OK;
+  hipFuncAttributes fa;
+  hipError_t e = hipFuncGetAttributes(&fa, (const void*)k.queue[pe]);
+  if (e != hipSuccess) return (int)e;
+  const int alloc = ((fa.numRegs + 7) / 8) * 8;
+  int bpc = alloc > 0 ? 512 / alloc : 1;
+  bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
+  const size_t lds_cu = 160 * 1024 - 2048;
+  int best_t = 0, best_b = 1;
+  for (int b = bpc; b >= 1; --b) {
+    int T = QSORT;
+    while (T >= QBLOCK && k.queue_lds(T) + sched_bytes > lds_cu / b) T -= 64;
+    if (T < QBLOCK) continue;
+    if (b * T > best_b * best_t) {
+      best_t = T;
+      best_b = b;
+    }
+    if (T == QSORT) break;  // the full tile at the highest occupancy that allows it
+  }
+  p->q_tile[pe] = best_t > 0 ? best_t : -1;
+  p->q_bpc[pe] = best_b;
+  if (best_t > 0) {
+    e = hipFuncSetAttribute((const void*)k.queue[pe], hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(k.queue_lds(best_t) + sched_bytes));
+    if (e != hipSuccess) return (int)e;
+  }
+  return PCG_OK;
+}
+
 // Fill every lazily queried occupancy of the plan's candidate persistent kernels (done before a stream
 // capture so that no query runs while capturing).
 static int warm_occupancy(pcg_plan* p) {
@@ -489,6 +525,10 @@ static int warm_occupancy(pcg_plan* p) {
       if (q < 0) return -q;
       p->stream_occ[e] = q;
     }
+  }
+  if (p->integrator_id == PCG_INT_DOPRI5 && k.queue[0]) {
+    const int rc = queue_geometry(p, k, 0, 0);
+    if (rc != PCG_OK) return rc;
   }
   if (p->integrator_id == PCG_INT_RK4)
     for (int i = 0; i < k.nfeat; ++i)
@@ -541,6 +581,37 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
     const int ub = tb(false, p->integrator_id);
     hipLaunchKernelGGL(ufn, dim3(grid_for(io->B, ub)), dim3(ub), sh, (hipStream_t)stream, a);
     return (int)hipGetLastError();
+  }
+  // Adaptive plans: the work-queue kernel (lanes that finish early pull the next env from an LDS tile).
+  // PCG_OPT_VARIANT 1 keeps the classic one-env-per-lane kernel (A/B measurement), PCG_OPT_LDS_STAGES too.
+  if (p->integrator_id == PCG_INT_DOPRI5 && !lds_st && p->variant == 0 && k.queue[per_env_t ? 1 : 0]) {
+    const int pe = per_env_t ? 1 : 0;
+    const size_t sb = (per_env_t && a.sched_in_lds) ? sizeof(double) * (size_t)(c.nsp + c.nd) * c.N : 0;
+    rc = queue_geometry(p, k, pe, sb);
+    if (rc != PCG_OK) return rc;
+    if (p->q_tile[pe] > 0) {
+      a.q_tile = p->q_tile[pe];
+      if (const char* ev = std::getenv("PCG_Q_TILE")) {  // measurement switch: smaller tile (A/B)
+        const int tv = std::atoi(ev);
+        if (tv >= QBLOCK && tv <= a.q_tile) a.q_tile = tv;
+      }
+      if (std::getenv("PCG_Q_NOSORT")) a.q_tile |= 0x10000;  // measurement switch: FIFO order
+      int64_t nwg = (int64_t)p->num_cus * p->q_bpc[pe];
+      const int64_t cap = (io->B + QBLOCK - 1) / QBLOCK;  // no workgroup with less than one env per lane
+      if (nwg > cap) nwg = cap;
+      // The queue only pays when its tiles are well filled: with fewer than ~1.75 envs per lane in a sub-tile the
+      // re-balancing gain (measured 1.11x at 2.0 on BASELINE configs[2]) no longer covers the bookkeeping (0.99x at
+      // 1.33: the ME segment of configs[4]) -- such launches stay on the classic kernel.
+      const int64_t per = (io->B + nwg - 1) / nwg;
+      const int Tq = a.q_tile & 0xFFFF;
+      const int64_t nsub = (per + Tq - 1) / Tq;
+      const bool filled = (per + nsub - 1) / nsub >= (7 * QBLOCK) / 4 || std::getenv("PCG_Q_FORCE") != nullptr;
+      if (filled) {
+      hipLaunchKernelGGL(k.queue[pe], dim3((unsigned)nwg), dim3(QBLOCK), k.queue_lds(a.q_tile & 0xFFFF) + sb,
+                         (hipStream_t)stream, a);
+      return (int)hipGetLastError();
+      }
+    }
   }
   // lean variant when no noise / Gaussian disturbance / constraint work is configured
   // (the lean kernels also compile out a_delta, the terminal "batch" reward and per-env disturbances)

@@ -131,6 +131,7 @@ struct StepArgs {
   int32_t t_scalar;
   int32_t sched_in_lds;  // per-env-t kernels: schedules staged in LDS
   int32_t nt_stores;     // stream kernels: non-temporal stores for obs / reward
+  int32_t q_tile;        // work-queue kernel: slots of the LDS tile (<= 512)
   int32_t auto_reset;    // per-env-t kernels: reset the envs that finished in this step (pcg_step_autoreset)
   uint64_t reset_seed;   // RNG key of those resets
   // rollout
@@ -408,9 +409,19 @@ PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const do
   return finite_status<NX>(status, x, nx);
 }
 
-template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS, bool UNC = false>
-PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, double* stage_l, int64_t e,
-                      int t, const double (&a_in)[M::NA], double (&x)[M::NX], EnvOut<M>& out) {
+// What the pre-integration half of a step hands to the post-integration half (registers in the classic kernel,
+// partly LDS in the work-queue kernel): the held input vector, the disturbance slots, the t == 0 verdict.
+template <class M>
+struct EnvPre {
+  double u[M::NA + M::NDM];   // physical action | model disturbance inputs, held over [0,dt]
+  double dv[PCG_MAX_NDM];     // configured disturbance values (observation slots, constraint rows)
+  bool done_pre;              // pre-step constraint check at t == 0 said "done"
+};
+
+// ---- first half of make_env.step (pcgym.py:371-420): action map, disturbance injection, pre-step check ----
+template <class M, bool PER_ENV_T, bool EXTRAS>
+PCG_DEV void env_pre(const StepArgs& A, CDevConst& c, const double* sched_l, int64_t e, int t,
+                     const double (&a_in)[M::NA], const double (&x)[M::NX], EnvPre<M>& pre) {
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
   const int64_t B = A.B;
   const uint32_t flags = c.flags;
@@ -418,12 +429,10 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
   const int na = M::DYNAMIC ? c.na : NA;
   const int N = c.N, nsp = c.nsp, nso = c.nsp_obs, nd = c.nd;
   const int tn = min(t + 1, N - 1);  // schedule index clamp (the reference would IndexError)
-  const int tc = min(t, N - 1);
   const uint64_t env_id = (uint64_t)(A.env_offset + e);
-  typename M::CKP& kp = *(typename M::CKP*)(M::DYNAMIC ? c.kp_big : c.kp);
-
+  double (&u)[NA + NDM] = pre.u;
+  double (&dv)[PCG_MAX_NDM] = pre.dv;
   // ---- action map (pcgym.py:371-383) ----
-  double u[NA + NDM];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     double av = 0.0;
@@ -437,7 +446,8 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
     u[i] = av;
   }
   // ---- disturbance injection (pcgym.py:386-412) ----
-  double dv[PCG_MAX_NDM] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < PCG_MAX_NDM; ++k) dv[k] = 0.0;
 #pragma unroll
   for (int j = 0; j < NDM; ++j) u[NA + j] = c.d_default[j];
   if (NDM > 0 && nd > 0) {
@@ -459,40 +469,34 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
     }
   }
   // ---- pre-step constraint check at t == 0 (pcgym.py:414-420) ----
-  bool done = false;
+  pre.done_pre = false;
   if (EXTRAS && c.ncon > 0 && t == 0) {
     double sp0[PCG_MAX_NSP];
 #pragma unroll
     for (int k = 0; k < PCG_MAX_NSP; ++k) sp0[k] = (k < nso) ? c.x0[(M::DYNAMIC ? nx : NX) + k] : 0.0;
     const bool v = constraint_rows<M>(c, x, sp0, dv, u, A.g_pre, B, e);
-    done = v && (flags & PCG_F_DONE_ON_CONS);
+    pre.done_pre = v && (flags & PCG_F_DONE_ON_CONS);
   }
-  // ---- integrate over [0, dt], u held (pcgym.py:423-429, integrator.py:90-107,163-182) ----
-  if constexpr (UNC && !M::DYNAMIC) {
-    // per-env uncertain parameters (sampled at reset, pcgym.py:301-310): rebuild the folded model constants
-    // for this lane from the raw parameter vector with the env's values substituted
-    constexpr int NR = M::NRAW;
-    double raw[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) raw[i] = c.raw[i];
-    for (int j = 0; j < c.nunc; ++j) {
-      const double v = A.p_unc[(size_t)j * B + e];
-      out.ounc[j] = v;
-      const int idx = c.unc_index[j];
-#pragma unroll
-      for (int i = 0; i < NR; ++i) raw[i] = (i == idx) ? v : raw[i];
-    }
-    typename M::KP kpl;
-    double dd[PCG_MAX_NDM] = {0.0, 0.0, 0.0, 0.0};
-    M::prep(raw, NX, NA, reinterpret_cast<double*>(&kpl), dd);
-    if (c.ndm == 0) {  // unconfigured disturbance inputs take the (possibly uncertain) model parameters
-#pragma unroll
-      for (int j = 0; j < NDM; ++j) u[NA + j] = dd[j];
-    }
-    out.status = (uint8_t)integrate_env<M, INTEG, LDS_STAGES>(A, c, kpl, u, x, stage_l, e, nx);
-  } else {
-    out.status = (uint8_t)integrate_env<M, INTEG, LDS_STAGES>(A, c, kp, u, x, stage_l, e, nx);
-  }
+}
+
+// ---- second half of make_env.step (pcgym.py:432-498): SP slot, constraints, done, reward, observation ----
+// `x` is the integrated state, `status` what the integrator reported for this env.
+template <class M, bool PER_ENV_T, bool EXTRAS, bool UNC = false>
+PCG_DEV void env_post(const StepArgs& A, CDevConst& c, const double* sched_l, int64_t e, int t, const EnvPre<M>& pre,
+                      const double (&x)[M::NX], int status, EnvOut<M>& out) {
+  constexpr int NX = M::NX, NA = M::NA;
+  const int64_t B = A.B;
+  const uint32_t flags = c.flags;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  const int na = M::DYNAMIC ? c.na : NA;
+  const int N = c.N, nsp = c.nsp, nso = c.nsp_obs, nd = c.nd;
+  const int tn = min(t + 1, N - 1);
+  const int tc = min(t, N - 1);
+  const uint64_t env_id = (uint64_t)(A.env_offset + e);
+  const double (&u)[NA + M::NDM] = pre.u;
+  const double (&dv)[PCG_MAX_NDM] = pre.dv;
+  bool done = pre.done_pre;
+  out.status = (uint8_t)status;
   // ---- SP slot uses SP[t_old] (pcgym.py:432-438, quirk Q5); t += 1 ----
   double spv[PCG_MAX_NSP] = {0.0, 0.0, 0.0, 0.0};
   double spn[PCG_MAX_NSP] = {0.0, 0.0, 0.0, 0.0};
@@ -600,9 +604,54 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
   if constexpr (UNC) {
     for (int j = 0; j < c.nunc; ++j) {
       const int q = nx + nso + nd + j;
-      out.ounc[j] = (out.ounc[j] - c.omap[q].lo) * c.omap[q].sc + c.omap[q].off;
+      out.ounc[j] = (A.p_unc[(size_t)j * B + e] - c.omap[q].lo) * c.omap[q].sc + c.omap[q].off;
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------
+// One env step for the lane's environment: env_pre -> integrate over [0,dt] -> env_post.  Statement order follows
+// make_env.step (pcgym.py:350-500).  `x` is the lane's physical state (in/out); everything the hot path writes
+// comes back in `out` (registers).  Only the rare side outputs (a_save, constraint rows, DOPRI5 step counts) are
+// stored on the way.
+// ---------------------------------------------------------------------------
+template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS, bool UNC = false>
+PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, double* stage_l, int64_t e,
+                      int t, const double (&a_in)[M::NA], double (&x)[M::NX], EnvOut<M>& out) {
+  constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
+  const int64_t B = A.B;
+  const int nx = M::DYNAMIC ? c.nx : NX;
+  typename M::CKP& kp = *(typename M::CKP*)(M::DYNAMIC ? c.kp_big : c.kp);
+  EnvPre<M> pre;
+  env_pre<M, PER_ENV_T, EXTRAS>(A, c, sched_l, e, t, a_in, x, pre);
+  // ---- integrate over [0, dt], u held (pcgym.py:423-429, integrator.py:90-107,163-182) ----
+  int status;
+  if constexpr (UNC && !M::DYNAMIC) {
+    // per-env uncertain parameters (sampled at reset, pcgym.py:301-310): rebuild the folded model constants
+    // for this lane from the raw parameter vector with the env's values substituted
+    constexpr int NR = M::NRAW;
+    double raw[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) raw[i] = c.raw[i];
+    for (int j = 0; j < c.nunc; ++j) {
+      const double v = A.p_unc[(size_t)j * B + e];
+      const int idx = c.unc_index[j];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) raw[i] = (i == idx) ? v : raw[i];
+    }
+    typename M::KP kpl;
+    double dd[PCG_MAX_NDM] = {0.0, 0.0, 0.0, 0.0};
+    M::prep(raw, NX, NA, reinterpret_cast<double*>(&kpl), dd);
+    if (c.ndm == 0) {  // unconfigured disturbance inputs take the (possibly uncertain) model parameters
+#pragma unroll
+      for (int j = 0; j < NDM; ++j) pre.u[NA + j] = dd[j];
+    }
+    status = integrate_env<M, INTEG, LDS_STAGES>(A, c, kpl, pre.u, x, stage_l, e, nx);
+  } else {
+    status = integrate_env<M, INTEG, LDS_STAGES>(A, c, kp, pre.u, x, stage_l, e, nx);
+  }
+  env_post<M, PER_ENV_T, EXTRAS, UNC>(A, c, sched_l, e, t, pre, x, status, out);
 }
 
 // scalar (8 B per lane) store of one env's outputs; obs_base = &obs[0][e] of the destination
@@ -1307,6 +1356,10 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG)) void integrate_kernel(CDevCo
     if (i < nx) xg[(size_t)i * B + e] = x[i];
 }
 
+}  // namespace pcg
+#include "pcg_step_queue.hpp"
+namespace pcg {
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1337,6 +1390,8 @@ struct Kernels {
   StepFn step[PCG_INT_COUNT][2][2][2];  // [integrator][per_env_t][lds_stages][extras]
   StepFn stream[PCG_INT_COUNT][2];      // persistent streaming kernel [integrator][EPL-1] (entries may be null)
   StepFn step_unc[PCG_INT_COUNT][2]; // per-env parameter uncertainty [integrator][per_env_t] (null for affine)
+  StepFn queue[2];                   // DOPRI5 with the in-workgroup work queue [per_env_t] (null for affine)
+  size_t (*queue_lds)(int);          // LDS bytes of a tile of T slots
   StepFn pipe[2];                    // RK4 software-pipelined lean kernel [EPL-1] (may be null)
   StepFn pipe_ar[2];                 // the same with the same-launch auto-reset path compiled in [EPL-1]
   StepFn roll_lean[2];               // RK4 lean fused rollout [EPL-1] (may be null)
@@ -1368,6 +1423,9 @@ Kernels make_kernels() {
   k.integ[PCG_INT_DOPRI5][0] = integrate_kernel<M, PCG_INT_DOPRI5, false>;
   k.rhs = rhs_kernel<M>;
   if constexpr (!M::DYNAMIC) {
+    k.queue[0] = step_kernel_queue<M, false, true>;
+    k.queue[1] = step_kernel_queue<M, true, true>;
+    k.queue_lds = QLayout<M>::bytes;
     k.step_unc[PCG_INT_RK4][0] = step_kernel<M, PCG_INT_RK4, false, false, true, true>;
     k.step_unc[PCG_INT_RK4][1] = step_kernel<M, PCG_INT_RK4, true, false, true, true>;
     k.step_unc[PCG_INT_DOPRI5][0] = step_kernel<M, PCG_INT_DOPRI5, false, false, true, true>;

@@ -1,0 +1,352 @@
+// pcg_step_queue.hpp -- adaptive (DOPRI5) env step with an in-workgroup work queue: lanes that finish their env
+// early pull the next one instead of idling until the slowest lane of their wave is done.
+//
+// Why.  With one env per lane for a whole step, a wave's time is the MAXIMUM over its 64 lanes of the number of
+// attempted RK steps; on BASELINE configs[2] (multistage extraction over the full action box: 23..132 attempts per
+// env step, mean 72) the mean/max ratio inside a wave is 0.64 -- a third of the fp64 issue slots do nothing
+// (profiles/r1/configs.jsonl).  Re-ordering the batch in HBM by cost was built in round 1 and lost to its scattered
+// 8-byte accesses.  Here the re-balancing happens in LDS, and every HBM access stays coalesced:
+//
+//   phase 1  a 256-thread workgroup loads a tile of T envs (T <= 512: two per lane) the usual SoA way, runs the
+//            pre-integration half of the step (env_pre: action map, disturbances, t == 0 check) and parks state and
+//            held input in LDS [component][slot], together with the initial step size and a cost key;
+//   sort     the tile's slots are ordered by DECREASING cost key (bitonic sort of 512 packed 32-bit words in LDS):
+//            longest-processing-time-first is what keeps the tail short when every lane only sees ~2 envs -- with FIFO
+//            order the queue runs dry early and each wave still waits for its slowest last env (simulated on the
+//            measured step counts: FIFO 1.12x, LPT by this key 1.36x, exact LPT 1.46x);
+//   phase 2  every lane integrates one env at a time from the queue: one attempted RK step per loop iteration for
+//            all busy lanes of the wave; idle lanes pop the next sorted slot (one wave-aggregated LDS atomic per
+//            refill; refills are batched to >= 8 idle lanes because the refill code -- LDS loads + one RHS
+//            evaluation -- runs for the whole wave); the integrated state goes back to its slot;
+//   phase 3  the workgroup runs the post-integration half (env_post: SP slot, constraints, reward, noise,
+//            observation) one env per lane again and stores coalesced.
+//
+// Per-env arithmetic does not depend on which lane integrates an env or in which order: results are bitwise
+// independent of the batch order (tested with a permuted batch).  The step-size controller, tolerances and failure
+// semantics are those of dopri5() in pcg_integrators.hpp (same statements, kept in a resumable per-lane form).
+// Reference: integrator.py:65-88 (adaptive explicit 5(4) pair, rtol = atol = 1e-8).
+#pragma once
+
+namespace pcg {
+
+// Four waves share one 512-slot tile.  A single-wave workgroup with its own 128-slot tile (no cross-wave barrier, queue
+// head in a register) was built and measured as well: 1.05x over the classic kernel on BASELINE configs[2] against
+// 1.13x for this shape -- the larger pool is worth more than the barriers cost (profiles/r2/queue_kernel.md).
+constexpr int QBLOCK = 256;        // threads per workgroup (one wave per SIMD)
+constexpr int QSORT = 512;         // sort width = maximum tile: two envs per lane
+constexpr int QREFILL = 8;         // idle lanes that trigger a refill (or: no busy lane left)
+
+// model hook: a cheap, monotone proxy of the number of RK steps an env step will take (the sort key)
+template <class M, class = void>
+struct has_cost_key : std::false_type {};
+template <class M>
+struct has_cost_key<M, std::void_t<decltype(M::COST_KEY)>> : std::true_type {};
+
+// ---- DOPRI5 in resumable form: the state one lane carries for the env it is integrating -------------------------
+template <int NX>
+struct DpLane {
+  double x[NX], k1[NX];
+  double t, h;
+  int acc, rej;
+  bool rejected_last;
+};
+
+// k1 = f(x) and the initial step size (Hairer, Norsett & Wanner II.4) -- the statements of dopri5() before its loop
+template <int NX, class F>
+PCG_DEV double dopri5_h_init(const F& f, const double (&x)[NX], double (&k1)[NX], int n, double dt, double rtol,
+                             double atol) {
+  double y[NX], w[NX];
+  f(x, k1);
+  const double d0 = rms_scaled<NX>(x, x, x, n, rtol, atol);
+  const double d1 = rms_scaled<NX>(k1, x, x, n, rtol, atol);
+  double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+  h0 = fmin(h0, dt);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) y[i] = x[i] + h0 * k1[i];
+  f(y, w);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) w[i] -= k1[i];
+  const double d2 = rms_scaled<NX>(w, x, x, n, rtol, atol) / h0;
+  const double dm = fmax(d1, d2);
+  const double h1 = (dm <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : ctrl_pow(dm * dm * 1e4, 1.0);
+  return fmin(qtrunc6(fmin(100.0 * h0, h1)), dt);
+}
+
+// one attempted step (the body of dopri5()'s loop).  Returns -1 to continue, else the final PCG_ST_* status
+// (PCG_ST_OK: reached dt; on failure the caller poisons the state).
+template <int NX, class F>
+PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double rtol, double atol, int max_steps) {
+  constexpr double a21 = 1.0 / 5;
+  constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
+  constexpr double a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9;
+  constexpr double a51 = 19372.0 / 6561, a52 = -25360.0 / 2187, a53 = 64448.0 / 6561, a54 = -212.0 / 729;
+  constexpr double a61 = 9017.0 / 3168, a62 = -355.0 / 33, a63 = 46732.0 / 5247, a64 = 49.0 / 176,
+                   a65 = -5103.0 / 18656;
+  constexpr double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
+  constexpr double e1 = 71.0 / 57600, e3 = -71.0 / 16695, e4 = 71.0 / 1920, e5 = -17253.0 / 339200,
+                   e6 = 22.0 / 525, e7 = -1.0 / 40;
+  if (L.acc + L.rej >= max_steps) return PCG_ST_MAX_STEPS;
+  bool last = false;
+  double h = L.h;
+  if (L.t + h >= dt * (1.0 - 1e-14)) {
+    h = dt - L.t;
+    last = true;
+  }
+  double y[NX], kk[NX], w[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX];
+  const double (&x)[NX] = L.x;
+  const double (&k1)[NX] = L.k1;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (a21 * k1[i]);
+  f(y, k2);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (a31 * k1[i] + a32 * k2[i]);
+  f(y, k3);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (a41 * k1[i] + a42 * k2[i] + a43 * k3[i]);
+  f(y, k4);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i]);
+  f(y, k5);
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    y[i] = x[i] + h * (a61 * k1[i] + a62 * k2[i] + a63 * k3[i] + a64 * k4[i] + a65 * k5[i]);
+  f(y, k6);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (b1 * k1[i] + b3 * k3[i] + b4 * k4[i] + b5 * k5[i] + b6 * k6[i]);
+  f(y, kk);  // k7 at the 5th-order solution (FSAL)
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    w[i] = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * kk[i]);
+  const double E2 = ms_scaled<NX>(w, x, y, n, rtol, atol);  // accept iff E = sqrt(E2) < 1
+  if (E2 < 1.0) {
+    double fac = fmin(10.0, fmax(0.2, ctrl_pow(E2, 0.9)));
+    if (L.rejected_last && fac > 1.0) fac = 1.0;
+    L.t += h;
+    L.h = h * fac;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      L.x[i] = y[i];
+      L.k1[i] = kk[i];
+    }
+    L.rejected_last = false;
+    ++L.acc;
+    return last ? PCG_ST_OK : -1;
+  }
+  double fac = (E2 == E2) ? fmax(0.2, ctrl_pow(E2, 0.9)) : 0.2;  // NaN -> hardest shrink
+  if (fac > 1.0) fac = 1.0;
+  L.h = h * fac;
+  L.rejected_last = true;
+  ++L.rej;
+  if (!(L.h > 1e-13 * dt)) return PCG_ST_UNDERFLOW;  // step-size underflow (NaN state / blow-up)
+  return -1;
+}
+
+// LDS layout of one tile (T slots): xs[NX][T] | us[NU][T] | hs[T] | sortbuf[QSORT] u32 | acc[T] rej[T] flag[T] i32 | next
+template <class M>
+struct QLayout {
+  static constexpr int NU = M::NA + M::NDM;
+  PCG_HD static size_t bytes(int T) {
+    return sizeof(double) * (size_t)(M::NX + NU + 1) * T + sizeof(uint32_t) * QSORT + sizeof(int32_t) * 3 * (size_t)T + 16;
+  }
+};
+
+template <class M, bool PER_ENV_T, bool EXTRAS>
+__global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void step_kernel_queue(const StepArgs A) {  // wpe = waves per SIMD = workgroups per CU
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  static_assert(!M::DYNAMIC, "the work-queue kernel is built for the fixed-size models");
+  CDevConst& c = *A.C;
+  constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM, NU = NA + NDM;
+  const int T = A.q_tile & 0xFFFF;
+  const bool nosort = (A.q_tile & 0x10000) != 0;  // measurement switch (PCG_Q_NOSORT)
+  double* xs = lds;
+  double* us = xs + (size_t)NX * T;
+  double* hs = us + (size_t)NU * T;
+  uint32_t* sortbuf = reinterpret_cast<uint32_t*>(hs + T);
+  int32_t* accs = reinterpret_cast<int32_t*>(sortbuf + QSORT);
+  int32_t* rejs = accs + T;
+  int32_t* flag = rejs + T;   // bits 0-1: PCG_ST_* of the integration, bit 2: pre-step "done"
+  int32_t* next = flag + T;   // queue head (the first min(n, 256) sorted slots are handed out directly)
+  double* sched_l = reinterpret_cast<double*>(next + 4 + (T & 1));  // per-env-t schedule tables behind the tile (8-byte aligned)
+  if (PER_ENV_T) stage_schedules(A, c, sched_l);
+  typename M::CKP& kp = *(typename M::CKP*)c.kp;
+  const int64_t B = A.B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // this workgroup's contiguous range of envs, walked in sub-tiles of (almost) equal size <= T
+  const int64_t per = (B + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = min(B, lo + per);
+  if (lo >= hi) return;
+  const int nsub = (int)((hi - lo + T - 1) / T);
+  const int64_t sub = (hi - lo + nsub - 1) / nsub;
+  const double dt = c.dt, rtol = c.rtol, atol = c.atol;
+  for (int isub = 0; isub < nsub; ++isub) {
+    const int64_t base = lo + (int64_t)isub * sub;
+    const int n = (int)(min(hi, base + sub) - base);  // envs in this sub-tile
+    // ---------------- phase 1: load, pre-integration half, park in LDS ----------------
+    for (int s = tid; s < QSORT; s += QBLOCK) {
+      uint32_t word = (uint32_t)s;  // padding: sorts behind every real slot
+      if (s < n) {
+        const int64_t e = base + s;
+        const int t = PER_ENV_T ? A.t[e] : A.t_scalar;
+        double x[NX], a[NA];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = A.x[(size_t)i * B + e];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a[i] = A.a[(size_t)i * B + e];
+        EnvPre<M> pre;
+        env_pre<M, PER_ENV_T, EXTRAS>(A, c, sched_l, e, t, a, x, pre);
+        const typename M::Hold hold = M::hold(kp, pre.u);
+        const RhsFn<M> f{kp, hold};
+        double k1[NX];
+        const double h = dopri5_h_init<NX>(f, x, k1, NX, dt, rtol, atol);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xs[(size_t)i * T + s] = x[i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) us[(size_t)i * T + s] = pre.u[i];
+        hs[s] = h;
+        flag[s] = pre.done_pre ? 4 : 0;
+        float key;
+        if constexpr (has_cost_key<M>::value) key = (float)M::cost_key(kp, pre.u);
+        else key = (float)(dt / h);  // generic proxy: steps at the initial step size
+        key = nosort ? 1.0f : __builtin_fmaxf(key, 1e-30f);
+        word = ((__float_as_uint(key) >> 9) << 9) | (uint32_t)s;  // positive floats order like their bit patterns
+      }
+      sortbuf[s] = word;
+    }
+    if (tid == 0) *next = QBLOCK < n ? QBLOCK : n;
+    __syncthreads();
+    // ---------------- sort the slots by decreasing cost key (bitonic, QSORT words, QSORT/2 threads) ----------------
+    for (int k = 2; k <= QSORT; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));  // lower index of this thread's pair
+        const int p = i | j;
+        const uint32_t va = sortbuf[i], vb = sortbuf[p];
+        const bool desc = (i & k) == 0;  // descending overall
+        if ((va < vb) == desc) {
+          sortbuf[i] = vb;
+          sortbuf[p] = va;
+        }
+        __syncthreads();
+      }
+    // ---------------- phase 2: the work queue ----------------
+    {
+      DpLane<NX> L;
+      double u[NU];
+      int slot = tid < n ? (int)(sortbuf[tid] & (QSORT - 1)) : -1;
+      bool fresh = slot >= 0;
+      bool drained = n <= QBLOCK;  // wave-uniform: the queue has nothing (left) for this wave
+      // every spin is bounded: a lane integrates at most two envs' worth of its tile share plus the refill rounds; the
+      // bound is never reached by a correct run (max_steps bounds each env) and turns a logic error into a flagged
+      // PCG_ST_MAX_STEPS result instead of a hung GPU
+      const long long iter_cap = ((long long)c.max_steps + 4) * ((T + QBLOCK - 1) / QBLOCK + 1) + 4 * T;
+      for (long long iter = 0;; ++iter) {
+        if (iter > iter_cap) {
+          if (slot >= 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xs[(size_t)i * T + slot] = __builtin_nan("");
+            accs[slot] = L.acc;
+            rejs[slot] = L.rej;
+            flag[slot] |= PCG_ST_MAX_STEPS;
+          }
+          break;
+        }
+        if (fresh) {  // (re)fill: state and held input from the slot, k1 = f(x)
+#pragma unroll
+          for (int i = 0; i < NX; ++i) L.x[i] = xs[(size_t)i * T + slot];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) u[i] = us[(size_t)i * T + slot];
+          L.h = hs[slot];
+          L.t = 0.0;
+          L.acc = L.rej = 0;
+          L.rejected_last = false;
+          const typename M::Hold hold = M::hold(kp, u);
+          const RhsFn<M> f{kp, hold};
+          f(L.x, L.k1);
+          fresh = false;
+        }
+        const bool busy = slot >= 0;
+        const unsigned long long bm = __ballot(busy);
+        const int n_idle = 64 - __popcll(bm);
+        // the shared queue head is only touched when this wave could use it (>= QREFILL idle lanes, or nothing left
+        // in flight) and has not seen it empty yet: the steady-state iteration does no LDS access at all
+        if (!drained && (n_idle >= QREFILL || bm == 0ull)) {
+          // idle lanes pop: one LDS atomic per wave, lane r of the idle set takes sorted position head + r
+          const unsigned long long im = ~bm;
+          const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+          int got = 0;
+          if (!busy && rank == 0) got = atomicAdd(next, n_idle);
+          got = __shfl(got, __ffsll((long long)im) - 1);
+          drained = got + n_idle >= n;  // the head only grows: once past n it stays there
+          if (!busy) {
+            const int j = got + rank;
+            if (j < n) {
+              slot = (int)(sortbuf[j] & (QSORT - 1));
+              fresh = true;
+            }
+          }
+          if (got < n) continue;
+        }
+        if (bm == 0ull) break;  // nothing in flight in this wave and the queue is empty
+        if (busy) {
+          const typename M::Hold hold = M::hold(kp, u);
+          const RhsFn<M> f{kp, hold};
+          const int st = dopri5_attempt<NX>(f, L, NX, dt, rtol, atol, c.max_steps);
+          if (st >= 0) {  // finished (or gave up): park the result, free the lane
+            poison_if_failed<NX>(st, L.x);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xs[(size_t)i * T + slot] = L.x[i];
+            accs[slot] = L.acc;
+            rejs[slot] = L.rej;
+            flag[slot] |= st;
+            slot = -1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---------------- phase 3: post-integration half, coalesced stores ----------------
+    for (int s = tid; s < n; s += QBLOCK) {
+      const int64_t e = base + s;
+      const int t = PER_ENV_T ? A.t[e] : A.t_scalar;
+      double x[NX];
+      EnvPre<M> pre;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = xs[(size_t)i * T + s];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) pre.u[i] = us[(size_t)i * T + s];
+#pragma unroll
+      for (int k = 0; k < PCG_MAX_NDM; ++k) pre.dv[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < NDM; ++k)
+        if (k < c.nd) {  // the configured disturbance values are the matching entries of the held input
+          const int dslot = c.d_slot[k];
+          double v = 0.0;
+#pragma unroll
+          for (int j = 0; j < NDM; ++j) v = (j == dslot) ? pre.u[NA + j] : v;
+          pre.dv[k] = v;
+        }
+      const int fl = flag[s];
+      pre.done_pre = (fl & 4) != 0;
+      if (A.nsteps) {
+        A.nsteps[e] = accs[s];
+        A.nsteps[B + e] = rejs[s];
+      }
+      EnvOut<M> out;
+      env_post<M, PER_ENV_T, EXTRAS>(A, c, sched_l, e, t, pre, x, finite_status<NX>(fl & 3, x, NX), out);
+      if (A.auto_reset && out.done) {
+        __builtin_nontemporal_store(out.rew, A.rew + e);
+        A.done[e] = 1;
+        if (A.viol) A.viol[e] = out.viol ? 1 : 0;
+        if (A.status) A.status[e] = out.status;
+        reset_env(A, c, e, A.reset_seed);
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) A.x[(size_t)i * B + e] = x[i];
+      store_out<M>(A, c, e, out, A.obs + e);
+      if (PER_ENV_T) A.t[e] = t + 1;
+    }
+    __syncthreads();  // the tile's LDS is reused by the next sub-tile
+  }
+}
+
+}  // namespace pcg
