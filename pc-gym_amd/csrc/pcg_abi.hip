@@ -318,6 +318,8 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   d->dt = c->dt;
   d->h = c->dt / (c->substeps > 0 ? c->substeps : 1);
   d->rtol = c->rtol;
+  d->dt_edge = c->dt * (1.0 - 1e-14);
+  d->h_floor = 1e-13 * c->dt;
   d->atol = c->atol;
   d->nx = nx; d->na = na; d->ndm = ndm; d->nd = nd; d->nsp = nsp; d->nsp_obs = nso; d->ncon = ncon; d->nrew = nrew;
   d->N = c->N; d->substeps = c->substeps; d->max_steps = c->max_steps; d->nobs = nobs;

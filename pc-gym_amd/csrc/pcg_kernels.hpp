@@ -71,6 +71,7 @@ struct OMap {
 };
 struct DevConst {
   double dt, h, rtol, atol;
+  double dt_edge, h_floor;            // dt (1 - 1e-14) and 1e-13 dt of the DOPRI5 loop, folded on the host
   uint32_t flags;
   int32_t nx, na, ndm, nd, nsp, nsp_obs, ncon, nrew, N, substeps, max_steps, nobs, has_x0_unc, nunc;
   int32_t sp_index[PCG_MAX_NSP], d_slot[PCG_MAX_NDM];

@@ -75,7 +75,8 @@ PCG_DEV double dopri5_h_init(const F& f, const double (&x)[NX], double (&k1)[NX]
 // one attempted step (the body of dopri5()'s loop).  Returns -1 to continue, else the final PCG_ST_* status
 // (PCG_ST_OK: reached dt; on failure the caller poisons the state).
 template <int NX, class F>
-PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double rtol, double atol, int max_steps) {
+PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double dt_edge, double h_floor, double rtol,
+                           double atol, int max_steps) {
   constexpr double a21 = 1.0 / 5;
   constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
   constexpr double a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9;
@@ -88,11 +89,11 @@ PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double r
   if (L.acc + L.rej >= max_steps) return PCG_ST_MAX_STEPS;
   bool last = false;
   double h = L.h;
-  if (L.t + h >= dt * (1.0 - 1e-14)) {
+  if (L.t + h >= dt_edge) {  // dt (1 - 1e-14), folded on the host: no scalar fp64 unit -> it would sit in a VGPR
     h = dt - L.t;
     last = true;
   }
-  double y[NX], kk[NX], w[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX];
+  double y[NX], kk[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX];
   const double (&x)[NX] = L.x;
   const double (&k1)[NX] = L.k1;
 #pragma unroll
@@ -114,10 +115,16 @@ PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double r
 #pragma unroll
   for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (b1 * k1[i] + b3 * k3[i] + b4 * k4[i] + b5 * k5[i] + b6 * k6[i]);
   f(y, kk);  // k7 at the 5th-order solution (FSAL)
+  // error estimate and its scaled mean square in one pass (ms_scaled() without the intermediate vector)
+  double E2 = 0.0;
 #pragma unroll
-  for (int i = 0; i < NX; ++i)
-    w[i] = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * kk[i]);
-  const double E2 = ms_scaled<NX>(w, x, y, n, rtol, atol);  // accept iff E = sqrt(E2) < 1
+  for (int i = 0; i < NX; ++i) {
+    const double wi = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * kk[i]);
+    const double sc = atol + rtol * fmax(fabs(x[i]), fabs(y[i]));
+    const double r = wi * fast_rcp(sc);  // sc > 0
+    E2 += (i < n) ? r * r : 0.0;
+  }
+  E2 = E2 / n;  // accept iff E = sqrt(E2) < 1
   if (E2 < 1.0) {
     double fac = fmin(10.0, fmax(0.2, ctrl_pow(E2, 0.9)));
     if (L.rejected_last && fac > 1.0) fac = 1.0;
@@ -137,8 +144,98 @@ PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double r
   L.h = h * fac;
   L.rejected_last = true;
   ++L.rej;
-  if (!(L.h > 1e-13 * dt)) return PCG_ST_UNDERFLOW;  // step-size underflow (NaN state / blow-up)
+  if (!(L.h > h_floor)) return PCG_ST_UNDERFLOW;  // 1e-13 dt: step-size underflow (NaN state / blow-up)
   return -1;
+}
+
+// ---- phase 2: the work queue of one tile.  (Tried as a real, non-inlined function so that the loop would own the
+// whole register file: the call ABI's save / restore made it worse -- 772 B of scratch against 140.)
+template <class M>
+PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xs, double* us, const double* hs,
+                                                          const uint32_t* sortbuf, int32_t* accs, int32_t* rejs,
+                                                          int32_t* flag, int32_t* next, int T, int n, double dt, double dt_edge,
+                                                          double h_floor, double rtol, double atol, int max_steps) {
+  constexpr int NX = M::NX, NU = M::NA + M::NDM;
+  typename M::CKP& kp = *kpp;
+  const int tid = threadIdx.x;
+  DpLane<NX> L;
+  int slot = tid < n ? (int)(sortbuf[tid] & (QSORT - 1)) : -1;
+  bool fresh = slot >= 0;
+  bool drained = n <= QBLOCK;  // wave-uniform: the queue has nothing (left) for this wave
+  // every spin is bounded: a lane integrates at most two envs' worth of its tile share plus the refill rounds; the
+  // bound is never reached by a correct run (max_steps bounds each env) and turns a logic error into a flagged
+  // PCG_ST_MAX_STEPS result instead of a hung GPU
+  const long long cap64 = ((long long)max_steps + 4) * ((T + QBLOCK - 1) / QBLOCK + 1) + 4 * T;
+  const int iter_cap = cap64 > 0x7fffff00LL ? 0x7fffff00 : (int)cap64;
+  for (int iter = 0;; ++iter) {
+    if (iter > iter_cap) {
+      if (slot >= 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xs[(size_t)i * T + slot] = __builtin_nan("");
+        accs[slot] = L.acc;
+        rejs[slot] = L.rej;
+        flag[slot] |= PCG_ST_MAX_STEPS;
+      }
+      break;
+    }
+    if (fresh) {  // (re)fill: state and held input from the slot, k1 = f(x)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) L.x[i] = xs[(size_t)i * T + slot];
+      double u[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) u[i] = us[(size_t)i * T + slot];
+      L.h = hs[slot];
+      L.t = 0.0;
+      L.acc = L.rej = 0;
+      L.rejected_last = false;
+      const typename M::Hold hold = M::hold(kp, u);
+      const RhsFn<M> f{kp, hold};
+      f(L.x, L.k1);
+      fresh = false;
+    }
+    const bool busy = slot >= 0;
+    const unsigned long long bm = __ballot(busy);
+    const int n_idle = 64 - __popcll(bm);
+    // the shared queue head is only touched when this wave could use it (>= QREFILL idle lanes, or nothing left
+    // in flight) and has not seen it empty yet: the steady-state iteration does no LDS access at all
+    if (!drained && (n_idle >= QREFILL || bm == 0ull)) {
+      // idle lanes pop: one LDS atomic per wave, lane r of the idle set takes sorted position head + r
+      const unsigned long long im = ~bm;
+      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+      int got = 0;
+      if (!busy && rank == 0) got = atomicAdd(next, n_idle);
+      got = __shfl(got, __ffsll((long long)im) - 1);
+      drained = got + n_idle >= n;  // the head only grows: once past n it stays there
+      if (!busy) {
+        const int j = got + rank;
+        if (j < n) {
+          slot = (int)(sortbuf[j] & (QSORT - 1));
+          fresh = true;
+        }
+      }
+      if (got < n) continue;
+    }
+    if (bm == 0ull) break;  // nothing in flight in this wave and the queue is empty
+    if (busy) {
+      // the held input stays in LDS between attempts (a few ds_read per ~1000-instruction attempt) instead of in
+      // registers: the resumable loop sits right at the 256-register budget
+      double u[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) u[i] = us[(size_t)i * T + slot];
+      const typename M::Hold hold = M::hold(kp, u);
+      const RhsFn<M> f{kp, hold};
+      const int st = dopri5_attempt<NX>(f, L, NX, dt, dt_edge, h_floor, rtol, atol, max_steps);
+      if (st >= 0) {  // finished (or gave up): park the result, free the lane
+        poison_if_failed<NX>(st, L.x);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xs[(size_t)i * T + slot] = L.x[i];
+        accs[slot] = L.acc;
+        rejs[slot] = L.rej;
+        flag[slot] |= st;
+        slot = -1;
+      }
+    }
+  }
 }
 
 // LDS layout of one tile (T slots): xs[NX][T] | us[NU][T] | hs[T] | sortbuf[QSORT] u32 | acc[T] rej[T] flag[T] i32 | next
@@ -228,80 +325,7 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
         __syncthreads();
       }
     // ---------------- phase 2: the work queue ----------------
-    {
-      DpLane<NX> L;
-      double u[NU];
-      int slot = tid < n ? (int)(sortbuf[tid] & (QSORT - 1)) : -1;
-      bool fresh = slot >= 0;
-      bool drained = n <= QBLOCK;  // wave-uniform: the queue has nothing (left) for this wave
-      // every spin is bounded: a lane integrates at most two envs' worth of its tile share plus the refill rounds; the
-      // bound is never reached by a correct run (max_steps bounds each env) and turns a logic error into a flagged
-      // PCG_ST_MAX_STEPS result instead of a hung GPU
-      const long long iter_cap = ((long long)c.max_steps + 4) * ((T + QBLOCK - 1) / QBLOCK + 1) + 4 * T;
-      for (long long iter = 0;; ++iter) {
-        if (iter > iter_cap) {
-          if (slot >= 0) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) xs[(size_t)i * T + slot] = __builtin_nan("");
-            accs[slot] = L.acc;
-            rejs[slot] = L.rej;
-            flag[slot] |= PCG_ST_MAX_STEPS;
-          }
-          break;
-        }
-        if (fresh) {  // (re)fill: state and held input from the slot, k1 = f(x)
-#pragma unroll
-          for (int i = 0; i < NX; ++i) L.x[i] = xs[(size_t)i * T + slot];
-#pragma unroll
-          for (int i = 0; i < NU; ++i) u[i] = us[(size_t)i * T + slot];
-          L.h = hs[slot];
-          L.t = 0.0;
-          L.acc = L.rej = 0;
-          L.rejected_last = false;
-          const typename M::Hold hold = M::hold(kp, u);
-          const RhsFn<M> f{kp, hold};
-          f(L.x, L.k1);
-          fresh = false;
-        }
-        const bool busy = slot >= 0;
-        const unsigned long long bm = __ballot(busy);
-        const int n_idle = 64 - __popcll(bm);
-        // the shared queue head is only touched when this wave could use it (>= QREFILL idle lanes, or nothing left
-        // in flight) and has not seen it empty yet: the steady-state iteration does no LDS access at all
-        if (!drained && (n_idle >= QREFILL || bm == 0ull)) {
-          // idle lanes pop: one LDS atomic per wave, lane r of the idle set takes sorted position head + r
-          const unsigned long long im = ~bm;
-          const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
-          int got = 0;
-          if (!busy && rank == 0) got = atomicAdd(next, n_idle);
-          got = __shfl(got, __ffsll((long long)im) - 1);
-          drained = got + n_idle >= n;  // the head only grows: once past n it stays there
-          if (!busy) {
-            const int j = got + rank;
-            if (j < n) {
-              slot = (int)(sortbuf[j] & (QSORT - 1));
-              fresh = true;
-            }
-          }
-          if (got < n) continue;
-        }
-        if (bm == 0ull) break;  // nothing in flight in this wave and the queue is empty
-        if (busy) {
-          const typename M::Hold hold = M::hold(kp, u);
-          const RhsFn<M> f{kp, hold};
-          const int st = dopri5_attempt<NX>(f, L, NX, dt, rtol, atol, c.max_steps);
-          if (st >= 0) {  // finished (or gave up): park the result, free the lane
-            poison_if_failed<NX>(st, L.x);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) xs[(size_t)i * T + slot] = L.x[i];
-            accs[slot] = L.acc;
-            rejs[slot] = L.rej;
-            flag[slot] |= st;
-            slot = -1;
-          }
-        }
-      }
-    }
+    queue_integrate<M>(&kp, xs, us, hs, sortbuf, accs, rejs, flag, next, T, n, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps);
     __syncthreads();
     // ---------------- phase 3: post-integration half, coalesced stores ----------------
     for (int s = tid; s < n; s += QBLOCK) {

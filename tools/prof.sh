@@ -1,18 +1,18 @@
 #!/bin/bash
 # rocprofv3 recipe used for profiles/: run ON the GPU box (via gpurun).  usage: tools/prof.sh <tag> [bench args...]
-# Pass 1: kernel trace + stats.  Passes 2..n: one PMC group each (counters collected in their own runs,
-# with --kernel-trace only; FETCH_SIZE and WRITE_SIZE cannot share a pass: TCC has 4 slots, they need 3+2).
+# Pass 1: kernel trace + stats of the bench's default run.  Passes 2..n: one PMC group each (counters collected in their
+# own runs, with --kernel-trace only; FETCH_SIZE and WRITE_SIZE cannot share a pass: TCC has 4 slots, they need 3+2).
+# PROF_PMC_STEPS / PROF_PMC_WARMUP: length of the counter passes (counters are clock-independent: shorter runs).
 set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# the default bench.py run (5900 timed + 590 warm-up launches: the GPU needs ~50 ms to reach steady clocks)
 ARGS="--no-cpu-baseline $*"
-PMC_ARGS="--steps 590 --warmup 590 --no-cpu-baseline $*"  # counters are clock-independent: shorter
+PMC_ARGS="--steps ${PROF_PMC_STEPS:-590} --warmup ${PROF_PMC_WARMUP:-59} --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU" "GRBM_GUI_ACTIVE"; do
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$name -o p -- python $ROOT/bench.py $PMC_ARGS > /dev/null 2> $OUT/pmc_$name.log
 done

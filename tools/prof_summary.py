@@ -35,7 +35,7 @@ for f in find("pmc_*/**/*counter_collection.csv"):
         for row in csv.DictReader(fh):
             agg[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, cs in agg.items():
-        if "step_kernel" not in k and "reset" not in k:
+        if "step_kernel" not in k and "reset" not in k and "rollout" not in k:
             continue
         for cn, v in cs.items():
             print(f"{k[:70]:70s} {cn:28s} n={len(v)} mean={sum(v)/len(v):.6g}")
