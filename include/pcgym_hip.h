@@ -31,13 +31,25 @@
 #ifndef PCGYM_HIP_H
 #define PCGYM_HIP_H
 
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#else /* hipRTC (run-time compilation of the kernel headers with user expressions) ships no <stdint.h> */
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef short int16_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long int64_t;
+typedef unsigned long uint64_t;
+typedef unsigned long uintptr_t;
+#endif
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 5
+#define PCG_ABI_VERSION 6
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -63,6 +75,7 @@ extern "C" {
 #define PCG_E_VALUE -4       /* invalid scalar (dt<=0, substeps<1, ...)  */
 #define PCG_E_PLAN -5        /* plan handle invalid / wrong device       */
 #define PCG_E_UNSUPPORTED -6 /* combination not built                    */
+#define PCG_E_JIT -7         /* a user expression did not compile (pcg_last_jit_log() has the compiler output) */
 
 /* per-env health of a step, written to pcg_buffers.status (the reference's CVODES raises on an integration
  * failure, integrator.py:90-107; a batched kernel cannot raise per env, so it reports) */
@@ -217,6 +230,21 @@ typedef struct pcg_env_cfg {
   const int32_t* rew_box_index; /* [rew_nbox] state index                                                     */
   const double* rew_box_lo;     /* [rew_nbox] physical lower bound (constraint_showcase/custom_reward.py:4-5) */
   const double* rew_box_hi;     /* [rew_nbox] physical upper bound                                            */
+  /* User expressions: the NON-affine form of the reference's callables (constraints(x,u) pcgym.py:119-125, 560-577;
+   * custom_reward(self, obs, uk, violated) pcgym.py:201-205, 470-471), given as C source and compiled into this plan's
+   * step kernel with hipRTC at pcg_plan_create() (cached by source hash: in the process and under $PCG_JIT_CACHE).
+   *   user_cons_src    statements that fill g[0 .. ncon-1] (double) from  x[] = the reference's state vector
+   *                    [x | SP slots | disturbances] (physical units) and u[] = uk [action | disturbance inputs];
+   *                    con_A / con_b are ignored when it is given.  Quirk Q3 (state / input "de-normalised" once
+   *                    more under PCG_F_REF_COMPAT with normalisation on) is applied to x[] and u[] first, as for rows.
+   *   user_reward_src  ONE expression of type double over  o[] = the (noisy) physical observation vector the reference
+   *                    hands to custom_reward, x[] = the noise-free state vector, u[] = uk, sp[] = SP_k[t] at the new t,
+   *                    violated (0/1), t (new step counter), N.  Replaces the built-in reward.
+   * Available in the one-env-per-lane general kernel only (any integrator, lock-stepped or per-env counters); not with
+   * per-env uncertain parameters, pcg_rollout or pcg_graph.  Math: exp log sqrt pow fabs fmin fmax sin cos tanh. */
+  const char* user_cons_src;
+  const char* user_reward_src;
+  const char* jit_include_dir;  /* directory holding pcg_kernels.hpp and its siblings (the library's own csrc/)      */
 } pcg_env_cfg;
 
 /*
@@ -359,6 +387,9 @@ PCG_API int pcg_graph_create(pcg_graph** out, pcg_plan* plan, const pcg_buffers*
 PCG_API int pcg_graph_launch(pcg_graph* graph, void* stream);
 PCG_API int pcg_graph_set_seed(pcg_graph* graph, uint64_t seed);
 PCG_API int pcg_graph_destroy(pcg_graph* graph);
+
+/* Compiler output of the most recent failed run-time compilation in this process (static storage, "" if none). */
+PCG_API const char* pcg_last_jit_log(void);
 
 /* Raw Philox4x32-10 block for KAT tests: ctr[4], key[2] -> out[4]. (host) */
 PCG_API void pcg_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

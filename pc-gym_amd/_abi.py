@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PCG_ABI_VERSION = 5
+PCG_ABI_VERSION = 6
 PCG_MAX_NX = 24
 PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
@@ -30,6 +30,7 @@ PCG_E_DIM = -3
 PCG_E_VALUE = -4
 PCG_E_PLAN = -5
 PCG_E_UNSUPPORTED = -6
+PCG_E_JIT = -7
 
 PCG_OPT_ENV_OFFSET = 1
 PCG_OPT_LDS_STAGES = 2
@@ -117,6 +118,9 @@ class pcg_env_cfg(C.Structure):
         ("rew_box_index", _pi),
         ("rew_box_lo", _pd),
         ("rew_box_hi", _pd),
+        ("user_cons_src", C.c_char_p),
+        ("user_reward_src", C.c_char_p),
+        ("jit_include_dir", C.c_char_p),
     ]
 
 
@@ -164,6 +168,7 @@ EXPORTS = [
     "pcg_graph_launch",
     "pcg_graph_set_seed",
     "pcg_graph_destroy",
+    "pcg_last_jit_log",
     "pcg_philox4x32_10",
 ]
 
@@ -216,6 +221,8 @@ def declare(lib):
     lib.pcg_graph_set_seed.argtypes = [vp, C.c_uint64]
     lib.pcg_graph_destroy.restype = C.c_int
     lib.pcg_graph_destroy.argtypes = [vp]
+    lib.pcg_last_jit_log.restype = C.c_char_p
+    lib.pcg_last_jit_log.argtypes = []
     lib.pcg_philox4x32_10.restype = None
     lib.pcg_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]

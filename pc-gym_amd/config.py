@@ -116,6 +116,45 @@ def probe_affine(fn, dims, sample_points, what):
     return A, c
 
 
+_EXPR_FUNCS = {"exp", "log", "sqrt", "pow", "fabs", "fmin", "fmax", "sin", "cos", "tanh"}
+
+
+def compile_expr(text, names, arrays, scalars, what):
+    """One user expression (C syntax) -> C source over the kernel's arrays.
+
+    The reference takes Python callables for ``constraints`` (pcgym.py:119-125) and ``custom_reward``
+    (pcgym.py:201-205); a batched kernel cannot call Python, so the non-affine cases are written as C expressions and
+    compiled into the step kernel at plan creation (hipRTC).  ``names`` maps model names (states, inputs, 'SP_<key>')
+    to array elements; only those, the arrays in ``arrays`` (indexed with integer literals), the scalars in
+    ``scalars``, numeric literals, arithmetic / comparison / ?: operators and a few math functions are accepted."""
+    import re
+
+    if not isinstance(text, str) or not text.strip():
+        raise ValueError(f"{what}: expression must be a non-empty string")
+    if re.search(r"[;{}\\#\"']|//|/\*", text):
+        raise ValueError(f"{what}: only a single expression is accepted (no statements, comments or strings): {text!r}")
+    out, pos = [], 0
+    for m in re.finditer(r"[A-Za-z_][A-Za-z_0-9]*", text):
+        out.append(text[pos:m.start()])
+        w = m.group(0)
+        prev = text[:m.start()].rstrip()[-1:] if m.start() else ""
+        if prev.isdigit() or prev == ".":  # exponent of a numeric literal: 1e-3
+            if re.fullmatch(r"[eE][0-9]*", w):
+                out.append(w)
+                pos = m.end()
+                continue
+        if w in names:
+            out.append(names[w])
+        elif w in arrays or w in scalars or w in _EXPR_FUNCS:
+            out.append(w)
+        else:
+            raise ValueError(f"{what}: unknown name '{w}' in {text!r} (known: {sorted(names)} + {sorted(arrays)} "
+                             f"+ {sorted(scalars)} + {sorted(_EXPR_FUNCS)})")
+        pos = m.end()
+    out.append(text[pos:])
+    return "".join(out)
+
+
 class EnvSpec:
     """Numeric image of env_params (see module docstring)."""
 
@@ -144,6 +183,13 @@ class EnvSpec:
         # script uses (pc-gym_paper/train_policies/*/custom_reward.py, constraint_showcase/custom_reward.py):
         #   {"kind": "sp_track", "R": 0.1, "R_u": 0.0, "box": {"T": [lower_bound, upper_bound]}}
         self.reward_track = None
+        self._reward_expr = None
+        if isinstance(self.custom_reward, dict) and "expr" in self.custom_reward:
+            # the callable form of custom_reward as a C expression (compiled into the kernel, see compile_expr)
+            if set(self.custom_reward) - {"expr"}:
+                raise ValueError("custom_reward {'expr': ...} takes no other keys")
+            self._reward_expr = self.custom_reward["expr"]
+            self.custom_reward = None
         if isinstance(self.custom_reward, dict):
             rt = dict(self.custom_reward)
             kind = rt.pop("kind", "sp_track")
@@ -160,7 +206,7 @@ class EnvSpec:
                 raise ValueError("declarative custom_reward 'sp_track' needs set-points (SP)")
             self.custom_reward = None
         self.reward_batch = self.SP is None
-        if self.reward_batch and self.custom_reward is None:
+        if self.reward_batch and self.custom_reward is None and self._reward_expr is None:
             self.reward_states = list(p["reward_states"])
             self.maximise_reward = bool(p["maximise_reward"])
         else:
@@ -310,7 +356,14 @@ class EnvSpec:
             self.done_on_constraint = bool(p["done_on_cons_vio"])
             self.r_penalty = bool(p["r_penalty"])
             self.constraint_active = True
-            if isinstance(cons, dict):
+            self._cons_exprs = None
+            if isinstance(cons, dict) and "expr" in cons:
+                # non-affine g(x,u) as C expressions, one per row (compiled into the kernel, see compile_expr)
+                ex = cons["expr"]
+                self._cons_exprs = [ex] if isinstance(ex, str) else list(ex)
+                A = np.zeros((len(self._cons_exprs), self.nobs + self.nu))
+                b = np.zeros(len(self._cons_exprs))
+            elif isinstance(cons, dict):
                 A = np.atleast_2d(np.asarray(cons["A"], dtype=_f64))
                 b = _arr(cons["b"])
             elif callable(cons):
@@ -335,6 +388,24 @@ class EnvSpec:
                 raise ValueError("operands could not be broadcast together: the reference cannot "
                                  "combine normalise_a, disturbances and constraints for na>1 "
                                  "(pcgym.py:597-600); set reference_compat=False or normalise_a=False")
+
+        # --- user expressions -> C source --------------------------------------------------
+        self.user_cons_src = None
+        self.user_reward_src = None
+        st_names, in_names = list(info["states"]), list(info["inputs"])
+        if getattr(self, "_cons_exprs", None):
+            names = {n: f"x[{i}]" for i, n in enumerate(st_names)}
+            names.update({n: f"u[{j}]" for j, n in enumerate(in_names)})
+            names.update({f"SP_{k}": f"x[{self.nx + j}]" for j, k in enumerate(self.sp_keys[:self.nsp_obs])})
+            rows = [compile_expr(e, names, {"x", "u"}, set(), f"constraints['expr'][{r}]")
+                    for r, e in enumerate(self._cons_exprs)]
+            self.user_cons_src = "\n".join(f"  g[{r}] = (double)({e});" for r, e in enumerate(rows))
+        if self._reward_expr is not None:
+            names = {n: f"o[{i}]" for i, n in enumerate(st_names)}
+            names.update({n: f"u[{j}]" for j, n in enumerate(in_names)})
+            names.update({f"SP_{k}": f"sp[{j}]" for j, k in enumerate(self.sp_keys)})
+            self.user_reward_src = compile_expr(self._reward_expr, names, {"o", "x", "u", "sp"}, {"violated", "t", "N"},
+                                                "custom_reward['expr']")
 
         # --- noise, pcgym.py:63-66, 453-466 ----------------------------------------
         self.noise = bool(p.get("noise", False))
@@ -599,4 +670,10 @@ class EnvSpec:
             cfg.rew_nbox = len(self.rew_box_index)
             cfg.rew_box_index = pi(self.rew_box_index)
             cfg.rew_box_lo, cfg.rew_box_hi = pd(self.rew_box_lo), pd(self.rew_box_hi)
+        if self.user_cons_src is not None or self.user_reward_src is not None:
+            import os
+
+            cfg.user_cons_src = self.user_cons_src.encode() if self.user_cons_src is not None else None
+            cfg.user_reward_src = self.user_reward_src.encode() if self.user_reward_src is not None else None
+            cfg.jit_include_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc").encode()
         return cfg, keep

@@ -4,6 +4,14 @@
 #include "pcg_kernels.hpp"
 #include "pcg_step_feat.hpp"
 
+#include <hip/hiprtc.h>
+
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+
 namespace pcg {
 
 // reset (pcgym.py:263-349)
@@ -80,6 +88,7 @@ struct pcg_plan {
   double* dsched;    // [nsp+nd][N]
   size_t sched_bytes;
   int cfg_nu;        // na + ndm as the caller counts them
+  hipFunction_t jit_fn[2];  // run-time compiled general step kernel with user expressions [per_env_t] (or null)
 };
 static constexpr uint32_t PLAN_MAGIC = 0x50434731u;  // 'PCG1'
 
@@ -102,6 +111,7 @@ const char* pcg_strerror(int status) {
     case PCG_E_VALUE: return "invalid scalar value";
     case PCG_E_PLAN: return "invalid plan handle or wrong device";
     case PCG_E_UNSUPPORTED: return "combination not supported by this build";
+    case PCG_E_JIT: return "a user expression did not compile (see pcg_last_jit_log())";
     default: break;
   }
   if (status > 0) return hipGetErrorString((hipError_t)status);
@@ -172,7 +182,8 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   if (nrew && !c->rew_index) return PCG_E_NULL;
   if (nd && (!c->d_slot || !c->d_sched)) return PCG_E_NULL;
   if (ndm && !c->d_default) return PCG_E_NULL;
-  if (ncon && (!c->con_A || !c->con_b)) return PCG_E_NULL;
+  if (ncon && !c->user_cons_src && (!c->con_A || !c->con_b)) return PCG_E_NULL;
+  if ((c->user_cons_src || c->user_reward_src) && (k.dynamic || c->nunc > 0)) return PCG_E_UNSUPPORTED;
   if ((c->flags & PCG_F_A_DELTA) && (!c->a_act_low || !c->a_act_high || !c->a_0)) return PCG_E_NULL;
   if ((c->flags & PCG_F_NOISE) && !c->noise_pct) return PCG_E_NULL;
   if ((c->flags & PCG_F_GAUSS_DIST) && nd && (!c->d_sigma || !c->d_clip_lo || !c->d_clip_hi)) return PCG_E_NULL;
@@ -269,7 +280,26 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   }
   // constraint rows: cfg layout [state(nobs) | uk(cnu)] -> padded kernel layout; compat Q3 folded:
   //   state' = (s+1)*hs + lo = s*hs + (hs+lo)   (pcgym.py:601-608), input' likewise with a_space (:597-600)
-  for (int r = 0; r < ncon; ++r) {
+  // the same quirk for user constraint expressions, as an affine map of the vectors they index
+  for (int i = 0; i < PCG_MAX_NOBS; ++i) { d->q3_mul[i] = 1.0; d->q3_add[i] = 0.0; }
+  for (int j = 0; j < KNU; ++j) { d->q3u_mul[j] = 1.0; d->q3u_add[j] = 0.0; }
+  if (compat && norm_o)
+    for (int i = 0; i < nobs; ++i) {
+      const double hs = (c->o_high[i] - c->o_low[i]) / 2;
+      d->q3_mul[i] = hs;
+      d->q3_add[i] = hs + c->o_low[i];
+    }
+  if (compat && norm_a && c->user_cons_src) {
+    if (cnu != na && na != 1) return PCG_E_UNSUPPORTED;  // the reference itself raises (broadcast error)
+    for (int j = 0; j < cnu; ++j) {
+      const int q = (na == 1) ? 0 : j;
+      const double hs = (c->a_high[q] - c->a_low[q]) / 2;
+      const int col = (j < na) ? j : k.na + (j - na);  // kernel-side u layout [NA | NDM]
+      d->q3u_mul[col] = hs;
+      d->q3u_add[col] = hs + c->a_low[q];
+    }
+  }
+  for (int r = 0; r < (c->user_cons_src ? 0 : ncon); ++r) {
     const double* row = c->con_A + (size_t)r * (nobs + cnu);
     double b = c->con_b[r];
     for (int i = 0; i < nobs; ++i) {
@@ -340,6 +370,123 @@ static int kernel_id_for(const pcg_env_cfg* c) {
   return kid;
 }
 
+// ---- run-time compilation of user expressions (pcgym_hip.h: user_cons_src / user_reward_src) ---------------------
+// The general one-env-per-lane step kernel of the plan's model is instantiated from the library's own headers with the
+// user's source spliced in as pcg_user_constraints / pcg_user_reward, compiled with hipRTC, loaded as a module.
+struct JitModule {
+  hipFunction_t fn[2];
+};
+static std::mutex g_jit_mu;
+static std::map<uint64_t, JitModule> g_jit_cache;
+static std::string g_jit_log;
+
+static uint64_t fnv1a(const std::string& s) {
+  uint64_t h = 1469598103934665603ull;
+  for (unsigned char ch : s) h = (h ^ ch) * 1099511628211ull;
+  return h;
+}
+
+static int jit_step_kernels(const pcg_env_cfg* cfg, int kid, int device, hipFunction_t (&out)[2]) {
+  if (!cfg->jit_include_dir) return PCG_E_NULL;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  std::string arch = prop.gcnArchName;
+  arch = arch.substr(0, arch.find(':'));
+  std::ostringstream src;
+  if (cfg->user_cons_src) src << "#define PCG_USER_NCON " << cfg->ncon << "\n";
+  if (cfg->user_reward_src) src << "#define PCG_USER_REWARD 1\n";
+  src << "#include \"pcg_kernels.hpp\"\n"
+      << "static_assert(sizeof(pcg::DevConst) == " << sizeof(DevConst) << " && sizeof(pcg::StepArgs) == " << sizeof(StepArgs)
+      << ", \"kernel headers differ from the ones libpcgym_hip.so was built from\");\n"
+      << "namespace pcg {\n";
+  if (cfg->user_cons_src)
+    src << "__device__ void pcg_user_constraints(const double* x, const double* u, double* g) {\n" << cfg->user_cons_src
+        << "\n}\n";
+  if (cfg->user_reward_src)
+    src << "__device__ double pcg_user_reward(const double* o, const double* x, const double* u, const double* sp, "
+           "int violated, int t, int N) {\n  return (double)(" << cfg->user_reward_src << ");\n}\n";
+  src << "}\n";
+  std::string names[2];
+  for (int pe = 0; pe < 2; ++pe) {
+    std::ostringstream nm;
+    nm << "pcg::step_kernel<pcg::Model<" << kid << ">, " << cfg->integrator_id << ", " << (pe ? "true" : "false")
+       << ", false, true, false>";
+    names[pe] = nm.str();
+    src << "template __global__ void " << names[pe] << "(const pcg::StepArgs);\n";
+  }
+  const std::string text = src.str();
+  const uint64_t key = fnv1a(text + "|" + arch + "|" + std::to_string(PCG_ABI_VERSION) + "|" + std::to_string(device));
+  std::lock_guard<std::mutex> lk(g_jit_mu);
+  auto hit = g_jit_cache.find(key);
+  if (hit != g_jit_cache.end()) {
+    out[0] = hit->second.fn[0];
+    out[1] = hit->second.fn[1];
+    return PCG_OK;
+  }
+  // disk cache: code object + the two lowered kernel names
+  const char* cdir = std::getenv("PCG_JIT_CACHE");
+  std::string dir = cdir ? cdir : "/tmp/pcgym_amd_jit";
+  char hex[32];
+  std::snprintf(hex, sizeof(hex), "%016llx", (unsigned long long)fnv1a(text + "|" + arch + "|" + std::to_string(PCG_ABI_VERSION)));
+  const std::string base = dir + "/" + hex;
+  std::string code, low[2];
+  {
+    std::ifstream fc(base + ".co", std::ios::binary), fn(base + ".names");
+    if (fc && fn) {
+      code.assign(std::istreambuf_iterator<char>(fc), std::istreambuf_iterator<char>());
+      std::getline(fn, low[0]);
+      std::getline(fn, low[1]);
+      if (low[0].empty() || low[1].empty()) code.clear();
+    }
+  }
+  if (code.empty()) {
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, text.c_str(), "pcg_user_step.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return PCG_E_JIT;
+    for (int pe = 0; pe < 2; ++pe) hiprtcAddNameExpression(prog, names[pe].c_str());
+    const std::string oarch = "--offload-arch=" + arch, oinc = std::string("-I") + cfg->jit_include_dir;
+    const char* opts[] = {oarch.c_str(), "-O3", "-std=c++17", oinc.c_str()};
+    const hiprtcResult cr = hiprtcCompileProgram(prog, 4, opts);
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    g_jit_log.assign(ls, '\0');
+    if (ls) hiprtcGetProgramLog(prog, &g_jit_log[0]);
+    if (cr != HIPRTC_SUCCESS) {
+      hiprtcDestroyProgram(&prog);
+      return PCG_E_JIT;
+    }
+    for (int pe = 0; pe < 2; ++pe) {
+      const char* ln = nullptr;
+      if (hiprtcGetLoweredName(prog, names[pe].c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
+        hiprtcDestroyProgram(&prog);
+        return PCG_E_JIT;
+      }
+      low[pe] = ln;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    code.assign(cs, '\0');
+    hiprtcGetCode(prog, &code[0]);
+    hiprtcDestroyProgram(&prog);
+    // best effort: a cache that cannot be written is only slower next time
+    std::string mk = "mkdir -p '" + dir + "'";
+    if (std::system(mk.c_str()) == 0) {
+      std::ofstream fc(base + ".co.tmp", std::ios::binary), fn(base + ".names");
+      fc.write(code.data(), (std::streamsize)code.size());
+      fn << low[0] << "\n" << low[1] << "\n";
+      fc.close();
+      std::rename((base + ".co.tmp").c_str(), (base + ".co").c_str());
+    }
+  }
+  hipModule_t mod;
+  HIP_TRY(hipModuleLoadData(&mod, code.data()));
+  JitModule jm;
+  for (int pe = 0; pe < 2; ++pe) HIP_TRY(hipModuleGetFunction(&jm.fn[pe], mod, low[pe].c_str()));
+  g_jit_cache[key] = jm;
+  out[0] = jm.fn[0];
+  out[1] = jm.fn[1];
+  return PCG_OK;
+}
+
 int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   if (!out || !cfg) return PCG_E_NULL;
   *out = nullptr;
@@ -366,6 +513,7 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   p->env_offset = 0;
   p->dC = nullptr;
   p->dsched = nullptr;
+  p->jit_fn[0] = p->jit_fn[1] = nullptr;
   hipError_t e = hipGetDevice(&p->device);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&p->num_cus, hipDeviceAttributeMultiprocessorCount, p->device);
   if (e != hipSuccess) { delete p; return (int)e; }
@@ -390,9 +538,20 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
     delete p;
     return (int)e;
   }
+  if (cfg->user_cons_src || cfg->user_reward_src) {
+    rc = jit_step_kernels(cfg, p->kid, p->device, p->jit_fn);
+    if (rc != PCG_OK) {
+      (void)hipFree(p->dC);
+      (void)hipFree(p->dsched);
+      delete p;
+      return rc;
+    }
+  }
   *out = p;
   return PCG_OK;
 }
+
+const char* pcg_last_jit_log(void) { return g_jit_log.c_str(); }
 
 static bool plan_ok(const pcg_plan* p) { return p && p->magic == PLAN_MAGIC; }
 
@@ -568,6 +727,13 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       shmem += sb;
     }
   }
+  if (p->jit_fn[0]) {  // run-time compiled general kernel with the plan's user expressions
+    if (lds_st) return PCG_E_UNSUPPORTED;
+    void* argv[1] = {&a};
+    const size_t sh = (per_env_t && a.sched_in_lds) ? shmem : 0;
+    return (int)hipModuleLaunchKernel(p->jit_fn[per_env_t ? 1 : 0], grid_for(io->B, block), 1, 1, block, 1, 1, (unsigned)sh,
+                                      (hipStream_t)stream, argv, nullptr);
+  }
   if (c.nunc > 0) {  // per-env uncertain parameters: dedicated general kernel
     if (!io->p_unc) return PCG_E_NULL;
     StepFn ufn = k.step_unc[p->integrator_id][per_env_t ? 1 : 0];
@@ -723,7 +889,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   const DevConst& c = p->hc;
   if ((c.flags & PCG_F_A_DELTA) && !io->a_save) return PCG_E_NULL;
   if ((c.flags & PCG_F_REWARD_TRACK) && !io->u_prev) return PCG_E_NULL;
-  if (c.nunc > 0) return PCG_E_UNSUPPORTED;  // parameter uncertainty: per-step kernel only
+  if (c.nunc > 0 || p->jit_fn[0]) return PCG_E_UNSUPPORTED;  // parameter uncertainty / user expressions: per-step kernel only
   a.t_scalar = t0;
   a.seed = seed;
   a.T = T;
@@ -795,7 +961,7 @@ int pcg_graph_create(pcg_graph** out, pcg_plan* p, const pcg_buffers* io, const 
   *out = nullptr;
   if (!plan_ok(p)) return PCG_E_PLAN;
   if (!io || !a_steps) return PCG_E_NULL;
-  if (io->t) return PCG_E_UNSUPPORTED;
+  if (io->t || p->jit_fn[0]) return PCG_E_UNSUPPORTED;
   if (T <= 0 || t0 < 0 || io->B <= 0) return PCG_E_DIM;
   for (int j = 0; j < T; ++j)
     if (!a_steps[j] || (d_steps && !d_steps[j])) return PCG_E_NULL;

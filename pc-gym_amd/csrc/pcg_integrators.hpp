@@ -12,7 +12,9 @@
 // The controller is specified in DESIGN.md ("Adaptive stepping") and implemented
 // independently in oracle/pcg_oracle.c.
 #pragma once
+#ifndef __HIPCC_RTC__  // built in under hipRTC
 #include <hip/hip_runtime.h>
+#endif
 
 #include "pcg_models.hpp"
 

@@ -24,15 +24,18 @@
 // integration_engine (src/pcgym/integrator.py:65-107,163-182), model RHS
 // (src/pcgym/model_classes.py) -- see pcg_models.hpp for per-model line ranges.
 #pragma once
+#ifndef __HIPCC_RTC__  // built in under hipRTC
 #include <hip/hip_runtime.h>
+#endif
 
+#ifndef __HIPCC_RTC__  // host-side headers: not available (and not needed) under hipRTC
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
-#include <type_traits>
 #include <vector>
+#endif
 
 #include "../../include/pcgym_hip.h"
 #include "pcg_integrators.hpp"
@@ -103,6 +106,8 @@ struct DevConst {
   int32_t nbox, box_index[PCG_MAX_RBOX];
   double box_lo[PCG_MAX_RBOX], box_inv[PCG_MAX_RBOX];    // o_space low and 1/(high-low) of each boxed state
   double box_lon[PCG_MAX_RBOX], box_hin[PCG_MAX_RBOX];   // box bounds, normalised
+  // user constraint expressions (run-time compiled): quirk Q3 as an affine map of the state / input vector they see
+  double q3_mul[PCG_MAX_NOBS], q3_add[PCG_MAX_NOBS], q3u_mul[KNU], q3u_add[KNU];
 };
 
 using CDevConst = const PCG_CONSTANT DevConst;
@@ -311,6 +316,29 @@ struct RhsFn {
   PCG_DEV void operator()(const R (&x)[M::NX], R (&dx)[M::NX]) const { M::rhs(kp, hold, x, dx); }
 };
 
+#ifdef PCG_USER_NCON
+// user constraint expressions, defined by the run-time compiled translation unit (pcgym_hip.h: user_cons_src)
+__device__ void pcg_user_constraints(const double* x, const double* u, double* g);
+#endif
+#ifdef PCG_USER_REWARD
+__device__ double pcg_user_reward(const double* o, const double* x, const double* u, const double* sp, int violated,
+                                  int t, int N);
+#endif
+
+// the reference's state vector [x | SP slots | disturbances] as the user expressions index it
+template <class M>
+PCG_DEV void state_vector(CDevConst& c, const double (&x)[M::NX], const double (&spv)[PCG_MAX_NSP],
+                          const double (&dv)[PCG_MAX_NDM], double (&s)[PCG_MAX_NOBS]) {
+  const int nx = M::DYNAMIC ? c.nx : M::NX, nso = c.nsp_obs, nd = c.nd;
+#pragma unroll
+  for (int i = 0; i < PCG_MAX_NOBS; ++i) s[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < M::NX; ++i)
+    if (i < nx) s[i] = x[i];
+  for (int k = 0; k < nso; ++k) s[nx + k] = spv[k];
+  for (int k = 0; k < nd; ++k) s[nx + nso + k] = dv[k];
+}
+
 // constraint rows g = A.[x|sp|d|u] - b  (affine form of the reference's callable, pcgym.py:560-577);
 // writes rows to gout (if non-null) and returns "any row > 0".
 template <class M>
@@ -318,6 +346,22 @@ PCG_DEV bool constraint_rows(CDevConst& c, const double (&x)[M::NX], const doubl
                              const double (&dv)[PCG_MAX_NDM], const double (&u)[M::NA + M::NDM], double* gout,
                              int64_t B, int64_t e) {
   bool violated = false;
+#ifdef PCG_USER_NCON
+  {  // the callable form: g = user(x, u) on the (quirk Q3: re-"de-normalised") state / input vectors
+    double s[PCG_MAX_NOBS], uu[KNU], g[PCG_USER_NCON];
+    state_vector<M>(c, x, spv, dv, s);
+    for (int i = 0; i < c.nobs; ++i) s[i] = s[i] * c.q3_mul[i] + c.q3_add[i];
+#pragma unroll
+    for (int j = 0; j < KNU; ++j) uu[j] = (j < M::NA + M::NDM) ? u[j < M::NA + M::NDM ? j : 0] * c.q3u_mul[j] + c.q3u_add[j] : 0.0;
+    pcg_user_constraints(s, uu, g);
+#pragma unroll
+    for (int r = 0; r < PCG_USER_NCON; ++r) {
+      if (gout) gout[(size_t)r * B + e] = g[r];
+      violated |= (g[r] > 0.0);
+    }
+    return violated;
+  }
+#endif
   for (int r = 0; r < c.ncon; ++r) {
     const PCG_CONSTANT double* row = c.con_A[r];
     double g = -c.con_b[r];
@@ -568,7 +612,7 @@ PCG_DEV void env_post(const StepArgs& A, CDevConst& c, const double* sched_l, in
     for (int k = 0; k < PCG_MAX_NSP; ++k)
       if (k < nsp) {
         double xv = pick<NX>(on, c.sp_index[k]);
-        if constexpr (std::is_same<M, Model<PCG_MODEL_CRYST>>::value) {
+        if constexpr (tt::is_same<M, Model<PCG_MODEL_CRYST>>::value) {
           if (flags & PCG_F_REWARD_CRYST) {  // cryst_train.py:24-25: CV and Ln from the observed moments
             if (c.sp_index[k] == 5) xv = sqrt(on[2] * on[0] / (on[1] * on[1]) - 1.0);
             if (c.sp_index[k] == 6) xv = on[1] / on[0];
@@ -596,6 +640,16 @@ PCG_DEV void env_post(const StepArgs& A, CDevConst& c, const double* sched_l, in
       }
     out.rew = -cost;
   }
+#ifdef PCG_USER_REWARD
+  {  // the callable form of custom_reward(self, obs, uk, violated) (pcgym.py:470-471): obs = the noisy physical vector
+    double of[PCG_MAX_NOBS], xf[PCG_MAX_NOBS], uu[KNU];
+    state_vector<M>(c, on, spv, dv, of);
+    state_vector<M>(c, x, spv, dv, xf);
+#pragma unroll
+    for (int j = 0; j < KNU; ++j) uu[j] = (j < NA + M::NDM) ? u[j < NA + M::NDM ? j : 0] : 0.0;
+    out.rew = pcg_user_reward(of, xf, uu, spn, violated ? 1 : 0, t_new, N);
+  }
+#endif
 #pragma unroll
   for (int k = 0; k < PCG_MAX_NSP; ++k)
     if (k < nso) out.osp[k] = (spv[k] - c.omap[nx + k].lo) * c.omap[nx + k].sc + c.omap[nx + k].off;
@@ -1361,10 +1415,12 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG)) void integrate_kernel(CDevCo
 #include "pcg_step_queue.hpp"
 namespace pcg {
 
+using StepFn = void (*)(const StepArgs);
+
+#ifndef __HIPCC_RTC__
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-using StepFn = void (*)(const StepArgs);
 using RhsKFn = void (*)(CDevConst*, int64_t, int, const double*, const double*, double*);
 using IntKFn = void (*)(CDevConst*, int64_t, int, double*, const double*, int32_t*);
 
@@ -1476,5 +1532,7 @@ Kernels make_kernels() {
   k.kp_bytes = sizeof(typename M::KP);
   return k;
 }
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace pcg

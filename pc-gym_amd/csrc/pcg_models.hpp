@@ -9,7 +9,9 @@
 // model below); constants that the reference recomputes on every call
 // (q/V, 1/(rho*C), ...) are folded once on the host in prep().
 #pragma once
+#ifndef __HIPCC_RTC__  // built in under hipRTC
 #include <hip/hip_runtime.h>
+#endif
 
 #include "../../include/pcgym_hip.h"
 #include "pcg_pack.hpp"

@@ -9,9 +9,23 @@
 //
 // Pack<1> is a plain double in a struct: one code path for both widths.
 #pragma once
+#ifndef __HIPCC_RTC__  // built in under hipRTC
 #include <hip/hip_runtime.h>
+#endif
 
 namespace pcg {
+
+// the handful of type traits the device code needs, spelled out here so that the kernel headers also compile under
+// hipRTC (run-time compilation of user expressions, pcgym_amd/jit.py), which ships no <type_traits>
+namespace tt {
+struct true_type { static constexpr bool value = true; };
+struct false_type { static constexpr bool value = false; };
+template <class A, class B> struct is_same : false_type {};
+template <class A> struct is_same<A, A> : true_type {};
+template <bool C, class A, class B> struct conditional { using type = A; };
+template <class A, class B> struct conditional<false, A, B> { using type = B; };
+template <class...> using void_t = void;
+}  // namespace tt
 
 #define PCG_PK __device__ __forceinline__
 

@@ -38,9 +38,9 @@ constexpr int QREFILL = 8;         // idle lanes that trigger a refill (or: no b
 
 // model hook: a cheap, monotone proxy of the number of RK steps an env step will take (the sort key)
 template <class M, class = void>
-struct has_cost_key : std::false_type {};
+struct has_cost_key : tt::false_type {};
 template <class M>
-struct has_cost_key<M, std::void_t<decltype(M::COST_KEY)>> : std::true_type {};
+struct has_cost_key<M, tt::void_t<decltype(M::COST_KEY)>> : tt::true_type {};
 
 // ---- DOPRI5 in resumable form: the state one lane carries for the env it is integrating -------------------------
 template <int NX>

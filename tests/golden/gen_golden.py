@@ -275,7 +275,7 @@ def gen_steps(P, out, only_new=False):
     for name, sc in SC.scenarios().items():
         if only_new and os.path.exists(os.path.join(out, f"step_{name}.npz")):
             continue
-        p = sc["env_params"]
+        p = sc.get("ref_env_params", sc["env_params"])  # (Python callables where our side takes C expressions)
         if sc.get("ref_custom_reward"):  # the reference side runs its own callable (loaded from the reference tree)
             import copy
             import importlib.util

@@ -47,6 +47,24 @@ def cons_me(x, u):
     return np.array([x[8] - 0.45, 0.2 - x[0]]).reshape(-1,)
 
 
+def cons_cstr_nonaffine(x, u):
+    """a quadratic band on T and a curved Ca floor: NOT affine in (x, u) -- on our side the same two rows are C
+    expressions compiled into the step kernel (env_params['constraints'] = {'expr': [...]})"""
+    return np.array([0.02 * (x[1] - 325.0) ** 2 - 0.5, 0.84 - x[0] - 5e-4 * (u[0] - 298.0) ** 2]).reshape(-1,)
+
+
+def cons_cstr_nonaffine_q3(x, u):
+    """with normalise_o / normalise_a the reference hands the callable a re-"de-normalised" state and input (quirk Q3,
+    pcgym.py:597-608): T = 327 K arrives as 8508 -- the bounds are written for THOSE numbers"""
+    return np.array([1e-6 * (x[1] - 8500.0) ** 2 - 0.004, 1.0e3 - 1.0e-2 * u[0] ** 2 + x[0]]).reshape(-1,)
+
+
+def reward_cstr_exp(self, x, u, con):
+    """custom_reward(self, obs, uk, violated) protocol (pcgym.py:470-471): tracking + an exponential temperature cost
+    + a violation charge -- outside the declarative sp_track family; on our side a C expression"""
+    return float(-1e3 * (x[0] - self.SP["Ca"][self.t]) ** 2 - 0.05 * np.exp(0.1 * (x[1] - 330.0)) - (5.0 if con else 0.0))
+
+
 class LinearCustomModel:
     """Shape of tests/environment/test_make_env_custom_model.py:7-25 (written
     from the protocol description, pcgym.py:150-153: __call__(x,u), info(),
@@ -327,6 +345,19 @@ def scenarios():
                                                       "oracle_reward", "extract"))
 
     # the reference's own known-answer test (custom linear model)
+    # ---- non-affine callables: Python on the reference side, C expressions (run-time compiled) on ours ----------
+    p = _cstr_base()
+    p.update(model="cstr", normalise_a=False, normalise_o=False, done_on_cons_vio=False, r_penalty=True)
+    pr = dict(p, constraints=cons_cstr_nonaffine)
+    pe = dict(p, constraints={"expr": ["0.02*(T-325.0)*(T-325.0) - 0.5", "0.84 - Ca - 5e-4*pow(Tc-298.0, 2)"]})
+    S["cstr_expr_cons_raw"] = dict(env_params=pe, ref_env_params=pr, steps=59, action_seed=41, raw_actions=True)
+    p = _cstr_base()
+    p.update(model="cstr", normalise_a=True, normalise_o=True, done_on_cons_vio=True, r_penalty=False)
+    pr = dict(p, constraints=cons_cstr_nonaffine_q3, custom_reward=reward_cstr_exp)
+    pe = dict(p, constraints={"expr": ["1e-6*(x[1]-8500.0)*(x[1]-8500.0) - 0.004", "1.0e3 - 1.0e-2*u[0]*u[0] + x[0]"]},
+              custom_reward={"expr": "-1e3*(Ca-SP_Ca)*(Ca-SP_Ca) - 0.05*exp(0.1*(T-330.0)) - (violated ? 5.0 : 0.0)"})
+    S["cstr_expr_reward_q3"] = dict(env_params=pe, ref_env_params=pr, steps=59, action_seed=42)
+
     S["custom_linear_kat"] = dict(
         env_params={
             "custom_model": LinearCustomModel(1.5, 2.5),

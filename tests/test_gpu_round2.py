@@ -495,3 +495,103 @@ def test_work_queue_results_do_not_depend_on_the_batch_order(monkeypatch):
         assert torch.equal(e1.nsteps[:, perm], e2.nsteps) and torch.equal(e1.obs_soa[:, perm], e2.obs_soa)
     e1.close()
     e2.close()
+
+
+# ---------------------------------------------------------------- run-time compiled user expressions (hipRTC) ----
+@pytest.mark.parametrize("name", ["cstr_expr_cons_raw", "cstr_expr_reward_q3"])
+def test_user_expressions_in_the_batched_kernel_match_the_reference_callables(name):
+    """non-affine constraints(x,u) / custom_reward(self, obs, uk, violated): Python callables in the reference
+    (tests/golden/scenarios.py: cons_cstr_nonaffine*, reward_cstr_exp), C expressions compiled into the general step
+    kernel with hipRTC here.  (a) every env of a VecEnv batch replays the reference's recording; (b) per-env random
+    actions against the oracle's integration + a NumPy evaluation of the same callables."""
+    torch = _torch()
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+    from pcgym_amd.config import EnvSpec
+
+    sc = SC.scenarios()[name]
+    g = H.gold("step_" + name)
+    p = copy.deepcopy(sc["env_params"])
+    p.update(H.tight_for(p))
+    B = 130
+    env = VecEnv(p, n_envs=B, seed=1)
+    assert env.spec.user_cons_src is not None and env.spec.ncon == 2
+    A = SC.actions_for(name, sc)
+    obs, _ = env.reset()
+    assert np.allclose(obs.cpu().numpy(), g["obs"][0][None, :], rtol=1e-12, atol=1e-12)
+    ci = g["cons_info"]
+    for i in range(sc["steps"]):
+        a = torch.tensor(np.repeat(A[i].reshape(-1, 1), B, axis=1), device=env.device)
+        o, r, d, _, info = env.step(a)
+        want = g["obs"][i + 1]
+        assert np.all(np.abs(o.cpu().numpy() - want[None, :]) <= 2e-9 * np.maximum(np.abs(want), 1.0)), (name, i)
+        assert np.allclose(r.cpu().numpy(), g["rew"][i], rtol=1e-7, atol=1e-9), (name, i, r[0].item(), g["rew"][i])
+        if i == 0:
+            assert np.allclose(env.g_pre.cpu().numpy(), ci[:, 0:1], rtol=1e-9, atol=1e-9 * np.max(np.abs(ci)))
+        assert np.allclose(info["g"].cpu().numpy(), ci[:, i + 1:i + 2], rtol=1e-8, atol=1e-9 * np.max(np.abs(ci))), (name, i)
+        assert np.array_equal(info["viol"].cpu().numpy(), np.full(B, int((ci[:, i + 1] > 0).any()), dtype=np.uint8))
+    env.close()
+
+    # (b) random per-env actions: integration by the oracle (same plan without the expressions), epilogue in NumPy
+    ref = sc["ref_env_params"]
+    cons_py, rew_py = ref["constraints"], ref.get("custom_reward")
+    pb = copy.deepcopy(p)
+    pb.pop("constraints"), pb.pop("custom_reward", None)
+    for k in ("done_on_cons_vio", "r_penalty"):
+        pb.pop(k, None)
+    B = 1001
+    env = VecEnv(copy.deepcopy(p), n_envs=B, seed=3, per_env_t=True)
+    s = env.spec
+    orc = O.OracleEnv(EnvSpec(pb), B, seed=3, per_env_t=True)
+    env.reset()
+    orc.reset()
+    rng = np.random.default_rng(5)
+    lo, hi = s.a_low[0], s.a_high[0]
+    olo, ohi = s.o_low, s.o_high
+    for i in range(6):
+        a = rng.uniform(-1, 1, (1, B)) if s.normalise_a else rng.uniform(lo, hi, (1, B))
+        _, r, d, _, info = env.step(torch.tensor(a, device=env.device))
+        orc.step(a)
+        uk = (a[0] + 1) * (hi - lo) / 2 + lo if s.normalise_a else a[0]
+        sp_old = s.sp[0, min(i, s.N - 1)]
+        sp_new = s.sp[0, min(i + 1, s.N - 1)]
+        gg = np.zeros((2, B))
+        rr = np.zeros(B)
+        for b in range(B):
+            st = np.array([orc.x[0, b], orc.x[1, b], sp_old])
+            uu = np.array([uk[b]])
+            sq, uq = st, uu
+            if s.reference_compat and s.normalise_o:  # quirk Q3: what the reference hands the callable
+                sq = (st + 1) * (ohi - olo) / 2 + olo
+            if s.reference_compat and s.normalise_a:
+                uq = (uu + 1) * (hi - lo) / 2 + lo
+            gg[:, b] = cons_py(sq, uq)
+            viol = bool((gg[:, b] > 0).any())
+            if rew_py is not None:
+                class _E:  # the attributes the callable reads from `self`
+                    SP = {"Ca": s.sp[0]}
+                    t = i + 1
+                rr[b] = rew_py(_E, st, uu, viol)
+            else:
+                rr[b] = -1e3 * (st[0] - sp_new) ** 2 - (1000.0 if (viol and s.r_penalty) else 0.0)
+        assert np.allclose(env.x.cpu().numpy(), orc.x, rtol=1e-11), (name, i)
+        assert np.allclose(info["g"].cpu().numpy(), gg, rtol=1e-9, atol=1e-9 * np.abs(gg).max()), (name, i)
+        assert np.array_equal(info["viol"].cpu().numpy().astype(bool), (gg > 0).any(axis=0)), (name, i)
+        assert np.allclose(r.cpu().numpy(), rr, rtol=1e-9, atol=1e-9), (name, i)
+    env.close()
+
+
+def test_user_expression_errors_are_reported_not_crashed():
+    """a C expression that does not compile -> PCG_E_JIT with the compiler's message; names outside the whitelist are
+    rejected on the host before anything is compiled"""
+    _torch()
+    from pcgym_amd import VecEnv, _lib
+
+    p = copy.deepcopy(SC.scenarios()["cstr_expr_cons_raw"]["env_params"])
+    p["constraints"] = {"expr": ["T - ", "Ca"]}  # syntactically broken C
+    with pytest.raises(_lib.PcgError) as ei:
+        VecEnv(p, n_envs=8)
+    assert ei.value.status == -7 and b"error" in _lib.load().pcg_last_jit_log()
+    p["constraints"] = {"expr": ["system(T)"]}
+    with pytest.raises(ValueError):
+        VecEnv(p, n_envs=8)

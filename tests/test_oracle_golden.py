@@ -153,7 +153,9 @@ def test_reference_kat_custom_linear_model():
     assert np.allclose(env.obs[:, 0], exact, rtol=1e-8)
 
 
-STEP_SCENARIOS = sorted(SC.scenarios().keys())
+# (scenarios whose callables are C expressions on our side exist only as compiled kernels: the GPU tests replay their
+# reference recordings; the C oracle has no expression evaluator)
+STEP_SCENARIOS = sorted(k for k, v in SC.scenarios().items() if "ref_env_params" not in v)
 
 
 @pytest.mark.parametrize("name", STEP_SCENARIOS)
