@@ -6,6 +6,7 @@ per-timestep hot path as HIP kernels behind the C ABI in include/pcgym_hip.h.
 """
 from .config import EnvSpec  # noqa: F401
 from .env import StepGraph, VecEnv, make_env, make_vec_env  # noqa: F401
+from .gather import HostGather  # noqa: F401
 from .mixed import MixedVecEnv, make_mixed_sharded_env, mixed_shard_layout  # noqa: F401
 from .rollout import collect_rollouts, reproducibility_metric  # noqa: F401
 from .spaces import Box  # noqa: F401

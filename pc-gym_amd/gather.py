@@ -1,0 +1,54 @@
+"""Host-side trajectory gather (BASELINE.json north_star: "host-side trajectory gather only").
+
+The step kernels leave observation, reward and done on the device; a host consumer (logging, a CPU policy, the
+reference's rollout containers -- policy_evaluation.py:155-197 fills numpy arrays step by step) wants them in host
+memory.  ``HostGather`` moves them without stalling the step loop:
+
+  main stream :  step k  ->  device-to-device snapshot of obs/rew/done into staging[k % 2]  ->  step k+1 ...
+  copy stream :                 (waits for the snapshot)  D2H staging[k % 2] -> pinned host[k % 2]
+
+The snapshot costs ~33 MB of HBM traffic per step for cstr at B = 2^20 (a few us); the D2H leg runs at PCIe speed
+concurrently with the following steps.  The step loop only waits when it is more than two steps ahead of the bus.
+"""
+from __future__ import annotations
+
+
+class HostGather:
+    def __init__(self, env, fields=("obs", "rew", "done")):
+        import torch
+
+        self.env = env
+        self.torch = torch
+        self.fields = tuple(fields)
+        src = {"obs": env.obs_soa, "rew": env.rew, "done": env.done, "x": env.x}
+        self._src = [src[f] for f in self.fields]
+        self._stage = [[torch.empty_like(t) for t in self._src] for _ in range(2)]
+        self._host = [[torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in self._src] for _ in range(2)]
+        self._copy = torch.cuda.Stream(device=env.device)
+        self._snap = [torch.cuda.Event() for _ in range(2)]
+        self._done = [torch.cuda.Event() for _ in range(2)]
+        self._k = 0
+        self.bytes_per_step = sum(t.numel() * t.element_size() for t in self._src)
+
+    def push(self):
+        """Call after env.step(): snapshot this step's outputs and start their D2H copy.  Returns the slot index."""
+        torch = self.torch
+        k = self._k & 1
+        main = torch.cuda.current_stream(self.env.device)
+        if self._k >= 2:
+            main.wait_event(self._done[k])  # staging[k] is free once its previous D2H has finished
+        for s, d in zip(self._src, self._stage[k]):
+            d.copy_(s, non_blocking=True)
+        self._snap[k].record(main)
+        with torch.cuda.stream(self._copy):
+            self._copy.wait_event(self._snap[k])
+            for s, h in zip(self._stage[k], self._host[k]):
+                h.copy_(s, non_blocking=True)
+            self._done[k].record(self._copy)
+        self._k += 1
+        return k
+
+    def wait(self, slot):
+        """Block the host until the copy into `slot` has landed; returns {field: pinned host tensor}."""
+        self._done[slot].synchronize()
+        return dict(zip(self.fields, self._host[slot]))
