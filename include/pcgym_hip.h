@@ -274,9 +274,11 @@ typedef struct pcg_buffers {
                                             leaves it alone, as the reference never clears u_prev              */
   double* p_unc;      /* [nunc][B]  in/out  per-env values of the uncertain parameters: written by
                                             pcg_reset, read by pcg_step (required when nunc > 0)        */
-  uint8_t* status;    /* [B]        out|NULL PCG_ST_* of this step for every env.  An env whose adaptive
-                                            integration fails gets a NaN state (never a silently wrong one)
-                                            whether or not this buffer is given                         */
+  uint8_t* status;    /* [B]     in/out|NULL per-env health, STICKY: a step that is not PCG_ST_OK writes its
+                                            PCG_ST_* code, an OK step leaves the entry alone -- the buffer holds "what
+                                            went wrong since the host last cleared it" and costs no traffic while
+                                            nothing does.  An env whose adaptive integration fails gets a NaN state
+                                            (never a silently wrong one) whether or not this buffer is given      */
 } pcg_buffers;
 
 typedef struct pcg_plan pcg_plan; /* opaque */

@@ -118,6 +118,7 @@ class OracleEnv:
         self.episode += 1
         if mask is None:
             self.t = 0
+            self.status[:] = 0
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         lib().orc_reset(C.byref(self.cfg), C.byref(self.buf), _p(self.slots), _p(m), self._seed(), self.env_offset)
         return self.obs

@@ -95,6 +95,29 @@ static void rhs_me(const double* p, const double* x, const double* u, int nu, do
   }
 }
 
+/* The same right-hand side in the KERNEL's operation order (pc-gym_amd/csrc/pcg_models.hpp, MEImpl<true>::rhs:
+ * pre-folded constants 1/Vl, 1/Vg, 1/m, Kla Vl; fused multiply-adds where the kernel has them), for eq_exponent == 2.
+ * This model runs the adaptive pair at its stability limit, where a last-bit difference of one evaluation changes the
+ * step-size sequence a few steps later (tests/helpers.py); with this twin inside the integrator the oracle follows the
+ * kernel bit for bit.  It is pinned to rhs_me() -- the reference's own expression order, itself pinned to the
+ * reference's vectors -- at 4e-16 relative (tests/test_oracle_golden.py); orc_rhs() keeps reporting rhs_me(). */
+static void rhs_me_kernel_order(const double* p, const double* x, const double* u, int nu, double* dx) {
+  double iVl = 1 / p[0], iVg = 1 / p[1], inv_m = 1 / p[2], KlaVl = p[3] * p[0], X0 = p[5], Y6 = p[6];
+  double L = u[0], G = u[1];
+  if (nu != 2) {
+    X0 = u[2];
+    Y6 = u[3];
+  }
+  for (int s = 0; s < 5; ++s) {
+    double X = x[2 * s], Y = x[2 * s + 1];
+    double Xp = (s == 0) ? X0 : x[2 * s - 2];
+    double Yn = (s == 4) ? Y6 : x[2 * s + 3];
+    double Q = KlaVl * fma(-(Y * Y), inv_m, X);
+    dx[2 * s] = iVl * fma(L, Xp - X, -Q);
+    dx[2 * s + 1] = iVg * fma(G, Yn - Y, Q);
+  }
+}
+
 /* model_classes.py:790-845.  p = Vl,Vg,m,Kla,k,eq_exponent,XA0,YA6,YB6,YC6 (:777-786).
  * x = (XA,YA,YB,YC) x 5 stages. */
 static void rhs_me_reactive(const double* p, const double* x, const double* u, int nu, double* dx) {
@@ -366,6 +389,18 @@ static void rhs(const orc_model* m, const double* x, const double* u, double* dx
   }
 }
 
+/* the right-hand side as the INTEGRATORS evaluate it: the reference's expression order, except for the extraction
+ * model with eq_exponent == 2, which uses the kernel-order twin (see rhs_me_kernel_order) unless switched off */
+static int g_me_kernel_order = 1;
+ORC_EXPORT void orc_set_me_kernel_order(int on) { g_me_kernel_order = on; }
+static void rhs_int(const orc_model* m, const double* x, const double* u, double* dx) {
+  if (m->model_id == PCG_MODEL_ME && g_me_kernel_order && m->p[4] == 2.0) rhs_me_kernel_order(m->p, x, u, m->nu, dx);
+  else rhs(m, x, u, dx);
+}
+ORC_EXPORT void orc_rhs_me_kernel_order(const double* p, const double* x, const double* u, int nu, double* dx) {
+  rhs_me_kernel_order(p, x, u, nu, dx);
+}
+
 /* ------------------------------------------------------------------------- */
 /* Integrators over one env step [0,dt], u held constant (integrator.py:163-182:
  * dae = {x, p=u, ode}, t0=0, tf=dt  => zero-order hold)                        */
@@ -377,13 +412,13 @@ static void rk4(const orc_model* m, double* x, const double* u, double dt, int n
   double h = dt / nsub;
   double k1[MAXNX], k2[MAXNX], k3[MAXNX], k4[MAXNX], y[MAXNX];
   for (int s = 0; s < nsub; ++s) {
-    rhs(m, x, u, k1);
+    rhs_int(m, x, u, k1);
     for (int i = 0; i < nx; ++i) y[i] = x[i] + 0.5 * h * k1[i];
-    rhs(m, y, u, k2);
+    rhs_int(m, y, u, k2);
     for (int i = 0; i < nx; ++i) y[i] = x[i] + 0.5 * h * k2[i];
-    rhs(m, y, u, k3);
+    rhs_int(m, y, u, k3);
     for (int i = 0; i < nx; ++i) y[i] = x[i] + h * k3[i];
-    rhs(m, y, u, k4);
+    rhs_int(m, y, u, k4);
     for (int i = 0; i < nx; ++i) x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
   }
 }
@@ -403,6 +438,26 @@ static double rms_scaled(const double* v, const double* y0, const double* y1, in
   }
   return sqrt(s / n);
 }
+
+/* Stage combinations as explicit fused multiply-adds in a fixed order: the twin of lc1..lc6 / axpy in
+ * pc-gym_amd/csrc/pcg_integrators.hpp.  The integrator's arithmetic is an exactly specified sequence of IEEE operations
+ * on both sides (this file is compiled with -ffp-contract=off; fma() is correctly rounded with or without hardware
+ * support), so that the states -- and with them the step-size sequences -- agree bit for bit. */
+static double lc1(double c1, double k1) { return c1 * k1; }
+static double lc2(double c1, double k1, double c2, double k2) { return fma(c2, k2, c1 * k1); }
+static double lc3(double c1, double k1, double c2, double k2, double c3, double k3) { return fma(c3, k3, lc2(c1, k1, c2, k2)); }
+static double lc4(double c1, double k1, double c2, double k2, double c3, double k3, double c4, double k4) {
+  return fma(c4, k4, lc3(c1, k1, c2, k2, c3, k3));
+}
+static double lc5(double c1, double k1, double c2, double k2, double c3, double k3, double c4, double k4, double c5,
+                  double k5) {
+  return fma(c5, k5, lc4(c1, k1, c2, k2, c3, k3, c4, k4));
+}
+static double lc6(double c1, double k1, double c2, double k2, double c3, double k3, double c4, double k4, double c5,
+                  double k5, double c6, double k6) {
+  return fma(c6, k6, lc5(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5));
+}
+static double axpy(double h, double s, double x) { return fma(h, s, x); }
 
 /* Step-size factors are quantised to 6 mantissa bits (truncation) -- part of the controller's specification
  * (DESIGN.md "Adaptive stepping"): the grid makes the step-size sequence independent of how E^(-1/5) is evaluated
@@ -433,7 +488,7 @@ static int dopri5(const orc_model* m, double* x, const double* u, double dt, dou
   double k1[MAXNX], k2[MAXNX], k3[MAXNX], k4[MAXNX], k5[MAXNX], k6[MAXNX], k7[MAXNX];
   double y[MAXNX], ynew[MAXNX], err[MAXNX];
   int acc = 0, rej = 0;
-  rhs(m, x, u, k1);
+  rhs_int(m, x, u, k1);
   /* initial step (Hairer, Norsett & Wanner II.4) */
   double h;
   {
@@ -441,8 +496,8 @@ static int dopri5(const orc_model* m, double* x, const double* u, double dt, dou
     double d1 = rms_scaled(k1, x, x, nx, rtol, atol);
     double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
     if (h0 > dt) h0 = dt;
-    for (int i = 0; i < nx; ++i) y[i] = x[i] + h0 * k1[i];
-    rhs(m, y, u, k2);
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h0, k1[i], x[i]);
+    rhs_int(m, y, u, k2);
     for (int i = 0; i < nx; ++i) err[i] = k2[i] - k1[i];
     double d2 = rms_scaled(err, x, x, nx, rtol, atol) / h0;
     double dm = d1 > d2 ? d1 : d2;
@@ -457,22 +512,22 @@ static int dopri5(const orc_model* m, double* x, const double* u, double dt, dou
     int last = 0;
     if (acc + rej >= max_steps) { status = 1; break; }
     if (t + h >= dt * (1.0 - 1e-14)) { h = dt - t; last = 1; }
-    for (int i = 0; i < nx; ++i) y[i] = x[i] + h * (a21 * k1[i]);
-    rhs(m, y, u, k2);
-    for (int i = 0; i < nx; ++i) y[i] = x[i] + h * (a31 * k1[i] + a32 * k2[i]);
-    rhs(m, y, u, k3);
-    for (int i = 0; i < nx; ++i) y[i] = x[i] + h * (a41 * k1[i] + a42 * k2[i] + a43 * k3[i]);
-    rhs(m, y, u, k4);
-    for (int i = 0; i < nx; ++i) y[i] = x[i] + h * (a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i]);
-    rhs(m, y, u, k5);
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc1(a21, k1[i]), x[i]);
+    rhs_int(m, y, u, k2);
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc2(a31, k1[i], a32, k2[i]), x[i]);
+    rhs_int(m, y, u, k3);
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc3(a41, k1[i], a42, k2[i], a43, k3[i]), x[i]);
+    rhs_int(m, y, u, k4);
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc4(a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]), x[i]);
+    rhs_int(m, y, u, k5);
     for (int i = 0; i < nx; ++i)
-      y[i] = x[i] + h * (a61 * k1[i] + a62 * k2[i] + a63 * k3[i] + a64 * k4[i] + a65 * k5[i]);
-    rhs(m, y, u, k6);
+      y[i] = axpy(h, lc5(a61, k1[i], a62, k2[i], a63, k3[i], a64, k4[i], a65, k5[i]), x[i]);
+    rhs_int(m, y, u, k6);
     for (int i = 0; i < nx; ++i)
-      ynew[i] = x[i] + h * (b1 * k1[i] + b3 * k3[i] + b4 * k4[i] + b5 * k5[i] + b6 * k6[i]);
-    rhs(m, ynew, u, k7);
+      ynew[i] = axpy(h, lc5(b1, k1[i], b3, k3[i], b4, k4[i], b5, k5[i], b6, k6[i]), x[i]);
+    rhs_int(m, ynew, u, k7);
     for (int i = 0; i < nx; ++i)
-      err[i] = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * k7[i]);
+      err[i] = h * lc6(e1, k1[i], e3, k3[i], e4, k4[i], e5, k5[i], e6, k6[i], e7, k7[i]);
     double E = rms_scaled(err, x, ynew, nx, rtol, atol);
     if (E < 1.0) {
       double f = (E == 0.0) ? 10.0 : fmin(10.0, fmax(0.2, qtrunc6(0.9 * pow(E, -0.2))));
@@ -920,7 +975,7 @@ ORC_EXPORT int orc_step(const pcg_env_cfg* c, const pcg_buffers* io, double* slo
     io->rew[b] = o.rew;
     io->done[b] = o.done;
     if (io->viol) io->viol[b] = o.viol;
-    if (io->status) io->status[b] = o.status;
+    if (io->status && o.status) io->status[b] = o.status; /* sticky, like the kernels: only failures are written */
     if (io->g)
       for (int i = 0; i < ncon; ++i) io->g[(size_t)i * B + b] = g[i];
     if (io->g_pre && t_old == 0)

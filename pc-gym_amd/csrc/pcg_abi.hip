@@ -195,15 +195,8 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   const bool norm_a = c->flags & PCG_F_NORMALISE_A, norm_o = c->flags & PCG_F_NORMALISE_O;
   const bool compat = c->flags & PCG_F_REF_COMPAT;
   for (int i = 0; i < na; ++i) {
-    const double lo = c->a_low[i], hs = (c->a_high[i] - c->a_low[i]) / 2;
-    if (!norm_a) {
-      d->amap[i] = AMap{0, 1, 0};
-    } else if ((c->flags & PCG_F_A_DELTA) && compat) {
-      // Q1 (pcgym.py:372-379): f(f(a)), f(a) = (a+1)*hs + lo
-      d->amap[i] = AMap{1, hs * hs, (lo + 1) * hs + lo};
-    } else {
-      d->amap[i] = AMap{1, hs, lo};
-    }
+    d->a_lo[i] = c->a_low[i];
+    d->a_hi[i] = c->a_high[i];
     if (c->flags & PCG_F_A_DELTA) {
       d->a_act_lo[i] = c->a_act_low[i]; d->a_act_hi[i] = c->a_act_high[i]; d->a_0[i] = c->a_0[i];
     }
@@ -598,7 +591,6 @@ int64_t pcg_plan_bytes_per_env_step(const pcg_plan* p, const pcg_buffers* io) {
   if ((c.flags & PCG_F_A_DELTA) && io->a_save) A += 16 * c.na;
   if ((c.flags & PCG_F_REWARD_TRACK) && io->u_prev) A += 16 * c.na;
   if (io->nsteps) A += 8;
-  if (io->status) A += 1;
   A += 16 * c.nunc;  // per-env parameters read + their observation slots written
   return A;
 }
@@ -793,7 +785,8 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   const bool lean_ar_ok = !auto_reset || ((p->variant == 4 || p->variant == 0) && p->integrator_id == PCG_INT_RK4 && k.pipe[0]);
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto al2 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 1u) == 0; };
-  if (!per_env_t && !extras && !lds_st && !io->viol && !io->status && p->variant != 1 && stream_ok && lean_ar_ok &&
+  const bool pipe_ok = (p->variant == 4 || p->variant == 0) && p->integrator_id == PCG_INT_RK4 && k.pipe[0];
+  if (!per_env_t && !extras && !lds_st && !io->viol && (!io->status || pipe_ok) && p->variant != 1 && stream_ok && lean_ar_ok &&
       k.stream[p->integrator_id][0]) {
     const bool epl2_ok = k.stream[p->integrator_id][1] && (io->B % 2 == 0) && al16(io->x) && al16(io->a) &&
                          al16(io->obs) && al16(io->rew) && al2(io->done);

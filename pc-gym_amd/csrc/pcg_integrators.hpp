@@ -94,6 +94,31 @@ PCG_DEV double ctrl_pow(double E2, double scale) {
   return qtrunc6(f);
 }
 
+// Linear combinations of stage derivatives as EXPLICIT fused multiply-adds in a fixed order.  The functions that use
+// them switch compiler contraction off (#pragma clang fp contract(off)), so the arithmetic that feeds back into the
+// state -- stage points, the new solution, the step size -- is one exactly specified sequence of IEEE operations:
+// every kernel that integrates an env (classic, work-queue, fused rollout) produces the same bits, and the oracle
+// (C fma()) can follow it bit for bit.  That matters for the stability-limited extraction model, whose step-size
+// sequence amplifies a last-bit difference into a different (equally valid) sequence (tests/helpers.py).
+PCG_DEV double lc1(double c1, double k1) { return c1 * k1; }
+PCG_DEV double lc2(double c1, double k1, double c2, double k2) { return __builtin_fma(c2, k2, c1 * k1); }
+PCG_DEV double lc3(double c1, double k1, double c2, double k2, double c3, double k3) {
+  return __builtin_fma(c3, k3, lc2(c1, k1, c2, k2));
+}
+PCG_DEV double lc4(double c1, double k1, double c2, double k2, double c3, double k3, double c4, double k4) {
+  return __builtin_fma(c4, k4, lc3(c1, k1, c2, k2, c3, k3));
+}
+PCG_DEV double lc5(double c1, double k1, double c2, double k2, double c3, double k3, double c4, double k4, double c5,
+                   double k5) {
+  return __builtin_fma(c5, k5, lc4(c1, k1, c2, k2, c3, k3, c4, k4));
+}
+PCG_DEV double lc6(double c1, double k1, double c2, double k2, double c3, double k3, double c4, double k4, double c5,
+                   double k5, double c6, double k6) {
+  return __builtin_fma(c6, k6, lc5(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5));
+}
+// x + h * s
+PCG_DEV double axpy(double h, double s, double x) { return __builtin_fma(h, s, x); }
+
 // mean square of v_i / (atol + rtol max(|y0_i|, |y1_i|))  (the RMS norm squared)
 template <int NX>
 PCG_DEV double ms_scaled(const double (&v)[NX], const double (&y0)[NX], const double (&y1)[NX], int n,
@@ -117,6 +142,7 @@ PCG_DEV double rms_scaled(const double (&v)[NX], const double (&y0)[NX], const d
 template <int NX, class F, class ST>
 PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double rtol, double atol,
                    int max_steps, int& nacc, int& nrej) {
+#pragma clang fp contract(off)
   constexpr double a21 = 1.0 / 5;
   constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
   constexpr double a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9;
@@ -140,7 +166,7 @@ PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double 
     double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
     h0 = fmin(h0, dt);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) y[i] = x[i] + h0 * kk[i];
+    for (int i = 0; i < NX; ++i) y[i] = axpy(h0, kk[i], x[i]);
     f(y, w);
 #pragma unroll
     for (int i = 0; i < NX; ++i) w[i] -= kk[i];
@@ -162,43 +188,41 @@ PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double 
       last = true;
     }
 #pragma unroll
-    for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (a21 * K.get(0, i));
+    for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc1(a21, K.get(0, i)), x[i]);
     f(y, kk);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       K.set(1, i, kk[i]);
-      y[i] = x[i] + h * (a31 * K.get(0, i) + a32 * kk[i]);
+      y[i] = axpy(h, lc2(a31, K.get(0, i), a32, kk[i]), x[i]);
     }
     f(y, kk);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       K.set(2, i, kk[i]);
-      y[i] = x[i] + h * (a41 * K.get(0, i) + a42 * K.get(1, i) + a43 * kk[i]);
+      y[i] = axpy(h, lc3(a41, K.get(0, i), a42, K.get(1, i), a43, kk[i]), x[i]);
     }
     f(y, kk);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       K.set(3, i, kk[i]);
-      y[i] = x[i] + h * (a51 * K.get(0, i) + a52 * K.get(1, i) + a53 * K.get(2, i) + a54 * kk[i]);
+      y[i] = axpy(h, lc4(a51, K.get(0, i), a52, K.get(1, i), a53, K.get(2, i), a54, kk[i]), x[i]);
     }
     f(y, kk);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       K.set(4, i, kk[i]);
-      y[i] = x[i] + h * (a61 * K.get(0, i) + a62 * K.get(1, i) + a63 * K.get(2, i) + a64 * K.get(3, i) +
-                         a65 * kk[i]);
+      y[i] = axpy(h, lc5(a61, K.get(0, i), a62, K.get(1, i), a63, K.get(2, i), a64, K.get(3, i), a65, kk[i]), x[i]);
     }
     f(y, kk);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       K.set(5, i, kk[i]);
-      y[i] = x[i] + h * (b1 * K.get(0, i) + b3 * K.get(2, i) + b4 * K.get(3, i) + b5 * K.get(4, i) + b6 * kk[i]);
+      y[i] = axpy(h, lc5(b1, K.get(0, i), b3, K.get(2, i), b4, K.get(3, i), b5, K.get(4, i), b6, kk[i]), x[i]);
     }
     f(y, kk);  // k7 at the 5th-order solution (FSAL)
 #pragma unroll
     for (int i = 0; i < NX; ++i)
-      w[i] = h * (e1 * K.get(0, i) + e3 * K.get(2, i) + e4 * K.get(3, i) + e5 * K.get(4, i) +
-                  e6 * K.get(5, i) + e7 * kk[i]);
+      w[i] = h * lc6(e1, K.get(0, i), e3, K.get(2, i), e4, K.get(3, i), e5, K.get(4, i), e6, K.get(5, i), e7, kk[i]);
     const double E2 = ms_scaled<NX>(w, x, y, n, rtol, atol);  // accept iff E = sqrt(E2) < 1
     if (E2 < 1.0) {
       double fac = fmin(10.0, fmax(0.2, ctrl_pow(E2, 0.9)));

@@ -66,9 +66,6 @@ constexpr int CON_W = PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + KNU; // padded co
 // maps are interleaved per row, so the compiler can fetch them with a few wide s_load_dwordx8/x16
 // instead of ~50 separate 8-byte scalar loads (the scalar cache is shared by several CUs and every
 // wave of the grid replays this prologue).
-struct AMap {
-  double pre, scale, off;  // act = (a + pre) * scale + off      (folds pcgym.py:372-379)
-};
 struct OMap {
   double lo, sc, off;      // obs = (o - lo) * sc + off          (pcgym.py:483-498; mask -> sc=off=0)
 };
@@ -79,7 +76,7 @@ struct DevConst {
   int32_t nx, na, ndm, nd, nsp, nsp_obs, ncon, nrew, N, substeps, max_steps, nobs, has_x0_unc, nunc;
   int32_t sp_index[PCG_MAX_NSP], d_slot[PCG_MAX_NDM];
   double kp[16];                      // model KP (pcg_models.hpp) of the five built-in models
-  AMap amap[PCG_MAX_NA];
+  double a_lo[PCG_MAX_NA], a_hi[PCG_MAX_NA];  // a_space: action_map() (pcgym.py:372-379)
   double r_scale[PCG_MAX_NX];
   double d_default[PCG_MAX_NDM];
   OMap omap[PCG_MAX_NOBS];
@@ -454,6 +451,27 @@ PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const do
   return finite_status<NX>(status, x, nx);
 }
 
+// Action map of make_env.step (pcgym.py:371-379) for one action component, in the reference's own operation order and
+// without compiler contraction: (a + 1) (high - low) / 2 + low, applied twice under quirk Q1 (a_delta with
+// reference_compat).  Every kernel -- classic, work-queue, streaming, feature-masked, fused rollout -- goes through
+// this one function, so the held input is the same bits everywhere, and the same bits as the oracle's.  (Round 1
+// folded the map into one FMA per action; the two extra flops are invisible next to an RK step, and a last-bit
+// difference of the input is what the stability-limited adaptive case cannot tolerate: tests/helpers.py.)
+PCG_DEV double action_map(double a, double lo, double hi, bool norm, bool twice) {
+#pragma clang fp contract(off)
+  double av = a;
+  if (norm) av = (av + 1.0) * (hi - lo) * 0.5 + lo;
+  if (twice) av = (av + 1.0) * (hi - lo) * 0.5 + lo;
+  return av;
+}
+template <int W>
+PCG_DEV Pack<W> action_map(const Pack<W>& a, double lo, double hi, bool norm, bool twice) {
+  Pack<W> r;
+#pragma unroll
+  for (int j = 0; j < W; ++j) r.v[j] = action_map(a.v[j], lo, hi, norm, twice);
+  return r;
+}
+
 // What the pre-integration half of a step hands to the post-integration half (registers in the classic kernel,
 // partly LDS in the work-queue kernel): the held input vector, the disturbance slots, the t == 0 verdict.
 template <class M>
@@ -467,6 +485,7 @@ struct EnvPre {
 template <class M, bool PER_ENV_T, bool EXTRAS>
 PCG_DEV void env_pre(const StepArgs& A, CDevConst& c, const double* sched_l, int64_t e, int t,
                      const double (&a_in)[M::NA], const double (&x)[M::NX], EnvPre<M>& pre) {
+#pragma clang fp contract(off)
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
   const int64_t B = A.B;
   const uint32_t flags = c.flags;
@@ -477,12 +496,13 @@ PCG_DEV void env_pre(const StepArgs& A, CDevConst& c, const double* sched_l, int
   const uint64_t env_id = (uint64_t)(A.env_offset + e);
   double (&u)[NA + NDM] = pre.u;
   double (&dv)[PCG_MAX_NDM] = pre.dv;
-  // ---- action map (pcgym.py:371-383) ----
+  // ---- action map (pcgym.py:371-383): action_map(), bit-identical to the oracle's held input ----
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     double av = 0.0;
     if (i < na) {
-      av = (a_in[i] + c.amap[i].pre) * c.amap[i].scale + c.amap[i].off;
+      av = action_map(a_in[i], c.a_lo[i], c.a_hi[i], (flags & PCG_F_NORMALISE_A) != 0,
+                      (flags & PCG_F_A_DELTA) && (flags & PCG_F_REF_COMPAT));
       if (EXTRAS && (flags & PCG_F_A_DELTA)) {
         av = A.a_save[(size_t)i * B + e] + av;  // Q2: the unclipped sum drives the plant
         A.a_save[(size_t)i * B + e] = fmin(fmax(av, c.a_act_lo[i]), c.a_act_hi[i]);
@@ -749,7 +769,7 @@ PCG_DEV void store_out(const StepArgs& A, CDevConst& c, int64_t e, const EnvOut<
   __builtin_nontemporal_store(out.rew, A.rew + e);
   A.done[e] = out.done ? 1 : 0;
   if (A.viol) A.viol[e] = out.viol ? 1 : 0;
-  if (A.status) A.status[e] = out.status;
+  if (A.status && out.status != PCG_ST_OK) A.status[e] = out.status;  // sticky: only failures are written
 }
 
 // cooperative copy of the schedules into LDS (per-env-t kernels)
@@ -788,7 +808,7 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG), wpe(M::NX, INTEG, LDS_STAGES
     __builtin_nontemporal_store(out.rew, A.rew + e);
     A.done[e] = 1;
     if (A.viol) A.viol[e] = out.viol ? 1 : 0;
-    if (A.status) A.status[e] = out.status;
+    if (A.status && out.status != PCG_ST_OK) A.status[e] = out.status;  // sticky: only failures are written
     reset_env(A, c, e, A.reset_seed);
     return;
   }
@@ -850,7 +870,7 @@ PCG_DEV void env_step_lean(const StepArgs& A, CDevConst& c, int t, const Pack<W>
   R u[NA + NDM];
 #pragma unroll
   for (int i = 0; i < NA; ++i)
-    u[i] = (i < na) ? (a_in[i] + c.amap[i].pre) * c.amap[i].scale + c.amap[i].off : R(0.0);
+    u[i] = (i < na) ? action_map(a_in[i], c.a_lo[i], c.a_hi[i], (c.flags & PCG_F_NORMALISE_A) != 0, false) : R(0.0);
   double ud[NDM > 0 ? NDM : 1];
 #pragma unroll
   for (int j = 0; j < NDM; ++j) ud[j] = c.d_default[j];
@@ -1196,6 +1216,15 @@ __global__ __launch_bounds__(BLOCK, PCG_LEAN_WPE) void step_kernel_pipe(const St
         for (int j = 0; j < EPL; ++j) as[i].v[j] = (i < na) ? Vec<EPL>::get(av[i], j) : 0.0;
       LeanOut<M, EPL> out;
       env_step_lean<M, EPL>(A, c, t, as, xs, out);
+      if (A.status) {  // per-env health: fixed-step RK4 can only leave a non-finite state; only failures are written
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+          bool ok = true;
+#pragma unroll
+          for (int i = 0; i < NX; ++i) ok = ok && (__builtin_fabs(xs[i].v[j]) < __builtin_inf());
+          if (!ok) A.status[e0 + j] = PCG_ST_NONFINITE;
+        }
+      }
       if (AR && A.auto_reset && out.done) {
         // last step of a lock-stepped episode with same-launch auto-reset: reward / done of the finished step,
         // then the new episode's state and observation instead of the terminal ones (pcg_step_autoreset)

@@ -91,6 +91,23 @@ PCG_PACK_FN1(sqrt)
 PCG_PACK_FN1(fabs)
 #undef PCG_PACK_FN1
 
+// explicit fused multiply-add for both value types (model code whose rounding is part of a bit-exact contract)
+PCG_PK double pk_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <int W>
+PCG_PK Pack<W> pk_fma(const Pack<W>& a, const Pack<W>& b, const Pack<W>& c) {
+  Pack<W> r;
+#pragma unroll
+  for (int i = 0; i < W; ++i) r.v[i] = __builtin_fma(a.v[i], b.v[i], c.v[i]);
+  return r;
+}
+template <int W>
+PCG_PK Pack<W> pk_fma(const Pack<W>& a, double b, const Pack<W>& c) {
+  Pack<W> r;
+#pragma unroll
+  for (int i = 0; i < W; ++i) r.v[i] = __builtin_fma(a.v[i], b, c.v[i]);
+  return r;
+}
+
 // ---- fast fp64 helpers for arguments of known range (no special-case handling) -------------------
 // 1/x: hardware estimate + two Newton steps, ~1 ulp; x finite, normal, non-zero.  6 VALU instructions
 // against 11 for the IEEE divide sequence (div_scale x2, rcp, 5 fma, div_fmas, div_fixup).

@@ -139,7 +139,8 @@ PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, int64_t e0, int t, c
   R u[NA + NDM];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    R av = (a_in[i] + c.amap[i].pre) * c.amap[i].scale + c.amap[i].off;
+    R av = action_map(a_in[i], c.a_lo[i], c.a_hi[i], (flags & PCG_F_NORMALISE_A) != 0,
+                      (flags & PCG_F_A_DELTA) && (flags & PCG_F_REF_COMPAT));
     if constexpr (ADELTA) {
       if (flags & PCG_F_A_DELTA) {
         av = asave_in[i] + av;  // Q2: the unclipped sum drives the plant
@@ -394,7 +395,11 @@ PCG_DEV void store_feat(const StepArgs& A, CDevConst& c, int64_t e0, const Pack<
   }
   store8(A.done, bd);
   if (A.viol) store8(A.viol, bv);
-  if (A.status) store8(A.status, out.status);
+  if (A.status) {  // sticky: only failures are written
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+      if (out.status[j] != PCG_ST_OK) A.status[e0 + j] = out.status[j];
+  }
   if constexpr ((FT & FT_ADELTA) != 0) {
     if (c.flags & PCG_F_A_DELTA) {
 #pragma unroll

@@ -55,6 +55,7 @@ struct DpLane {
 template <int NX, class F>
 PCG_DEV double dopri5_h_init(const F& f, const double (&x)[NX], double (&k1)[NX], int n, double dt, double rtol,
                              double atol) {
+#pragma clang fp contract(off)
   double y[NX], w[NX];
   f(x, k1);
   const double d0 = rms_scaled<NX>(x, x, x, n, rtol, atol);
@@ -62,7 +63,7 @@ PCG_DEV double dopri5_h_init(const F& f, const double (&x)[NX], double (&k1)[NX]
   double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
   h0 = fmin(h0, dt);
 #pragma unroll
-  for (int i = 0; i < NX; ++i) y[i] = x[i] + h0 * k1[i];
+  for (int i = 0; i < NX; ++i) y[i] = axpy(h0, k1[i], x[i]);
   f(y, w);
 #pragma unroll
   for (int i = 0; i < NX; ++i) w[i] -= k1[i];
@@ -77,6 +78,7 @@ PCG_DEV double dopri5_h_init(const F& f, const double (&x)[NX], double (&k1)[NX]
 template <int NX, class F>
 PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double dt_edge, double h_floor, double rtol,
                            double atol, int max_steps) {
+#pragma clang fp contract(off)
   constexpr double a21 = 1.0 / 5;
   constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
   constexpr double a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9;
@@ -97,29 +99,29 @@ PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double d
   const double (&x)[NX] = L.x;
   const double (&k1)[NX] = L.k1;
 #pragma unroll
-  for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (a21 * k1[i]);
+  for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc1(a21, k1[i]), x[i]);
   f(y, k2);
 #pragma unroll
-  for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (a31 * k1[i] + a32 * k2[i]);
+  for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc2(a31, k1[i], a32, k2[i]), x[i]);
   f(y, k3);
 #pragma unroll
-  for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (a41 * k1[i] + a42 * k2[i] + a43 * k3[i]);
+  for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc3(a41, k1[i], a42, k2[i], a43, k3[i]), x[i]);
   f(y, k4);
 #pragma unroll
-  for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i]);
+  for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc4(a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]), x[i]);
   f(y, k5);
 #pragma unroll
   for (int i = 0; i < NX; ++i)
-    y[i] = x[i] + h * (a61 * k1[i] + a62 * k2[i] + a63 * k3[i] + a64 * k4[i] + a65 * k5[i]);
+    y[i] = axpy(h, lc5(a61, k1[i], a62, k2[i], a63, k3[i], a64, k4[i], a65, k5[i]), x[i]);
   f(y, k6);
 #pragma unroll
-  for (int i = 0; i < NX; ++i) y[i] = x[i] + h * (b1 * k1[i] + b3 * k3[i] + b4 * k4[i] + b5 * k5[i] + b6 * k6[i]);
+  for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc5(b1, k1[i], b3, k3[i], b4, k4[i], b5, k5[i], b6, k6[i]), x[i]);
   f(y, kk);  // k7 at the 5th-order solution (FSAL)
   // error estimate and its scaled mean square in one pass (ms_scaled() without the intermediate vector)
   double E2 = 0.0;
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    const double wi = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * kk[i]);
+    const double wi = h * lc6(e1, k1[i], e3, k3[i], e4, k4[i], e5, k5[i], e6, k6[i], e7, kk[i]);
     const double sc = atol + rtol * fmax(fabs(x[i]), fabs(y[i]));
     const double r = wi * fast_rcp(sc);  // sc > 0
     E2 += (i < n) ? r * r : 0.0;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
         __builtin_nontemporal_store(out.rew, A.rew + e);
         A.done[e] = 1;
         if (A.viol) A.viol[e] = out.viol ? 1 : 0;
-        if (A.status) A.status[e] = out.status;
+        if (A.status && out.status != PCG_ST_OK) A.status[e] = out.status;
         reset_env(A, c, e, A.reset_seed);
         continue;
       }

@@ -44,9 +44,10 @@ class VecEnv:
                              auto-reset when episodes can end at different times)
     auto_reset : bool        reset finished envs inside step() (gymnasium "same-step" mode)
     env_offset : int         global index of env 0 (multi-GPU sharding: keeps RNG streams disjoint)
-    track_status : bool      keep a per-env health byte of every step (``env.status``: 0 ok, 1 DOPRI5 step budget
-                             exhausted, 2 step-size underflow, 3 non-finite state -- include/pcgym_hip.h PCG_ST_*);
-                             an env whose adaptive integration fails gets a NaN state either way
+    track_status : bool      keep a per-env health byte (``env.status``: 0 ok, 1 DOPRI5 step budget exhausted, 2 step-size
+                             underflow, 3 non-finite state -- include/pcgym_hip.h PCG_ST_*).  Sticky: only failures
+                             are written, reset() (or ``env.status.zero_()``) clears; an env whose adaptive
+                             integration fails gets a NaN state either way
     """
 
     def __init__(self, env_params, n_envs=1, device=None, seed=0, per_env_t=False, auto_reset=False,
@@ -186,6 +187,8 @@ class VecEnv:
             mptr = mask.data_ptr()
         else:
             self.t = 0
+            if self.status is not None:
+                self.status.zero_()  # the health bytes are sticky: a full reset opens a fresh window
         _lib.check(self._lib.pcg_reset(self._plan, self._bufp, mptr, self._episode_seed(), self._stream()),
                    "pcg_reset")
         return self.obs, {}

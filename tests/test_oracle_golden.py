@@ -188,6 +188,23 @@ def test_full_step_tuples_match_reference(name):
     assert np.allclose(env.x[:, 0], g["state"][T][: s.nx], rtol=2e-9)
 
 
+def test_extraction_rhs_kernel_order_twin_is_pinned_to_the_reference_vectors():
+    """the integrators evaluate the 10-state extraction model through rhs_me_kernel_order (the kernel's operation
+    order, so that the adaptive path is bit-identical on both sides); it must agree with the reference's own vectors
+    like the reference-order restatement does"""
+    import ctypes as C
+
+    l = O.lib()
+    l.orc_rhs_me_kernel_order.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
+    g = H.gold("rhs_multistage_extraction")
+    p = np.array([5, 5, 1, 5, 2, 0.6, 0.05], dtype=np.float64)
+    for k in range(g["x"].shape[0]):
+        xi, ui, out = np.ascontiguousarray(g["x"][k]), np.ascontiguousarray(g["u"][k]), np.zeros(10)
+        l.orc_rhs_me_kernel_order(p.ctypes.data, xi.ctypes.data, ui.ctypes.data, ui.shape[0], out.ctypes.data)
+        want = g["dx"][k]
+        assert np.all(np.abs(out - want) <= 2e-14 * np.maximum(np.abs(want), 1e-3 * np.abs(want).max()))
+
+
 def test_philox_known_answers():
     """Random123 kat_vectors for philox4x32-10."""
     assert O.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
