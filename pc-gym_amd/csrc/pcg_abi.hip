@@ -818,15 +818,15 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   // covers what this launch uses is taken.  PCG_OPT_VARIANT 1 forces the classic one-env-per-lane kernel (A/B).
   if (p->integrator_id == PCG_INT_RK4 && k.nfeat > 0 && !lds_st && (p->variant == 0 || p->variant == 4)) {
     unsigned need = 0;
-    if (c.flags & PCG_F_NOISE) need |= FT_NOISE;
     if (c.ncon > 0) need |= FT_CONS;
     if (c.flags & PCG_F_A_DELTA) need |= FT_ADELTA;
     if (c.flags & PCG_F_REWARD_TRACK) need |= FT_TRACK;
     if (c.flags & PCG_F_REWARD_BATCH) need |= FT_BATCH;
     if (auto_reset) need |= FT_AR;
-    // per-env step counters, per-env / Gaussian disturbances: the classic kernel is the faster one (measured), and a
+    // observation noise, per-env step counters, per-env / Gaussian disturbances: the classic kernel is the faster one
+    // (measured), and a
     // lock-stepped same-launch reset needs every env to end together
-    bool ok = !per_env_t && !io->d && !((c.flags & PCG_F_GAUSS_DIST) && c.nd > 0) &&
+    bool ok = !per_env_t && !io->d && !(c.flags & PCG_F_NOISE) && !((c.flags & PCG_F_GAUSS_DIST) && c.nd > 0) &&
               !(auto_reset && (c.flags & PCG_F_DONE_ON_CONS) && c.ncon > 0) && (io->B % 2 == 0) && al16(io->x) &&
               al16(io->a) && al16(io->obs) && al16(io->rew) && al2(io->done) && al2(io->viol) && al2(io->status) &&
               al16(io->a_save) && al16(io->u_prev) && al16(io->g) && al16(io->g_pre);

@@ -16,10 +16,11 @@
 //   * feat_table<M>(): the curated list of masks built for a model (the single features, the pairs the paper
 //     configurations use, "everything"); the host picks the smallest superset of what a launch needs.
 //
-// Measured (profiles/r2/extras_probe.txt, cstr B = 2^20): this shape wins for constraint rows (16.4 vs 18.2 us) and
-// observation noise (16.1 vs 16.7), ties for the tracking reward, and LOSES to the classic one-env-per-lane kernel
-// for per-env step counters (16.0 vs 14.9), Gaussian / per-env disturbances (18.0 vs 17.2) -- so those three stay
-// on the classic kernel and are not features here (first cut had them: removed with the data).
+// Measured (profiles/r2/extras_probe*.txt, cstr B = 2^20, two boxes): this shape wins for constraint rows (15.7 vs 18.3
+// and 17.5 vs 18.6 us), ties or wins for the tracking reward (16.0 vs 17.4, 16.9 vs 16.9), and does NOT beat the classic
+// one-env-per-lane kernel for observation noise (16.1 vs 16.5 on one box, 17.4 vs 16.8 on the other; with tracking
+// 19.3-20.3 vs 18.9), per-env step counters (16.0 vs 14.9) and Gaussian / per-env disturbances (18.0 vs 17.2) -- so
+// those stay on the classic kernel and are not features here (the first cuts had them: removed with the data).
 //
 // Statement order follows make_env.step (reference src/pcgym/pcgym.py:350-500) exactly as env_step does; both are
 // checked against the same oracle recordings.  Only RK4 plans of the small HBM-bound models (NX <= 4) come here:
@@ -29,13 +30,12 @@
 namespace pcg {
 
 enum : unsigned {
-  FT_NOISE = 1u,    // PCG_F_NOISE                      pcgym.py:453-466
   FT_CONS = 4u,     // constraint rows, penalty, done-on-violation   pcgym.py:414-420, 443-446, 560-615
   FT_ADELTA = 8u,   // PCG_F_A_DELTA                    pcgym.py:376-383
   FT_TRACK = 16u,   // PCG_F_REWARD_TRACK               pc-gym_paper/.../custom_reward.py
   FT_BATCH = 32u,   // PCG_F_REWARD_BATCH               pcgym.py:502-532
   FT_AR = 256u,     // same-launch auto-reset of a lock-stepped batch (pcg_step_autoreset)
-  FT_ALL = FT_NOISE | FT_CONS | FT_ADELTA | FT_TRACK | FT_BATCH | FT_AR
+  FT_ALL = FT_CONS | FT_ADELTA | FT_TRACK | FT_BATCH | FT_AR
 };
 
 template <int W>
@@ -126,7 +126,7 @@ PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, int64_t e0, int t, c
                            FeatOut<M, W>& out) {
   static_assert(!M::DYNAMIC, "the feature kernels are built for the fixed-size models");
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM, ND = FeatOut<M, W>::ND;
-  constexpr bool NOISE = FT & FT_NOISE, CONS = FT & FT_CONS, ADELTA = FT & FT_ADELTA, TRACK = FT & FT_TRACK,
+  constexpr bool CONS = FT & FT_CONS, ADELTA = FT & FT_ADELTA, TRACK = FT & FT_TRACK,
                  BATCH = FT & FT_BATCH, AR = FT & FT_AR;
   using R = Pack<W>;
   const int64_t B = A.B;
@@ -240,23 +240,11 @@ PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, int64_t e0, int t, c
         }
       }
   }
-  // ---- observation: noise (pcgym.py:452-466), normalise (:483-489), mask (:495-498) ----
+  // ---- observation (no noise on this shape: measured slower than the classic kernel): normalise (pcgym.py:483-489),
+  //      mask (:495-498) ----
   R on[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) on[i] = x[i];
-  if constexpr (NOISE) {
-    if (flags & PCG_F_NOISE) {
-#pragma unroll
-      for (int i = 0; i < NX; i += 2)
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          double z0, z1;
-          rng_normal2(A.seed, (uint64_t)(A.env_offset + e0 + j), (uint32_t)t, RNG_NOISE + (uint32_t)(i >> 1), z0, z1);
-          on[i].v[j] += z0 * x[i].v[j] * c.noise_pct[i];
-          if (i + 1 < NX) on[i + 1].v[j] += z1 * x[i + 1].v[j] * c.noise_pct[i + 1];
-        }
-    }
-  }
 #pragma unroll
   for (int i = 0; i < NX; ++i) out.ox[i] = (on[i] - c.omap[i].lo) * c.omap[i].sc + c.omap[i].off;
   if constexpr (TRACK) {
@@ -498,9 +486,9 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel_feat(const StepArgs A) {
   }
 }
 
-// The masks built for every small model: each single feature, the combinations the reference's paper
-// configurations use (noise + tracking reward; noise + constraints; all three), the auto-reset launch of a
-// lock-stepped episode, and "everything".  Mask 0 is the lean step with the viol / status outputs.
+// The masks built for every small model: the single features, constraints + tracking (the constraint-showcase
+// configuration), the auto-reset launch of a lock-stepped episode, and "everything".  Mask 0 is the lean step with
+// the `viol` output.
 template <class M>
 inline int feat_table(FeatEntry* out, int cap) {
   int n = 0;
@@ -509,12 +497,9 @@ inline int feat_table(FeatEntry* out, int cap) {
   };
   add(0u, step_kernel_feat<M, 2, 0u>);
   add(FT_AR, step_kernel_feat<M, 2, FT_AR>);
-  add(FT_NOISE, step_kernel_feat<M, 2, FT_NOISE>);
   add(FT_CONS, step_kernel_feat<M, 2, FT_CONS>);
   add(FT_TRACK, step_kernel_feat<M, 2, FT_TRACK>);
-  add(FT_NOISE | FT_TRACK, step_kernel_feat<M, 2, FT_NOISE | FT_TRACK>);
-  add(FT_NOISE | FT_CONS, step_kernel_feat<M, 2, FT_NOISE | FT_CONS>);
-  add(FT_NOISE | FT_CONS | FT_TRACK, step_kernel_feat<M, 2, FT_NOISE | FT_CONS | FT_TRACK>);
+  add(FT_CONS | FT_TRACK, step_kernel_feat<M, 2, FT_CONS | FT_TRACK>);
   add(FT_ALL, step_kernel_feat<M, 2, FT_ALL>);
   return n;
 }
