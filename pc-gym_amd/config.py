@@ -133,6 +133,8 @@ def compile_expr(text, names, arrays, scalars, what):
         raise ValueError(f"{what}: expression must be a non-empty string")
     if re.search(r"[;{}\\#\"']|//|/\*", text):
         raise ValueError(f"{what}: only a single expression is accepted (no statements, comments or strings): {text!r}")
+    if re.search(r"(?<![=!<>])=(?!=)|\+\+|--", text):
+        raise ValueError(f"{what}: assignments / increments are not accepted: {text!r}")
     out, pos = [], 0
     for m in re.finditer(r"[A-Za-z_][A-Za-z_0-9]*", text):
         out.append(text[pos:m.start()])

@@ -897,7 +897,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
   const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH | PCG_F_REWARD_TRACK)) ||
                       c.ncon > 0 || io->d != nullptr;
-  if (!extras && p->integrator_id == PCG_INT_RK4 && !io->viol && !io->status && p->variant != 1 && k.roll_lean[0]) {
+  if (!extras && p->integrator_id == PCG_INT_RK4 && !io->viol && p->variant != 1 && k.roll_lean[0]) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool ev = ((a.a_ss | a.a_cs | a.o_ss | a.o_cs | a.r_ss) & 1) == 0;  // 16-byte rows stay 16-byte aligned
     const bool e2 = ev && k.roll_lean[1] && (io->B % 2 == 0) && al16(io->x) && al16(a_seq) && al16(io->obs) &&

@@ -1315,6 +1315,15 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel_lean(const StepArgs A) {
         }
     }
   }
+  if (A.status) {  // a non-finite state is absorbing: one check at the end covers the T steps (sticky byte)
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      bool ok = true;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) ok = ok && (__builtin_fabs(xs[i].v[j]) < __builtin_inf());
+      if (!ok) A.status[e0 + j] = PCG_ST_NONFINITE;
+    }
+  }
   // final state and the last step's outputs into the regular per-step buffers
   double tmp[EPL];
 #pragma unroll

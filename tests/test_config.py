@@ -265,3 +265,25 @@ def test_empirical_distribution_parsing_and_oracle_sampling():
     p["empirical_distribution"] = {"x0": [1.0]}
     with pytest.raises(ValueError, match="not supported"):
         EnvSpec(p)
+
+
+def test_c_expression_constraints_and_rewards_are_translated_and_vetted():
+    """the non-affine forms of constraints / custom_reward: C expressions with model names, compiled into the kernel at
+    plan creation -- here only the host side (translation, whitelist); the GPU tests replay reference recordings"""
+    from pcgym_amd.config import compile_expr
+
+    p = P("cstr_expr_reward_q3")
+    s = EnvSpec(p)
+    assert s.ncon == 2 and s.user_cons_src.count("g[") == 2 and "x[1]" in s.user_cons_src
+    assert s.custom_reward is None and "o[0]" in s.user_reward_src and "sp[0]" in s.user_reward_src
+    cfg, keep = s.to_cfg()
+    assert cfg.user_cons_src and cfg.user_reward_src and cfg.jit_include_dir.endswith(b"csrc")
+    assert compile_expr("1e-3*T + 2.5E+2 - Tc", {"T": "x[1]", "Tc": "u[0]"}, {"x", "u"}, set(), "t") == \
+        "1e-3*x[1] + 2.5E+2 - u[0]"
+    for bad in ("system(1)", "T; T", "x[1] /* c */", "__builtin_trap()", "T = 3", ""):
+        with pytest.raises(ValueError):
+            compile_expr(bad, {"T": "x[1]"}, {"x", "u"}, set(), "t")
+    q = P("cstr_expr_cons_raw")
+    q["constraints"] = {"expr": ["T - 330", "nonsense_name"]}
+    with pytest.raises(ValueError):
+        EnvSpec(q)

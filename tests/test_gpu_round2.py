@@ -595,3 +595,33 @@ def test_user_expression_errors_are_reported_not_crashed():
     p["constraints"] = {"expr": ["system(T)"]}
     with pytest.raises(ValueError):
         VecEnv(p, n_envs=8)
+
+
+def test_host_gather_delivers_every_step_in_order():
+    """pcgym_amd.HostGather: device-to-device snapshot + pinned D2H on a second stream, two slots in flight -- every
+    step's obs / rew / done arrives on the host unchanged while the step loop runs ahead"""
+    torch = _torch()
+    import bench as BN
+    from pcgym_amd import HostGather, VecEnv
+
+    B = 1 << 16
+    env = VecEnv(BN.workload_params(), n_envs=B, seed=2, auto_reset=True)
+    ref = VecEnv(BN.workload_params(), n_envs=B, seed=2, auto_reset=True)
+    env.reset()
+    ref.reset()
+    g = HostGather(env)
+    assert g.bytes_per_step == B * (3 * 8 + 8 + 1)
+    gen = torch.Generator(device=env.device).manual_seed(4)
+    acts = 2 * torch.rand((70, 1, B), generator=gen, device=env.device, dtype=torch.float64) - 1
+    pending = []
+    for i in range(70):  # across an episode boundary (59 steps)
+        env.step(acts[i])
+        pending.append((i, g.push()))
+        if len(pending) == 2:  # consume one step late: the loop stays one step ahead of the bus
+            k, slot = pending.pop(0)
+            out = g.wait(slot)
+            ref.step(acts[k])
+            assert torch.equal(out["obs"], ref.obs_soa.cpu()) and torch.equal(out["rew"], ref.rew.cpu()), k
+            assert torch.equal(out["done"], ref.done.cpu()), k
+    env.close()
+    ref.close()

@@ -84,3 +84,47 @@ def test_world_size_2_gloo_sharded_run_equals_single_device_run(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "SHARD_OK" in r.stdout
+
+
+def test_mixed_shard_layout_partitions_every_segment_and_keeps_global_offsets():
+    """BASELINE configs[4] sharding (pcgym_amd.mixed_shard_layout): every rank gets the same fraction of every
+    model segment, offsets follow the global layout [segment 0 | segment 1 | ...]; stepping the shards with the oracle
+    standing in for the device (same env_offset contract) reproduces the unsharded mixed batch bit for bit, Gaussian
+    disturbance streams included."""
+    import copy
+
+    import bench as BN
+    from oracle import oracle as O
+    from pcgym_amd import mixed_shard_layout
+    from pcgym_amd.config import EnvSpec
+
+    sizes = [1001, 700, 333]
+    segs = [(p, n) for (p, _), n in zip(BN.mixed_segments(6), sizes)]
+    for world in (1, 2, 3, 8):
+        lay = [mixed_shard_layout(segs, r, world) for r in range(world)]
+        for k, n in enumerate(sizes):
+            base = sum(sizes[:k])
+            spans = sorted((l[k][2], l[k][2] + l[k][1]) for l in lay)
+            assert spans[0][0] == base and spans[-1][1] == base + n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(s[1] - s[0] for s in spans) - min(s[1] - s[0] for s in spans) <= 1
+    rng = np.random.default_rng(3)
+    T = 3
+    world = 2
+    lay = [mixed_shard_layout(segs, r, world) for r in range(world)]
+    for k, (p, n) in enumerate(segs):
+        spec = EnvSpec(copy.deepcopy(p))
+        base = sum(sizes[:k])
+        full = O.OracleEnv(spec, n, seed=9, env_offset=base)
+        full.reset()
+        parts = [O.OracleEnv(spec, l[k][1], seed=9, env_offset=l[k][2]) for l in lay]
+        for e in parts:
+            e.reset()
+        for i in range(T):
+            a = rng.uniform(-0.5, 1, (spec.na, n))
+            full.step(a)
+            for e, l in zip(parts, lay):
+                lo = l[k][2] - base
+                e.step(a[:, lo:lo + l[k][1]])
+        assert np.array_equal(np.concatenate([e.x for e in parts], axis=1), full.x), spec.model.name
+        assert np.array_equal(np.concatenate([e.obs for e in parts], axis=1), full.obs), spec.model.name
