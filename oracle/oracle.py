@@ -101,7 +101,7 @@ class OracleEnv:
         self.g = np.zeros((s.ncon, B)) if s.ncon else None
         self.g_pre = np.zeros((s.ncon, B)) if s.ncon else None
         self.t_env = np.zeros(B, dtype=np.int32) if per_env_t else None
-        self.nsteps = np.zeros((2, B), dtype=np.int32) if s.integrator == "dopri5" else None
+        self.nsteps = np.zeros((2, B), dtype=np.int32) if s.integrator != "rk4" else None
         b = self.buf = abi.pcg_buffers()
         b.B = B
         b.x, b.obs, b.rew, b.done, b.viol = _p(self.x), _p(self.obs), _p(self.rew), _p(self.done), _p(self.viol)

@@ -40,6 +40,7 @@ PCG_OPT_NT_STORES = 5
 
 PCG_INT_RK4 = 0
 PCG_INT_DOPRI5 = 1
+PCG_INT_RODAS3 = 2
 
 PCG_F_NORMALISE_A = 0x0001
 PCG_F_NORMALISE_O = 0x0002

@@ -7,7 +7,7 @@ Mirrors the parsing done by the reference ``make_env.__init__`` and its
 C ABI.  Nothing numeric about the hot path happens here.
 
 New optional keys (do not exist in the reference):
-  integrator   'rk4' | 'dopri5'   (default per model, see DEFAULT_INTEGRATOR)
+  integrator   'rk4' | 'dopri5' | 'rodas3' (stiff-capable Rosenbrock)   (default per model, see DEFAULT_INTEGRATOR)
   substeps     RK4 sub-steps per env step
   rtol, atol   DOPRI5 tolerances (default 1e-8, integrator.py:61)
   max_steps    DOPRI5 step budget per env step
@@ -523,8 +523,8 @@ class EnvSpec:
         if self.integration_method == "jax":
             d_int = "dopri5"
         self.integrator = p.get("integrator", d_int)
-        if self.integrator not in ("rk4", "dopri5"):
-            raise ValueError("integrator must be 'rk4' or 'dopri5'")
+        if self.integrator not in ("rk4", "dopri5", "rodas3"):
+            raise ValueError("integrator must be 'rk4', 'dopri5' or 'rodas3'")
         d_sub = default_substeps(self.model.model_id, self.dt)
         if self.affine_AB is not None:
             # affine models: keep |A|_inf * h <= 0.05 (RK4 local error ~ (|A| h)^5 / 120)
@@ -633,7 +633,7 @@ class EnvSpec:
         params = self.param_vector()
         cfg = abi.pcg_env_cfg()
         cfg.model_id = self.model.model_id
-        cfg.integrator_id = abi.PCG_INT_RK4 if self.integrator == "rk4" else abi.PCG_INT_DOPRI5
+        cfg.integrator_id = {"rk4": abi.PCG_INT_RK4, "dopri5": abi.PCG_INT_DOPRI5, "rodas3": abi.PCG_INT_RODAS3}[self.integrator]
         cfg.nx, cfg.na, cfg.ndm, cfg.nd = self.nx, self.na, self.ndm, self.nd
         cfg.nsp, cfg.ncon, cfg.nrew, cfg.N = self.nsp, self.ncon, self.nrew, self.N
         cfg.nsp_obs = self.nsp_obs

@@ -173,7 +173,7 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   if (c->N < 2 || c->N > PCG_MAX_N) return PCG_E_DIM;
   if (!(c->dt > 0.0) || !std::isfinite(c->dt)) return PCG_E_VALUE;
   if (c->integrator_id == PCG_INT_RK4 && c->substeps < 0) return PCG_E_VALUE;  // 0 = no integration (I/O probe)
-  if (c->integrator_id == PCG_INT_DOPRI5 && (!(c->rtol > 0) || !(c->atol >= 0) || c->max_steps < 1))
+  if (c->integrator_id != PCG_INT_RK4 && (!(c->rtol > 0) || !(c->atol >= 0) || c->max_steps < 1))
     return PCG_E_VALUE;
   const int nobs = nx + nso + nd + nunc, cnu = na + ndm;
   if (!c->params || !c->x0 || !c->a_low || !c->a_high || !c->o_low || !c->o_high) return PCG_E_NULL;
@@ -710,19 +710,20 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   const bool per_env_t = io->t != nullptr;
   const Kernels& k = kernels(p->kid);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
-  const int block = tb(lds_st, p->integrator_id);
-  size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
+  const int block = tb(lds_st, p->integrator_id, k.nx);
+  size_t shmem = sizeof(double) * integ_lds_doubles(k.nx, p->integrator_id, lds_st);
+  const size_t integ_shmem = shmem;
   if (per_env_t) {
     const size_t sb = sizeof(double) * (size_t)(c.nsp + c.nd) * c.N;
-    if (sb > 0 && shmem + sb <= 64 * 1024) {
+    if (sb > 0 && shmem + sb <= (shmem > 48 * 1024 ? 160 : 64) * 1024) {
       a.sched_in_lds = 1;
       shmem += sb;
     }
   }
   if (p->jit_fn[0]) {  // run-time compiled general kernel with the plan's user expressions
-    if (lds_st) return PCG_E_UNSUPPORTED;
+    if (lds_st || integ_shmem > 48 * 1024) return PCG_E_UNSUPPORTED;
     void* argv[1] = {&a};
-    const size_t sh = (per_env_t && a.sched_in_lds) ? shmem : 0;
+    const size_t sh = (per_env_t && a.sched_in_lds) ? shmem : integ_shmem;
     return (int)hipModuleLaunchKernel(p->jit_fn[per_env_t ? 1 : 0], grid_for(io->B, block), 1, 1, block, 1, 1, (unsigned)sh,
                                       (hipStream_t)stream, argv, nullptr);
   }
@@ -853,6 +854,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
     }
   }
   StepFn fn = k.step[p->integrator_id][per_env_t ? 1 : 0][lds_st ? 1 : 0][extras ? 1 : 0];
+  if (!fn) return PCG_E_UNSUPPORTED;
   if (shmem > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(fn, dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
@@ -910,6 +912,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   const int block = tb(lds_st, p->integrator_id);
   const size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
   StepFn fn = k.rollout[p->integrator_id][lds_st ? 1 : 0];
+  if (!fn) return PCG_E_UNSUPPORTED;  // the Rosenbrock integrator steps through pcg_step only
   if (shmem > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(fn, dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
@@ -1062,9 +1065,10 @@ int pcg_integrate(pcg_plan* p, int64_t B, double* x, const double* u, int32_t* n
   if (B <= 0) return B == 0 ? PCG_OK : PCG_E_DIM;
   const Kernels& k = kernels(p->kid);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
-  const int block = tb(lds_st, p->integrator_id);
-  const size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
+  const int block = tb(lds_st, p->integrator_id, k.nx);
+  const size_t shmem = sizeof(double) * integ_lds_doubles(k.nx, p->integrator_id, lds_st);
   IntKFn fn = k.integ[p->integrator_id][lds_st ? 1 : 0];
+  if (!fn) return PCG_E_UNSUPPORTED;
   if (shmem > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(fn, dim3(grid_for(B, block)), dim3(block), shmem, (hipStream_t)stream, (CDevConst*)p->dC, B, p->cfg_nu, x,

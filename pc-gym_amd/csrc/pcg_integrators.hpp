@@ -86,13 +86,16 @@ PCG_DEV double qtrunc6(double v) {
 // for a double log + exp); when the fp32 result lands within 2^-10 of a grid cell edge (0.2 % of the calls), or E2 is
 // outside the comfortable fp32 range, the double path decides, so the quantised value never depends on the fp32
 // rounding.  Both infinities map to values the callers clip (E2 -> 0: huge, E2 -> inf: tiny).
-PCG_DEV double ctrl_pow(double E2, double scale) {
-  double f = scale * (double)__builtin_amdgcn_exp2f(-0.1f * __builtin_amdgcn_logf((float)E2));
+// NEG_EXP: the exponent applied to the MEAN SQUARE, i.e. half the method's: 0.1 for the 5(4) pair (E^(-1/5)),
+// 1/6 for the 3(2) Rosenbrock pair (E^(-1/3)).
+PCG_DEV double ctrl_pow_e(double E2, double scale, float neg_exp_f, double neg_exp_d) {
+  double f = scale * (double)__builtin_amdgcn_exp2f(-neg_exp_f * __builtin_amdgcn_logf((float)E2));
   const unsigned frac = (unsigned)(__double_as_longlong(f) >> 36) & 0x3FFu;  // the 10 bits below the kept ones
   if (frac == 0u || frac == 0x3FFu || !(E2 > 1e-30 && E2 < 1e30))
-    f = scale * exp_bounded(-0.1 * log_pos(E2));
+    f = scale * exp_bounded(-neg_exp_d * log_pos(E2));
   return qtrunc6(f);
 }
+PCG_DEV double ctrl_pow(double E2, double scale) { return ctrl_pow_e(E2, scale, 0.1f, 0.1); }
 
 // Linear combinations of stage derivatives as EXPLICIT fused multiply-adds in a fixed order.  The functions that use
 // them switch compiler contraction off (#pragma clang fp contract(off)), so the arithmetic that feeds back into the
@@ -244,6 +247,231 @@ PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double 
       rejected_last = true;
       ++rej;
       if (!(h > 1e-13 * dt)) {  // step-size underflow (NaN state / blow-up): give up on this lane
+        status = 2;
+        break;
+      }
+    }
+  }
+  nacc = acc;
+  nrej = rej;
+  return status;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rodas3 -- a stiff-capable integrator (the reference solves with CVODES BDF,
+// integrator.py:163-182).  Sandu, Verwer, Blom, Spee, Carmichael & Potra (1997): 4-stage linearly implicit
+// Rosenbrock method, order 3 with an embedded order-2 estimate, L-stable, stiffly accurate, gamma = 1/2; per step one
+// Jacobian (forward differences of the model's RHS: generic over the registry), one LU factorisation of
+// W = I/(gamma h) - J with partial pivoting and four triangular solves.  Per-lane adaptive step size with the same
+// norm, quantised factor and failure semantics as dopri5() (exponent 1/3, growth limit 6).
+// The per-lane matrix lives in LDS  W[(i*NX + j)][lane]  (lane-contiguous 8-byte words: conflict-free), the pivot
+// rows behind it; vectors stay in registers.  For the registry models at their canonical stiffness the explicit pair
+// is faster; this integrator is for the user whose model is stiff beyond |lambda| dt ~ 1e3.
+// ---------------------------------------------------------------------------------------------------------------
+// one wave per workgroup; past 16 states only half of its lanes carry an env, so that the matrices (nx^2 x lanes x 8 B)
+// still fit the 160 KB of LDS (nx = 24: 147 KB + pivots)
+constexpr int ros_threads(int nx) { return nx <= 16 ? 64 : 32; }
+constexpr size_t ros_lds_doubles(int nx) { return (size_t)(nx * nx + (nx + 1) / 2) * ros_threads(nx); }
+
+template <int NX>
+struct RosLds {
+  static constexpr int T = ros_threads(NX);
+  double* W;     // &lds[lane]
+  int32_t* piv;  // &((int32_t*)(lds + NX*NX*T))[lane]
+  PCG_DEV explicit RosLds(double* lds) : W(lds + threadIdx.x), piv(reinterpret_cast<int32_t*>(lds + NX * NX * T) + threadIdx.x) {}
+  PCG_DEV double& w(int i, int j) const { return W[(i * NX + j) * T]; }
+  PCG_DEV int32_t& p(int k) const { return piv[k * T]; }
+};
+
+// unroll depth of the factorisation's outer loops: full for the small systems (the compiler can then batch the LDS
+// reads of a row instead of paying one LDS round trip per element), rolled for the large ones (code size)
+constexpr int ros_unroll(int nx) { return nx <= 10 ? nx : 1; }
+
+// LU with partial pivoting, in place; returns false on a (numerically) singular pivot
+template <int NX>
+PCG_DEV bool ros_lu(const RosLds<NX>& L, int n) {
+  bool ok = true;
+  constexpr int UK = ros_unroll(NX);
+#pragma unroll UK
+  for (int k = 0; k < NX; ++k) {
+    if (k >= n) break;
+    int pk = k;
+    double best = fabs(L.w(k, k));
+#pragma unroll
+    for (int i = k + 1; i < NX; ++i) {
+      if (i < n) {
+        const double v = fabs(L.w(i, k));
+        pk = (v > best) ? i : pk;
+        best = (v > best) ? v : best;
+      }
+    }
+    L.p(k) = pk;
+    if (pk != k) {
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        if (j < n) {
+          const double a = L.w(k, j), b = L.w(pk, j);
+          L.w(k, j) = b;
+          L.w(pk, j) = a;
+        }
+      }
+    }
+    const double d = L.w(k, k);
+    ok = ok && (fabs(d) > 1e-300) && (d == d);
+    const double inv = 1.0 / d;
+    double rowk[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) rowk[j] = (j > k && j < n) ? L.w(k, j) : 0.0;
+#pragma unroll UK
+    for (int i = k + 1; i < NX; ++i) {
+      if (i >= n) break;
+      const double l = L.w(i, k) * inv;
+      L.w(i, k) = l;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        if (j > k && j < n) L.w(i, j) = L.w(i, j) - l * rowk[j];
+      }
+    }
+  }
+  return ok;
+}
+
+// solve W z = b in place (b in registers; the row swaps by select chains: no dynamic register indexing)
+template <int NX>
+PCG_DEV void ros_solve(const RosLds<NX>& L, int n, double (&b)[NX]) {
+#pragma unroll
+  for (int k = 0; k < NX; ++k) {
+    if (k < n) {
+      const int pk = L.p(k);
+      const double bk = b[k];
+      double bp = bk;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) bp = (i == pk) ? b[i] : bp;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) b[i] = (i == pk) ? bk : b[i];
+      b[k] = bp;
+    }
+  }
+#pragma unroll
+  for (int i = 1; i < NX; ++i) {
+    if (i < n) {
+      double sacc = b[i];
+#pragma unroll
+      for (int j = 0; j < NX; ++j)
+        if (j < i) sacc -= L.w(i, j) * b[j];
+      b[i] = sacc;
+    }
+  }
+#pragma unroll
+  for (int ii = 0; ii < NX; ++ii) {
+    const int i = NX - 1 - ii;
+    if (i < n) {
+      double sacc = b[i];
+#pragma unroll
+      for (int j = 0; j < NX; ++j)
+        if (j > i && j < n) sacc -= L.w(i, j) * b[j];
+      b[i] = sacc / L.w(i, i);
+    }
+  }
+}
+
+// returns PCG_ST_OK, PCG_ST_MAX_STEPS or PCG_ST_UNDERFLOW (the caller poisons the state on failure)
+template <int NX, class F>
+PCG_DEV int rodas3(const F& f, const RosLds<NX>& L, double (&x)[NX], int n, double dt, double rtol, double atol,
+                   int max_steps, int& nacc, int& nrej) {
+#pragma clang fp contract(off)
+  constexpr double gam = 0.5;
+  double f0[NX], k1[NX], k2[NX], k3[NX], k4[NX], y[NX], fy[NX];
+  int acc = 0, rej = 0, status = 0;
+  f(x, f0);
+  double h;
+  {  // initial step: h0 of Hairer, Norsett & Wanner II.4 (the first stage of dopri5()'s heuristic), quantised
+    const double d0 = rms_scaled<NX>(x, x, x, n, rtol, atol);
+    const double d1 = rms_scaled<NX>(f0, x, x, n, rtol, atol);
+    const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    h = fmin(qtrunc6(100.0 * h0), dt);
+  }
+  double t = 0.0;
+  bool rejected_last = false;
+  for (;;) {
+    bool last = false;
+    if (acc + rej >= max_steps) {
+      status = 1;
+      break;
+    }
+    if (t + h >= dt * (1.0 - 1e-14)) {
+      h = dt - t;
+      last = true;
+    }
+    // Jacobian by forward differences, W = I/(gamma h) - J
+    // perturbation ~ sqrt(eps) / rtol x the error weight of the component (CVODES' difference quotient scales the
+    // same way); the x_max term only keeps it non-zero when atol = 0 and x_j = 0
+    double xmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xmax = fmax(xmax, (i < n) ? fabs(x[i]) : 0.0);
+    const double wfloor = atol / rtol + 1e-12 * xmax + 1e-100;
+#pragma unroll 1
+    for (int j = 0; j < NX; ++j) {
+      if (j >= n) break;
+      double xj = 0.0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xj = (i == j) ? x[i] : xj;
+      const double del = 1.4901161193847656e-8 * (fabs(xj) + wfloor);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) y[i] = (i == j) ? x[i] + del : x[i];
+      f(y, fy);
+      const double idel = 1.0 / ((xj + del) - xj);  // the perturbation that was actually applied
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        if (i < n) L.w(i, j) = -(fy[i] - f0[i]) * idel;
+    }
+    const double igh = 1.0 / (gam * h), ih = 1.0 / h;
+    for (int i = 0; i < NX; ++i) {
+      if (i >= n) break;
+      L.w(i, i) = L.w(i, i) + igh;
+    }
+    const bool lu_ok = ros_lu<NX>(L, n);
+    // stage 1 .. 4 (a21 = 0: stage 2 re-uses f(x))
+#pragma unroll
+    for (int i = 0; i < NX; ++i) k1[i] = f0[i];
+    ros_solve<NX>(L, n, k1);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) k2[i] = f0[i] + (4.0 * ih) * k1[i];
+    ros_solve<NX>(L, n, k2);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = x[i] + 2.0 * k1[i];
+    f(y, fy);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) k3[i] = fy[i] + ih * (k1[i] - k2[i]);
+    ros_solve<NX>(L, n, k3);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = x[i] + 2.0 * k1[i] + k3[i];
+    f(y, fy);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) k4[i] = fy[i] + ih * (k1[i] - k2[i] - (8.0 / 3.0) * k3[i]);
+    ros_solve<NX>(L, n, k4);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = x[i] + 2.0 * k1[i] + k3[i] + k4[i];  // m = (2, 0, 1, 1); error = k4
+    double E2 = ms_scaled<NX>(k4, x, y, n, rtol, atol);
+    if (!lu_ok) E2 = __builtin_nan("");
+    if (E2 < 1.0) {
+      double fac = fmin(6.0, fmax(0.2, ctrl_pow_e(E2, 0.9, 1.0f / 6.0f, 1.0 / 6.0)));
+      if (rejected_last && fac > 1.0) fac = 1.0;
+      t += h;
+      h *= fac;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = y[i];
+      rejected_last = false;
+      ++acc;
+      if (last) break;
+      f(x, f0);
+    } else {
+      double fac = (E2 == E2) ? fmax(0.2, ctrl_pow_e(E2, 0.9, 1.0f / 6.0f, 1.0 / 6.0)) : 0.2;
+      if (fac > 1.0) fac = 1.0;
+      h *= fac;
+      rejected_last = true;
+      ++rej;
+      if (!(h > 1e-13 * dt)) {
         status = 2;
         break;
       }

@@ -51,7 +51,13 @@ constexpr int BLOCK = 256;      // threads per workgroup (4 waves, one per SIMD)
 constexpr int BLOCK_LDS = 64;   // LDS-staged DOPRI5: 6*NX*8 B of stage storage per lane
 // Adaptive (DOPRI5) kernels run one wave per workgroup: lanes take different numbers of steps, a 4-wave workgroup
 // holds its CU slots until its slowest wave ends, and single-wave workgroups let the dispatcher refill per wave.
-constexpr int tb(bool lds_stages, int integ) { return (lds_stages || integ == PCG_INT_DOPRI5) ? BLOCK_LDS : BLOCK; }
+constexpr int tb(bool lds_stages, int integ, int nx = 0) {
+  return integ == PCG_INT_RODAS3 ? ros_threads(nx) : (lds_stages || integ == PCG_INT_DOPRI5) ? BLOCK_LDS : BLOCK;
+}
+// doubles of dynamic LDS the integrator itself needs per workgroup (the schedules follow them)
+constexpr size_t integ_lds_doubles(int nx, int integ, bool lds_stages) {
+  return integ == PCG_INT_RODAS3 ? ros_lds_doubles(nx) : lds_stages ? (size_t)6 * nx * BLOCK_LDS : 0;
+}
 // Minimum waves per SIMD asked of the register allocator.  DOPRI5 with <= 10 states needs ~280 registers
 // when left alone (1 wave/SIMD, latency-bound: measured 14k cycles per attempted step against ~3.6k of
 // issue); capping it at 256 costs a few spills and doubles the resident waves.
@@ -433,6 +439,15 @@ PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const do
   int status = PCG_ST_OK;
   if (INTEG == PCG_INT_RK4) {
     rk4<NX>(f, x, c.h, c.substeps);
+  } else if (INTEG == PCG_INT_RODAS3) {
+    int nacc = 0, nrej = 0;
+    const RosLds<NX> Lm(stage_l);
+    status = rodas3<NX>(f, Lm, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    if (A.nsteps) {
+      A.nsteps[e] = nacc;
+      A.nsteps[A.B + e] = nrej;
+    }
+    poison_if_failed<NX>(status, x);
   } else {
     int nacc = 0, nrej = 0;
     if (LDS_STAGES) {
@@ -782,14 +797,14 @@ PCG_DEV void stage_schedules(const StepArgs& A, CDevConst& c, double* sched_l) {
 }
 
 template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS, bool UNC = false>
-__global__ __launch_bounds__(tb(LDS_STAGES, INTEG), wpe(M::NX, INTEG, LDS_STAGES)) void step_kernel(const StepArgs A) {
+__global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX), wpe(M::NX, INTEG, LDS_STAGES)) void step_kernel(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA;
   double* stage_l = lds;
-  double* sched_l = lds + (LDS_STAGES ? 6 * NX * BLOCK_LDS : 0);
+  double* sched_l = lds + integ_lds_doubles(NX, INTEG, LDS_STAGES);
   if (PER_ENV_T) stage_schedules(A, c, sched_l);
-  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES, INTEG) + threadIdx.x;
+  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES, INTEG, M::NX) + threadIdx.x;
   if (e >= A.B) return;
   const int64_t B = A.B;
   const int nx = M::DYNAMIC ? c.nx : NX;
@@ -1408,12 +1423,12 @@ __global__ __launch_bounds__(BLOCK) void rhs_kernel(CDevConst* C, int64_t B, int
 }
 
 template <class M, int INTEG, bool LDS_STAGES>
-__global__ __launch_bounds__(tb(LDS_STAGES, INTEG)) void integrate_kernel(CDevConst* C, int64_t B, int nu_rows,
-                                                                   double* xg, const double* ug, int32_t* nsteps) {
+__global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX)) void integrate_kernel(CDevConst* C, int64_t B, int nu_rows,
+                                                                          double* xg, const double* ug, int32_t* nsteps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   CDevConst& c = *C;
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
-  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES, INTEG) + threadIdx.x;
+  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES, INTEG, NX) + threadIdx.x;
   if (e >= B) return;
   const int nx = M::DYNAMIC ? c.nx : NX;
   const int na = M::DYNAMIC ? c.na : NA;
@@ -1429,6 +1444,15 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG)) void integrate_kernel(CDevCo
   const RhsFn<M> f{kp, hold};
   if (INTEG == PCG_INT_RK4) {
     rk4<NX>(f, x, c.h, c.substeps);
+  } else if (INTEG == PCG_INT_RODAS3) {
+    int nacc = 0, nrej = 0;
+    const RosLds<NX> Lm(lds);
+    const int status = rodas3<NX>(f, Lm, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    poison_if_failed<NX>(status, x);
+    if (nsteps) {
+      nsteps[e] = nacc;
+      nsteps[B + e] = nrej;
+    }
   } else {
     int nacc = 0, nrej = 0, status;
     if (LDS_STAGES) {
@@ -1516,6 +1540,10 @@ Kernels make_kernels() {
   k.rollout[PCG_INT_DOPRI5][0] = rollout_kernel<M, PCG_INT_DOPRI5, false>;
   k.integ[PCG_INT_RK4][0] = integrate_kernel<M, PCG_INT_RK4, false>;
   k.integ[PCG_INT_DOPRI5][0] = integrate_kernel<M, PCG_INT_DOPRI5, false>;
+  // stiff-capable Rosenbrock integrator: general kernel only (one wave per workgroup, per-lane matrices in LDS)
+  k.step[PCG_INT_RODAS3][0][0][0] = k.step[PCG_INT_RODAS3][0][0][1] = step_kernel<M, PCG_INT_RODAS3, false, false, true>;
+  k.step[PCG_INT_RODAS3][1][0][0] = k.step[PCG_INT_RODAS3][1][0][1] = step_kernel<M, PCG_INT_RODAS3, true, false, true>;
+  k.integ[PCG_INT_RODAS3][0] = integrate_kernel<M, PCG_INT_RODAS3, false>;
   k.rhs = rhs_kernel<M>;
   if constexpr (!M::DYNAMIC) {
     k.queue[0] = step_kernel_queue<M, false, true>;
@@ -1553,11 +1581,13 @@ Kernels make_kernels() {
   for (int pe = 0; pe < 2; ++pe)
     for (int ex = 0; ex < 2; ++ex) {
       k.step[PCG_INT_RK4][pe][1][ex] = k.step[PCG_INT_RK4][pe][0][ex];
+      k.step[PCG_INT_RODAS3][pe][1][ex] = k.step[PCG_INT_RODAS3][pe][0][ex];
       if (!k.step[PCG_INT_DOPRI5][pe][1][ex]) k.step[PCG_INT_DOPRI5][pe][1][ex] = k.step[PCG_INT_DOPRI5][pe][0][ex];
     }
   k.rollout[PCG_INT_RK4][1] = k.rollout[PCG_INT_RK4][0];
   if (!k.rollout[PCG_INT_DOPRI5][1]) k.rollout[PCG_INT_DOPRI5][1] = k.rollout[PCG_INT_DOPRI5][0];
   k.integ[PCG_INT_RK4][1] = k.integ[PCG_INT_RK4][0];
+  k.integ[PCG_INT_RODAS3][1] = k.integ[PCG_INT_RODAS3][0];
   if (!k.integ[PCG_INT_DOPRI5][1]) k.integ[PCG_INT_DOPRI5][1] = k.integ[PCG_INT_DOPRI5][0];
   k.nfeat = feat_fill<ID>(k.feat, MAX_FEAT);
   k.has_lds_stages = M::FULL;

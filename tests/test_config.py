@@ -158,6 +158,15 @@ def test_integrator_selection():
     with pytest.raises(ValueError):
         EnvSpec(p)
     assert default_substeps(M.CSTR, 1.0) == 10 and default_substeps(M.CRYST, 1.0) == 32
+    # the stiff-capable Rosenbrock integrator is an explicit opt-in
+    p = P("me_canonical")
+    p.update(integrator="rodas3", rtol=1e-6, atol=1e-8)
+    s = EnvSpec(p)
+    cfg, _keep = s.to_cfg()
+    assert s.integrator == "rodas3" and cfg.integrator_id == abi.PCG_INT_RODAS3 and cfg.rtol == 1e-6
+    p["integrator"] = "bdf"
+    with pytest.raises(ValueError, match="rodas3"):
+        EnvSpec(p)
 
 
 def test_shape_errors():

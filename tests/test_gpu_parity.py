@@ -170,6 +170,20 @@ INT_CASES = [
     ("heat_exchanger", "heat_exchanger", dict(integrator="rk4", substeps=8), 1e-12),
     ("invariant_batch", "invariant_batch", dict(integrator="rk4", substeps=64), 1e-10),
     ("coupled_oscillator", "coupled_oscillator", dict(integrator="dopri5"), 1e-9),
+    # stiff-capable Rosenbrock integrator (per-lane LU in LDS): every state-count class of the registry -- 1, 2, 4, 7,
+    # 10, 16 (64 lanes per wave), 20, 24 (32 lanes per wave) -- and the run-time-sized affine model
+    ("first_order_system", "first_order_system", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("cstr", "cstr", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("cstr_d", "cstr", dict(integrator="rodas3", rtol=1e-7, atol=1e-9), 1e-9),
+    ("four_tank", "four_tank", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("crystallization", "crystallization", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("multistage_extraction", "multistage_extraction", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("multistage_extraction_d", "multistage_extraction", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("distillation_column", "distillation_column", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("biofilm_reactor", "biofilm_reactor", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("multistage_extraction_reactive", "multistage_extraction_reactive", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("heat_exchanger", "heat_exchanger", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("polymerisation_reactor", "polymerisation_reactor", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-8),
 ]
 
 
@@ -208,6 +222,13 @@ def test_integrate_vs_oracle(fix, model, kw, tol, lds_stages):
     want, ns_o = O.integrate(spec, xs, us)
     scale = np.maximum(np.abs(want), 1e-6 * np.max(np.abs(want), axis=1, keepdims=True))
     err = np.max(np.abs(got - want) / scale)
+    if kw["integrator"] == "rodas3":
+        # same controller, same arithmetic order (explicit twin in the oracle): identical step sequences; the LU
+        # solves amplify the RHS's last-bit differences by the condition number of I/(gamma h) - J
+        H.adaptive_check(model, got, want, ns.cpu().numpy(), ns_o, fix, tol=tol)
+        t = g["xf"][ok].T
+        assert np.all(np.abs(got - t) <= 3e-4 * np.abs(t) + 1e-6)  # third-order pair at 1e-6: its accuracy class
+        return
     if kw["integrator"] == "dopri5":
         # the quantised step-size controller (DESIGN.md "Adaptive stepping") makes both sides take the SAME
         # sequence of steps: accepted / rejected counts are identical for every sample and the states agree like
@@ -301,6 +322,11 @@ BATCH_CASES = [
     ("cstr_con_reward", RK, 1e-12),
     ("cryst_paper_reward", {}, 1e-10),
     ("cstr_partial_obs", RK, 1e-12),
+    # stiff-capable integrator through the full step (general kernel, LDS matrices + LDS schedules when per-env t)
+    ("cstr_cons_pen_norm", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("me_dist_cons", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("cryst_adelta", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
+    ("me_reactive", dict(integrator="rodas3", rtol=1e-5, atol=1e-7), 1e-9),
 ]
 
 
@@ -337,7 +363,7 @@ def test_batched_step_vs_oracle(name, kw, tol, per_env_t, B):
     spec = env.spec
     orc = O.OracleEnv(spec, B, seed=5, per_env_t=per_env_t)
     acts = _rand_actions(spec, T, B, 3)  # the FULL action box (ME: L up to 500, G up to 1000, |lambda| dt ~ 240)
-    adaptive = spec.integrator == "dopri5"
+    adaptive = spec.integrator != "rk4"
     o_g, _ = env.reset()
     o_c = orc.reset()
     rng = np.random.default_rng(9)

@@ -625,3 +625,75 @@ def test_host_gather_delivers_every_step_in_order():
             assert torch.equal(out["done"], ref.done.cpu()), k
     env.close()
     ref.close()
+
+
+# ---- stiff-capable integrator (the reference integrates with CVODES BDF) ----------------
+def test_rosenbrock_integrator_on_a_stiffened_column_through_the_hip_path():
+    """The extraction column with hold-ups / 100 (|lambda| dt ~ 24,000): with a plan's usual step budget the explicit
+    pair reports failure (status byte, NaN state) for most of the action box, the Rosenbrock pair integrates every env
+    in ~250 steps, identically to its oracle twin, and agrees with the explicit pair given an unbounded budget."""
+    torch = _torch()
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+    from pcgym_amd import _abi as abi
+
+    B = 640
+    sc = SC.scenarios()["me_canonical"]
+    rng = np.random.default_rng(4)
+
+    from pcgym_amd import models as M
+
+    class multistage_extraction:  # the reference's custom_model hook (pcgym.py:150-153) with changed parameter values
+        def info(self):
+            d = M.get_model("multistage_extraction").info()
+            d["parameters"].update(Vl=0.05, Vg=0.05)
+            return d
+
+    def build(integ, max_steps):
+        p = copy.deepcopy(sc["env_params"])
+        p.update(integrator=integ, rtol=1e-6, atol=1e-8, max_steps=max_steps, custom_model=multistage_extraction())
+        return p
+
+    acts = rng.uniform(-1, 1, (3, 2, B))
+    res = {}
+    for integ, ms in (("rodas3", 2000), ("dopri5", 2000), ("dopri5", 40000)):
+        env = VecEnv(build(integ, ms), n_envs=B, seed=3)
+        assert env.spec.model.parameters["Vl"] == 0.05 and env.spec.integrator == integ
+        orc = O.OracleEnv(env.spec, B, seed=3)
+        env.reset()
+        orc.reset()
+        for i in range(3):
+            env.step(torch.tensor(acts[i], device=env.device))
+            orc.step(acts[i])
+            if integ == "rodas3":
+                _cmp(env, orc, 1e-9, ("stiff column", i))
+        torch.cuda.synchronize()
+        res[(integ, ms)] = (env.x.cpu().numpy(), env.status.cpu().numpy(), env.nsteps.cpu().numpy())
+        assert np.array_equal(env.status.cpu().numpy(), orc.status)
+        env.close()
+    xr, sr, nr = res[("rodas3", 2000)]
+    xb, sb, _ = res[("dopri5", 2000)]
+    xd, sd, nd = res[("dopri5", 40000)]
+    assert not sr.any() and np.isfinite(xr).all() and nr.sum(axis=0).max() < 600
+    # (a failed env stays failed: its NaN state makes the following steps fail too, and the sticky byte keeps the last code)
+    assert (sb != abi.PCG_ST_OK).mean() > 0.5 and np.isnan(xb[:, sb != 0]).all() and np.isfinite(xb[:, sb == 0]).all()
+    assert not sd.any() and nd.sum(axis=0).mean() > 2000
+    assert np.max(np.abs(xr - xd)) <= 2e-5
+
+
+def test_rosenbrock_plans_are_refused_where_no_kernel_exists():
+    torch = _torch()
+    from pcgym_amd import VecEnv, collect_rollouts
+
+    p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+    p.update(integrator="rodas3", rtol=1e-6, atol=1e-8)
+    env = VecEnv(p, n_envs=256, seed=1)
+    env.reset()
+    a = torch.zeros((5, env.spec.na, 256), dtype=torch.float64, device=env.device)
+    with pytest.raises(RuntimeError, match="pcg_rollout"):
+        env.rollout(a)
+    # the collector steps instead (no fused kernel), and an open-loop episode stays finite
+    acts = torch.zeros((env.spec.N, env.spec.na, 256), dtype=torch.float64, device=env.device)
+    out = collect_rollouts(env, actions=acts)
+    assert torch.isfinite(out["x"]).all() and torch.isfinite(out["r"]).all()
+    env.close()

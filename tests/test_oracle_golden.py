@@ -120,6 +120,47 @@ def test_integrators_reach_true_solution(fix, model, tol_default, tight, tol_tig
     assert np.max(np.abs(xf.T - g["xf"]) / scale) <= tol_tight
 
 
+@pytest.mark.parametrize("fix,model", [(c[0], c[1]) for c in TIGHT_CASES])
+def test_rosenbrock_integrator_reaches_true_solution(fix, model):
+    """The stiff-capable integrator (Rodas3, order 3(2)) against the same LSODA(1e-13) answers: in its accuracy class at
+    the CVODES-like tolerance, and converging at third order as the tolerance tightens (1000 x tighter: ~10 x the
+    steps, ~1000 x less error)."""
+    g = H.gold("tight_" + fix)
+    dt = float(g["dt"])
+    nu = g["u"].shape[1]
+    scale = np.maximum(np.abs(g["xf"]), 1e-6 * np.max(np.abs(g["xf"]), axis=0, keepdims=True))
+    res = []
+    for tol in (1e-6, 1e-9):
+        s = _spec_for_integration(model, dt, nu, integrator="rodas3", rtol=tol, atol=tol * 1e-2)
+        xf, ns = O.integrate(s, g["x"].T, g["u"].T)
+        assert np.isfinite(xf).all()
+        res.append((np.max(np.abs(xf.T - g["xf"]) / scale), ns.sum(axis=0).mean()))
+    assert res[0][0] <= 3e-4 and res[1][0] <= 1e-6, res  # ignition / gel-effect samples set the bound (cstr_d: 1.4e-4)
+    assert res[1][0] <= 0.02 * res[0][0] + 1e-10 and res[1][1] <= 14 * res[0][1], res
+
+
+def test_rosenbrock_integrator_on_a_stiffened_column():
+    """What the integrator is for: the extraction column with its hold-ups divided by 100 (|lambda| dt ~ 24,000 at the
+    top of the action box).  The explicit pair is stability-bound and needs thousands of steps; the L-stable Rosenbrock
+    pair takes about as many as on the unstiffened column, and both arrive at the same state."""
+    g = H.gold("tight_multistage_extraction")
+    out = {}
+    for integ in ("dopri5", "rodas3"):
+        s = _spec_for_integration("multistage_extraction", float(g["dt"]), g["u"].shape[1], integrator=integ,
+                                  rtol=1e-6, atol=1e-8, max_steps=20000)
+        s.model.parameters["Vl"] = s.model.parameters["Vg"] = 0.05  # private copy of the registry entry
+        out[integ] = O.integrate(s, g["x"].T, g["u"].T)
+    (xd, nd), (xr, nr) = out["dopri5"], out["rodas3"]
+    assert nd.sum(axis=0).mean() > 3000 and nr.sum(axis=0).mean() < 300
+    assert np.isfinite(xr).all() and np.max(np.abs(xd - xr)) <= 5e-6
+    # with the default step budget of a plan that is a failed integration for the explicit pair: status, NaN state
+    s = _spec_for_integration("multistage_extraction", float(g["dt"]), g["u"].shape[1], integrator="dopri5",
+                              rtol=1e-6, atol=1e-8, max_steps=1000)
+    s.model.parameters["Vl"] = s.model.parameters["Vg"] = 0.05
+    xf, _ = O.integrate(s, g["x"].T, g["u"].T)
+    assert np.isnan(xf).any(axis=0).mean() > 0.5
+
+
 PAPER = [("cstr", "cstr"), ("four_tank", "four_tank"), ("multistage_extraction", "multistage_extraction"),
          ("crystallization", "crystallization"), ("cstr_constraint", "cstr")]
 
