@@ -140,6 +140,10 @@ def test_extraction_equilibrium_exponent_paths(model, fix, expo):
 
 
 # ------------------------------------------------------------ integrate ------
+# Rodas3 GPU vs oracle: identical step sequences, states to 5e-8 (the integrator's own tolerance is 1e-6): the
+# forward-difference Jacobian divides last-bit differences of two RHS evaluations by a perturbation of ~1.5e-8 |x_j|
+ROS_TOL = 5e-8
+
 INT_CASES = [
     ("cstr", "cstr", dict(integrator="rk4", substeps=4), 1e-12),
     ("cstr", "cstr", dict(integrator="dopri5"), 1e-9),
@@ -172,18 +176,18 @@ INT_CASES = [
     ("coupled_oscillator", "coupled_oscillator", dict(integrator="dopri5"), 1e-9),
     # stiff-capable Rosenbrock integrator (per-lane LU in LDS): every state-count class of the registry -- 1, 2, 4, 7,
     # 10, 16 (64 lanes per wave), 20, 24 (32 lanes per wave) -- and the run-time-sized affine model
-    ("first_order_system", "first_order_system", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("cstr", "cstr", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("cstr_d", "cstr", dict(integrator="rodas3", rtol=1e-7, atol=1e-9), 1e-9),
-    ("four_tank", "four_tank", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("crystallization", "crystallization", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("multistage_extraction", "multistage_extraction", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("multistage_extraction_d", "multistage_extraction", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("distillation_column", "distillation_column", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("biofilm_reactor", "biofilm_reactor", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("multistage_extraction_reactive", "multistage_extraction_reactive", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("heat_exchanger", "heat_exchanger", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("polymerisation_reactor", "polymerisation_reactor", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-8),
+    ("first_order_system", "first_order_system", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("cstr", "cstr", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("cstr_d", "cstr", dict(integrator="rodas3", rtol=1e-7, atol=1e-9), ROS_TOL),
+    ("four_tank", "four_tank", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("crystallization", "crystallization", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("multistage_extraction", "multistage_extraction", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("multistage_extraction_d", "multistage_extraction", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("distillation_column", "distillation_column", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("biofilm_reactor", "biofilm_reactor", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("multistage_extraction_reactive", "multistage_extraction_reactive", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("heat_exchanger", "heat_exchanger", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("polymerisation_reactor", "polymerisation_reactor", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
 ]
 
 
@@ -323,10 +327,10 @@ BATCH_CASES = [
     ("cryst_paper_reward", {}, 1e-10),
     ("cstr_partial_obs", RK, 1e-12),
     # stiff-capable integrator through the full step (general kernel, LDS matrices + LDS schedules when per-env t)
-    ("cstr_cons_pen_norm", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("me_dist_cons", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("cryst_adelta", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), 1e-9),
-    ("me_reactive", dict(integrator="rodas3", rtol=1e-5, atol=1e-7), 1e-9),
+    ("cstr_cons_pen_norm", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("me_dist_cons", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("cryst_adelta", dict(integrator="rodas3", rtol=1e-6, atol=1e-8), ROS_TOL),
+    ("me_reactive", dict(integrator="rodas3", rtol=1e-5, atol=1e-7), ROS_TOL),
 ]
 
 
@@ -385,7 +389,20 @@ def test_batched_step_vs_oracle(name, kw, tol, per_env_t, B):
         ex = np.max(np.abs(env.x.cpu().numpy() - orc.x) / xs, axis=0)
         eo = np.max(np.abs(og - oc) / sc_o, axis=0)
         er = np.abs(rg - rc) / np.maximum(np.abs(rc), 1.0)
-        if adaptive:
+        if spec.integrator == "rodas3":
+            # same controller and operation order, but the difference-quotient Jacobian turns last-bit differences of
+            # the RHS into ~1e-8 relative differences of W: every step is a one-step test from a common state (re-sync
+            # below), identical step counts for (almost) every env, states to ROS_TOL where the counts agree and
+            # within the integrator's own tolerance class where one side took an extra step
+            ns_g, ns_c = env.nsteps.cpu().numpy(), orc.nsteps
+            same = np.all(ns_g == ns_c, axis=0)
+            assert same.mean() >= 0.995, (name, i, same.mean())
+            assert np.max(ex[same]) <= tol and np.max(eo[same]) <= tol * 10, (name, i, np.max(ex[same]), np.max(eo[same]))
+            assert np.max(er[same]) <= tol * 20, (name, i)
+            assert np.max(ex) <= 1e-5 and np.max(eo) <= 1e-4, (name, i, np.max(ex))
+            assert not env.status.any()
+            env.x.copy_(torch.tensor(orc.x, device=env.device))
+        elif adaptive:
             # quantised controller: both sides take the same step sequence for EVERY env, so the adaptive path is
             # held to round-off like the fixed-step one, over the whole 12-step trajectory (no re-synchronisation);
             # the stability-limited extraction model: helpers.adaptive_check
@@ -397,7 +414,7 @@ def test_batched_step_vs_oracle(name, kw, tol, per_env_t, B):
                 env.x.copy_(torch.tensor(orc.x, device=env.device))  # re-sync: every step is a one-step test
             else:
                 assert np.max(eo) <= ta * 10, (name, i, np.max(eo))
-                assert np.max(er) <= max(ta * 1e3, 1e-9), (name, i)
+                assert np.max(er) <= max(ta * (1e3 if ta < 1e-9 else 20), 1e-9), (name, i)
         else:
             assert np.max(eo) <= tol * 10, (name, i)
             assert np.max(ex) <= tol, (name, i)
@@ -407,6 +424,8 @@ def test_batched_step_vs_oracle(name, kw, tol, per_env_t, B):
             assert np.mean(env.viol.cpu().numpy() == orc.viol) >= 0.999
             gs = np.maximum(np.abs(orc.g), 1e-3 * np.max(np.abs(orc.g)))
             gtol = 2e-5 if (adaptive and spec.model.name in H.STABILITY_LIMITED) else max(tol * 100, 1e-10)
+            if spec.integrator == "rodas3":
+                gtol = 1e-4  # covers an env whose two sides took a different number of steps
             assert np.max(np.abs(env.g.cpu().numpy() - orc.g) / gs) <= gtol
         if spec.a_delta:
             assert np.allclose(env.a_save_t.cpu().numpy(), orc.a_save, rtol=1e-13)
