@@ -117,10 +117,11 @@ enum pcg_integrator {
   PCG_INT_RK4 = 0,     /* classical RK4, `substeps` equal sub-steps per env step (zero-order hold on u) */
   PCG_INT_DOPRI5 = 1,  /* adaptive Dormand-Prince 5(4), per-lane step size, rtol/atol
                           (mirrors integrator.py:61 PIDController(rtol=1e-8, atol=1e-8)) */
-  PCG_INT_RODAS3 = 2,  /* stiff-capable: adaptive Rodas3 (4-stage linearly implicit Rosenbrock 3(2), L-stable; finite-
-                          difference Jacobian, per-lane LU in LDS), rtol/atol/max_steps as for DOPRI5.  The reference
-                          integrates with CVODES BDF (integrator.py:163-182).  Models with nx <= 16; pcg_step,
-                          pcg_step_autoreset and pcg_integrate (not pcg_rollout, not per-env uncertain parameters) */
+  PCG_INT_RODAS3 = 2,  /* stiff-capable: adaptive Rodas3 (4-stage linearly implicit Rosenbrock 3(2), L-stable; forward-
+                          difference Jacobian, per-lane pivoted LU in LDS), rtol/atol/max_steps as for DOPRI5.  The
+                          reference integrates with CVODES BDF (integrator.py:163-182).  Every model (nx <= 24);
+                          pcg_step, pcg_step_autoreset, pcg_graph_* and pcg_integrate; pcg_rollout and plans with
+                          per-env uncertain parameters return PCG_E_UNSUPPORTED */
   PCG_INT_COUNT = 3
 };
 

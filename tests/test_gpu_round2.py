@@ -697,3 +697,59 @@ def test_rosenbrock_plans_are_refused_where_no_kernel_exists():
     out = collect_rollouts(env, actions=acts)
     assert torch.isfinite(out["x"]).all() and torch.isfinite(out["r"]).all()
     env.close()
+    # ... but its steps record into a HIP graph like any other plan's (10-state model: 51 KB of LDS matrices per wave,
+    # beyond the default dynamic-LDS limit, raised per launch)
+    p = copy.deepcopy(SC.scenarios()["me_canonical"]["env_params"])
+    p.update(integrator="rodas3", rtol=1e-6, atol=1e-8)
+    e1, e2 = VecEnv(copy.deepcopy(p), n_envs=300, seed=1), VecEnv(copy.deepcopy(p), n_envs=300, seed=1)
+    e1.reset(), e2.reset()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    acts = [torch.rand((2, 300), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1 for _ in range(4)]
+    g = e2.capture_steps(acts)
+    for a in acts:
+        e1.step(a)
+    g.replay()
+    assert torch.equal(e1.x, e2.x) and torch.equal(e1.rew, e2.rew) and torch.equal(e1.obs_soa, e2.obs_soa)
+    g.destroy()
+    e1.close(), e2.close()
+
+
+def test_rosenbrock_integrator_inside_a_run_time_compiled_step_kernel():
+    """User expressions are compiled (hipRTC) into the plan's own general kernel, whatever its integrator: with
+    'rodas3' the states are bit-identical to the ahead-of-time kernel's, and the compiled constraint rows are the
+    NumPy evaluation of the same expressions on those states."""
+    torch = _torch()
+    from pcgym_amd import VecEnv
+
+    sc = SC.scenarios()["cstr_expr_cons_raw"]
+    p = copy.deepcopy(sc["env_params"])
+    p.update(integrator="rodas3", rtol=1e-7, atol=1e-9)
+    q = copy.deepcopy(p)
+    q.pop("constraints")
+    for k in ("done_on_cons_vio", "r_penalty"):
+        q.pop(k, None)
+    B = 515
+    for per_env_t in (False, True):
+        ea = VecEnv(copy.deepcopy(p), n_envs=B, seed=2, per_env_t=per_env_t)
+        eb = VecEnv(copy.deepcopy(q), n_envs=B, seed=2, per_env_t=per_env_t)
+        assert ea.spec.user_cons_src is not None and eb.spec.user_cons_src is None
+        ea.reset(), eb.reset()
+        gen = torch.Generator(device="cuda").manual_seed(8)
+        for i in range(5):
+            a = torch.rand((1, B), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+            if not ea.spec.normalise_a:
+                a = torch.tensor(ea.spec.a_low[0] + (a.cpu().numpy() + 1) / 2 * (ea.spec.a_high[0] - ea.spec.a_low[0]), device="cuda")
+            _, _, _, _, info = ea.step(a)
+            eb.step(a)
+            assert torch.equal(ea.x, eb.x) and torch.equal(ea.nsteps, eb.nsteps), (per_env_t, i)
+            x = ea.x.cpu().numpy()
+            u = a.cpu().numpy()[0]
+            if ea.spec.normalise_a:
+                u = (u + 1) * (ea.spec.a_high[0] - ea.spec.a_low[0]) / 2 + ea.spec.a_low[0]
+            ref = sc["ref_env_params"]["constraints"]
+            sp = ea.spec.sp[0, min(i, ea.spec.N - 1)]
+            want = np.stack([np.asarray(ref(np.array([x[0, b], x[1, b], sp]), np.array([u[b]])), dtype=float).reshape(-1)
+                             for b in range(0, B, 37)], axis=1)
+            got = info["g"].cpu().numpy()[:, ::37]
+            assert np.allclose(got, want, rtol=1e-9, atol=1e-9 * np.max(np.abs(want))), (per_env_t, i)
+        ea.close(), eb.close()
