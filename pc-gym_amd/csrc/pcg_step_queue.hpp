@@ -7,19 +7,25 @@
 // (profiles/r1/configs.jsonl).  Re-ordering the batch in HBM by cost was built in round 1 and lost to its scattered
 // 8-byte accesses.  Here the re-balancing happens in LDS, and every HBM access stays coalesced:
 //
-//   phase 1  a 256-thread workgroup loads a tile of T envs (T <= 512: two per lane) the usual SoA way, runs the
-//            pre-integration half of the step (env_pre: action map, disturbances, t == 0 check) and parks state and
-//            held input in LDS [component][slot], together with the initial step size and a cost key;
-//   sort     the tile's slots are ordered by DECREASING cost key (bitonic sort of 512 packed 32-bit words in LDS):
+//   phase 1  a 256-thread workgroup loads a tile of T envs (T <= 1024: four per lane) the usual SoA way, runs the
+//            pre-integration half of the step (env_pre: action map, disturbances, t == 0 check) and parks the held
+//            input in LDS [component][slot], together with the initial step size and a cost key.  The STATE stays where
+//            it is, in HBM/L2: a slot costs 8 (NU + 1) + 12 bytes of LDS instead of 8 (NX + NU + 1) + 12, which is what
+//            lets a tile hold four envs per lane (round 2's first build parked the state too and stopped at two:
+//            BASELINE configs[4]'s extraction segment, 683 envs per workgroup, fell into two half-filled tiles and
+//            lost the re-balancing gain);
+//   sort     the tile's slots are ordered by DECREASING cost key (bitonic sort of 512 / 1024 packed 32-bit words in LDS):
 //            longest-processing-time-first is what keeps the tail short when every lane only sees ~2 envs -- with FIFO
 //            order the queue runs dry early and each wave still waits for its slowest last env (simulated on the
 //            measured step counts: FIFO 1.12x, LPT by this key 1.36x, exact LPT 1.46x);
 //   phase 2  every lane integrates one env at a time from the queue: one attempted RK step per loop iteration for
 //            all busy lanes of the wave; idle lanes pop the next sorted slot (one wave-aggregated LDS atomic per
-//            refill; refills are batched to >= 8 idle lanes because the refill code -- LDS loads + one RHS
-//            evaluation -- runs for the whole wave); the integrated state goes back to its slot;
+//            refill; refills are batched to >= 8 idle lanes because the refill code -- the state's NX 8-byte loads
+//            from the tile's window of the batch (just read by phase 1: L2 hits) + one RHS evaluation -- runs for the
+//            whole wave); the integrated state is written back to its env's place in the batch (NX 8-byte stores per
+//            env step, against ~50,000 instructions of integration);
 //   phase 3  the workgroup runs the post-integration half (env_post: SP slot, constraints, reward, noise,
-//            observation) one env per lane again and stores coalesced.
+//            observation) one env per lane again, reading the new state coalesced, and stores coalesced.
 //
 // Per-env arithmetic does not depend on which lane integrates an env or in which order: results are bitwise
 // independent of the batch order (tested with a permuted batch).  The step-size controller, tolerances and failure
@@ -29,11 +35,12 @@
 
 namespace pcg {
 
-// Four waves share one 512-slot tile.  A single-wave workgroup with its own 128-slot tile (no cross-wave barrier, queue
+// Four waves share one tile.  A single-wave workgroup with its own 128-slot tile (no cross-wave barrier, queue
 // head in a register) was built and measured as well: 1.05x over the classic kernel on BASELINE configs[2] against
 // 1.13x for this shape -- the larger pool is worth more than the barriers cost (profiles/r2/queue_kernel.md).
 constexpr int QBLOCK = 256;        // threads per workgroup (one wave per SIMD)
-constexpr int QSORT = 512;         // sort width = maximum tile: two envs per lane
+constexpr int QSORT = 1024;        // maximum tile = maximum sort width: four envs per lane
+constexpr int QSLOT_BITS = 10;     // slot index bits below the cost key in a sort word
 constexpr int QREFILL = 8;         // idle lanes that trigger a refill (or: no busy lane left)
 
 // model hook: a cheap, monotone proxy of the number of RK steps an env step will take (the sort key)
@@ -153,7 +160,7 @@ PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double d
 // ---- phase 2: the work queue of one tile.  (Tried as a real, non-inlined function so that the loop would own the
 // whole register file: the call ABI's save / restore made it worse -- 772 B of scratch against 140.)
 template <class M>
-PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xs, double* us, const double* hs,
+PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, double* us, const double* hs,
                                                           const uint32_t* sortbuf, int32_t* accs, int32_t* rejs,
                                                           int32_t* flag, int32_t* next, int T, int n, double dt, double dt_edge,
                                                           double h_floor, double rtol, double atol, int max_steps) {
@@ -161,7 +168,7 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xs, double* us, const
   typename M::CKP& kp = *kpp;
   const int tid = threadIdx.x;
   DpLane<NX> L;
-  int slot = tid < n ? (int)(sortbuf[tid] & (QSORT - 1)) : -1;
+  int slot = tid < n ? (int)(sortbuf[tid] & (QSORT - 1)) : -1;  // QSORT - 1 == the QSLOT_BITS mask
   bool fresh = slot >= 0;
   bool drained = n <= QBLOCK;  // wave-uniform: the queue has nothing (left) for this wave
   // every spin is bounded: a lane integrates at most two envs' worth of its tile share plus the refill rounds; the
@@ -173,16 +180,16 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xs, double* us, const
     if (iter > iter_cap) {
       if (slot >= 0) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xs[(size_t)i * T + slot] = __builtin_nan("");
+        for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + slot] = __builtin_nan("");
         accs[slot] = L.acc;
         rejs[slot] = L.rej;
         flag[slot] |= PCG_ST_MAX_STEPS;
       }
       break;
     }
-    if (fresh) {  // (re)fill: state and held input from the slot, k1 = f(x)
+    if (fresh) {  // (re)fill: state from the batch (xg = &x[0][base of the tile]), held input from the slot, k1 = f(x)
 #pragma unroll
-      for (int i = 0; i < NX; ++i) L.x[i] = xs[(size_t)i * T + slot];
+      for (int i = 0; i < NX; ++i) L.x[i] = xg[(size_t)i * xstride + slot];
       double u[NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i) u[i] = us[(size_t)i * T + slot];
@@ -230,7 +237,7 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xs, double* us, const
       if (st >= 0) {  // finished (or gave up): park the result, free the lane
         poison_if_failed<NX>(st, L.x);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xs[(size_t)i * T + slot] = L.x[i];
+        for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + slot] = L.x[i];
         accs[slot] = L.acc;
         rejs[slot] = L.rej;
         flag[slot] |= st;
@@ -240,12 +247,12 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xs, double* us, const
   }
 }
 
-// LDS layout of one tile (T slots): xs[NX][T] | us[NU][T] | hs[T] | sortbuf[QSORT] u32 | acc[T] rej[T] flag[T] i32 | next
+// LDS layout of one tile (T slots): us[NU][T] | hs[T] | sortbuf[QSORT] u32 | acc[T] rej[T] flag[T] i32 | next
 template <class M>
 struct QLayout {
   static constexpr int NU = M::NA + M::NDM;
   PCG_HD static size_t bytes(int T) {
-    return sizeof(double) * (size_t)(M::NX + NU + 1) * T + sizeof(uint32_t) * QSORT + sizeof(int32_t) * 3 * (size_t)T + 16;
+    return sizeof(double) * (size_t)(NU + 1) * T + sizeof(uint32_t) * QSORT + sizeof(int32_t) * 3 * (size_t)T + 16;
   }
 };
 
@@ -257,8 +264,8 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM, NU = NA + NDM;
   const int T = A.q_tile & 0xFFFF;
   const bool nosort = (A.q_tile & 0x10000) != 0;  // measurement switch (PCG_Q_NOSORT)
-  double* xs = lds;
-  double* us = xs + (size_t)NX * T;
+  static_assert(QSORT == (1 << QSLOT_BITS), "slot index field");
+  double* us = lds;
   double* hs = us + (size_t)NU * T;
   uint32_t* sortbuf = reinterpret_cast<uint32_t*>(hs + T);
   int32_t* accs = reinterpret_cast<int32_t*>(sortbuf + QSORT);
@@ -281,7 +288,8 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
     const int64_t base = lo + (int64_t)isub * sub;
     const int n = (int)(min(hi, base + sub) - base);  // envs in this sub-tile
     // ---------------- phase 1: load, pre-integration half, park in LDS ----------------
-    for (int s = tid; s < QSORT; s += QBLOCK) {
+    const int S = n <= QSORT / 2 ? QSORT / 2 : QSORT;  // sort width
+    for (int s = tid; s < S; s += QBLOCK) {
       uint32_t word = (uint32_t)s;  // padding: sorts behind every real slot
       if (s < n) {
         const int64_t e = base + s;
@@ -298,8 +306,6 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
         double k1[NX];
         const double h = dopri5_h_init<NX>(f, x, k1, NX, dt, rtol, atol);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xs[(size_t)i * T + s] = x[i];
-#pragma unroll
         for (int i = 0; i < NU; ++i) us[(size_t)i * T + s] = pre.u[i];
         hs[s] = h;
         flag[s] = pre.done_pre ? 4 : 0;
@@ -307,27 +313,29 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
         if constexpr (has_cost_key<M>::value) key = (float)M::cost_key(kp, pre.u);
         else key = (float)(dt / h);  // generic proxy: steps at the initial step size
         key = nosort ? 1.0f : __builtin_fmaxf(key, 1e-30f);
-        word = ((__float_as_uint(key) >> 9) << 9) | (uint32_t)s;  // positive floats order like their bit patterns
+        word = ((__float_as_uint(key) >> QSLOT_BITS) << QSLOT_BITS) | (uint32_t)s;  // positive floats order like their bit patterns
       }
       sortbuf[s] = word;
     }
     if (tid == 0) *next = QBLOCK < n ? QBLOCK : n;
     __syncthreads();
-    // ---------------- sort the slots by decreasing cost key (bitonic, QSORT words, QSORT/2 threads) ----------------
-    for (int k = 2; k <= QSORT; k <<= 1)
+    // ---------------- sort the slots by decreasing cost key (bitonic, S words, S/2 pairs per stage) ----------------
+    for (int k = 2; k <= S; k <<= 1)
       for (int j = k >> 1; j > 0; j >>= 1) {
-        const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));  // lower index of this thread's pair
-        const int p = i | j;
-        const uint32_t va = sortbuf[i], vb = sortbuf[p];
-        const bool desc = (i & k) == 0;  // descending overall
-        if ((va < vb) == desc) {
-          sortbuf[i] = vb;
-          sortbuf[p] = va;
+        for (int q = tid; q < S / 2; q += QBLOCK) {
+          const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));  // lower index of this pair
+          const int p = i | j;
+          const uint32_t va = sortbuf[i], vb = sortbuf[p];
+          const bool desc = (i & k) == 0;  // descending overall
+          if ((va < vb) == desc) {
+            sortbuf[i] = vb;
+            sortbuf[p] = va;
+          }
         }
         __syncthreads();
       }
     // ---------------- phase 2: the work queue ----------------
-    queue_integrate<M>(&kp, xs, us, hs, sortbuf, accs, rejs, flag, next, T, n, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps);
+    queue_integrate<M>(&kp, A.x + base, B, us, hs, sortbuf, accs, rejs, flag, next, T, n, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps);
     __syncthreads();
     // ---------------- phase 3: post-integration half, coalesced stores ----------------
     for (int s = tid; s < n; s += QBLOCK) {
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
       double x[NX];
       EnvPre<M> pre;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) x[i] = xs[(size_t)i * T + s];
+      for (int i = 0; i < NX; ++i) x[i] = A.x[(size_t)i * B + e];  // written by phase 2 (same workgroup, behind a barrier)
 #pragma unroll
       for (int i = 0; i < NU; ++i) pre.u[i] = us[(size_t)i * T + s];
 #pragma unroll
@@ -366,8 +374,7 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
         reset_env(A, c, e, A.reset_seed);
         continue;
       }
-#pragma unroll
-      for (int i = 0; i < NX; ++i) A.x[(size_t)i * B + e] = x[i];
+      // (the new state is already in place)
       store_out<M>(A, c, e, out, A.obs + e);
       if (PER_ENV_T) A.t[e] = t + 1;
     }
