@@ -8,6 +8,7 @@ from .config import EnvSpec  # noqa: F401
 from .env import StepGraph, VecEnv, make_env, make_vec_env  # noqa: F401
 from .gather import HostGather  # noqa: F401
 from .mixed import MixedVecEnv, make_mixed_sharded_env, mixed_shard_layout  # noqa: F401
+from .reference_engine import hip_integration_engine  # noqa: F401
 from .rollout import collect_rollouts, reproducibility_metric  # noqa: F401
 from .spaces import Box  # noqa: F401
 
