@@ -49,7 +49,7 @@ typedef unsigned long uintptr_t;
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 6
+#define PCG_ABI_VERSION 7
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -109,8 +109,13 @@ enum pcg_model {
   PCG_MODEL_HEAT_EX = 14,      /* model_classes.py:935-1044 nx=24 nu=4           */
   PCG_MODEL_INV_BATCH = 15,    /* model_classes.py:268-293 nx=4, no inputs (one ignored dummy action) */
   PCG_MODEL_OSCILLATORS = 16,  /* model_classes.py:186-216 nx=20 (N=10), no inputs (dummy action)     */
-  PCG_MODEL_COUNT = 17
+  PCG_MODEL_USER = 17,         /* custom_model with an arbitrary (non-affine) right-hand side (pcgym.py:150-153,
+                                  tests/environment/test_make_env_custom_model.py:7-25): given as C source in
+                                  pcg_env_cfg.user_rhs_src and compiled into this plan's kernels with hipRTC;
+                                  nx <= PCG_MAX_NX, na <= PCG_MAX_NA, ndm <= PCG_MAX_NDM, n_params <= PCG_MAX_USER_PARAMS */
+  PCG_MODEL_COUNT = 18
 };
+#define PCG_MAX_USER_PARAMS 64
 
 /* integrators replacing integrator.py:90-107 (CVODES) / :65-88 (diffrax Tsit5) */
 enum pcg_integrator {
@@ -250,6 +255,12 @@ typedef struct pcg_env_cfg {
   const char* user_cons_src;
   const char* user_reward_src;
   const char* jit_include_dir;  /* directory holding pcg_kernels.hpp and its siblings (the library's own csrc/)      */
+  /* PCG_MODEL_USER: the model's right-hand side (the reference's custom_model.__call__(x, u), pcgym.py:150-153) as C
+   * statements that fill dx[0 .. nx-1] (double) from x[] (nx states), u[] (na inputs, then ndm disturbance inputs) and
+   * p[] (n_params parameters = cfg.params).  Compiled with hipRTC into this plan's general step kernel (both time
+   * modes), pcg_integrate and pcg_rhs; any integrator; composes with user_cons_src / user_reward_src.  Not available:
+   * pcg_rollout, per-env uncertain parameters. */
+  const char* user_rhs_src;
 } pcg_env_cfg;
 
 /*

@@ -57,6 +57,35 @@ def _p(a):
     return None if a is None else a.ctypes.data
 
 
+_user_libs = {}  # keep the dlopen handles (and with them the registered function) alive
+
+
+def register_user_rhs(spec):
+    """PCG_MODEL_USER: compile the spec's C statements (the very text the plan hands to hipRTC) with gcc and register
+    the function with the C oracle.  One user model at a time (the oracle keeps a single function pointer)."""
+    import hashlib
+    import tempfile
+
+    src = ("#include <math.h>\nvoid pcg_user_rhs(const double* x, const double* u, const double* p, double* dx) {\n"
+           "  (void)x; (void)u; (void)p;\n" + spec.user_rhs_src + "\n}\n")
+    key = hashlib.sha1(src.encode()).hexdigest()[:16]
+    if key not in _user_libs:
+        d = os.path.join(tempfile.gettempdir(), "pcg_oracle_user")
+        os.makedirs(d, exist_ok=True)
+        c, so = os.path.join(d, key + ".c"), os.path.join(d, key + ".so")
+        if not os.path.exists(so):
+            with open(c, "w") as f:
+                f.write(src)
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", so + ".tmp", c, "-lm"])
+            os.replace(so + ".tmp", so)
+        _user_libs[key] = C.CDLL(so)
+    fn = _user_libs[key].pcg_user_rhs
+    l = lib()
+    l.orc_set_user_rhs.restype = None
+    l.orc_set_user_rhs.argtypes = [C.c_void_p]
+    l.orc_set_user_rhs(C.cast(fn, C.c_void_p))
+
+
 def rhs(model_id, params, x, u):
     """x (nx,B), u (nu,B) SoA float64 -> dx (nx,B)."""
     x = np.ascontiguousarray(x, dtype=np.float64)

@@ -367,6 +367,13 @@ typedef struct {
   const double* p;
 } orc_model;
 
+/* PCG_MODEL_USER (custom_model with an arbitrary right-hand side, pcgym.py:150-153): the tests compile the SAME C
+ * statements the plan hands to hipRTC (pcg_env_cfg.user_rhs_src) with gcc into a small shared object and register the
+ * resulting function here -- the oracle has no expression evaluator of its own. */
+typedef void (*orc_user_rhs_fn)(const double* x, const double* u, const double* p, double* dx);
+static orc_user_rhs_fn g_user_rhs = 0;
+ORC_EXPORT void orc_set_user_rhs(orc_user_rhs_fn f) { g_user_rhs = f; }
+
 static void rhs(const orc_model* m, const double* x, const double* u, double* dx) {
   switch (m->model_id) {
     case PCG_MODEL_CSTR: rhs_cstr(m->p, x, u, m->nu, dx); break;
@@ -385,6 +392,10 @@ static void rhs(const orc_model* m, const double* x, const double* u, double* dx
     case PCG_MODEL_HEAT_EX: rhs_heat_exchanger(m->p, x, u, m->nu, dx); break;
     case PCG_MODEL_INV_BATCH: rhs_invariant_batch(m->p, x, u, m->nu, dx); break;
     case PCG_MODEL_OSCILLATORS: rhs_oscillators(m->p, x, u, m->nu, dx); break;
+    case PCG_MODEL_USER:
+      if (g_user_rhs) g_user_rhs(x, u, m->p, dx);
+      else for (int i = 0; i < m->nx; ++i) dx[i] = NAN; /* not registered: poison, never a silent zero */
+      break;
     default: rhs_affine(m->p, m->nx, x, u, m->nu, dx); break;
   }
 }

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PCG_ABI_VERSION = 6
+PCG_ABI_VERSION = 7
 PCG_MAX_NX = 24
 PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
@@ -15,6 +15,7 @@ PCG_MAX_NSP = 4
 PCG_MAX_NCON = 8
 PCG_MAX_NUNC = 8
 PCG_MAX_PARAMS = 128
+PCG_MAX_USER_PARAMS = 64
 PCG_MAX_NOBS = PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + PCG_MAX_NUNC
 PCG_MAX_NU = PCG_MAX_NA + PCG_MAX_NDM
 PCG_MAX_N = 4096
@@ -122,6 +123,7 @@ class pcg_env_cfg(C.Structure):
         ("user_cons_src", C.c_char_p),
         ("user_reward_src", C.c_char_p),
         ("jit_include_dir", C.c_char_p),
+        ("user_rhs_src", C.c_char_p),
     ]
 
 

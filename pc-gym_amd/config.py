@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import copy
 import ctypes as C
+from collections import OrderedDict
 
 import numpy as np
 
@@ -42,6 +43,7 @@ DEFAULT_INTEGRATOR = {
     M.ME_REACTIVE: "dopri5",
     M.CRYST: "rk4",
     M.AFFINE: "rk4",
+    M.USER: "dopri5",         # nothing is known about a user's right-hand side: adaptive
 }
 # Default RK4 sub-step length per model (model time units): substeps = ceil(dt / h).  Chosen so that
 # the canonical configs (cstr dt=26/60 -> 4, four_tank dt=1000/60 -> 4, cryst dt=1 -> 32, ME dt=1 ->
@@ -394,7 +396,25 @@ class EnvSpec:
         # --- user expressions -> C source --------------------------------------------------
         self.user_cons_src = None
         self.user_reward_src = None
+        self.user_rhs_src = None
         st_names, in_names = list(info["states"]), list(info["inputs"])
+        if getattr(self, "_rhs_exprs", None) is not None:
+            # names: states -> x[i], inputs -> u[j], disturbance inputs -> u[na + j] when the env feeds them (else their
+            # parameter value, like the reference models' "if u.size == ..." branches), parameters -> p[k]
+            rhs, aux = self._rhs_exprs
+            pnames = list(self.model.parameters.keys())
+            names = {n: f"x[{i}]" for i, n in enumerate(st_names)}
+            names.update({n: f"u[{j}]" for j, n in enumerate(in_names)})
+            names.update({n: f"p[{k}]" for k, n in enumerate(pnames)})
+            if self.ndm:
+                names.update({n: f"u[{self.na + j}]" for j, n in enumerate(info["disturbances"])})
+            lines, local = [], set()
+            for k, e in aux.items():
+                lines.append(f"  const double {k} = (double)({compile_expr(e, names, set(), local, f'custom_model aux[{k!r}]')});")
+                local.add(k)
+            for i, e in enumerate(rhs):
+                lines.append(f"  dx[{i}] = (double)({compile_expr(e, names, set(), local, f'custom_model rhs[{i}]')});")
+            self.user_rhs_src = "\n".join(lines)
         if getattr(self, "_cons_exprs", None):
             names = {n: f"x[{i}]" for i, n in enumerate(st_names)}
             names.update({n: f"u[{j}]" for j, n in enumerate(in_names)})
@@ -461,7 +481,7 @@ class EnvSpec:
                 self.x0_unc[:n] = xu[:n]
             self.unc_keys = [k for k in up if k != "x0"]
             if self.unc_keys:
-                if self.model.model_id == M.AFFINE:
+                if self.model.model_id in (M.AFFINE, M.USER):
                     raise ValueError("parameter uncertainty is not available for affine / custom models")
                 names = list(self.model.parameters.keys())
                 for k in self.unc_keys:
@@ -553,6 +573,35 @@ class EnvSpec:
         """custom_model (pcgym.py:150-153).  Registry-shaped objects reuse the
         matching kernel with the object's parameter values; any other object must
         have an affine RHS, which is compiled into PCG_MODEL_AFFINE."""
+        # (a) declarative form with an arbitrary right-hand side: C expressions, compiled at plan creation
+        rhs = m.get("rhs") if isinstance(m, dict) else getattr(m, "rhs_expr", None)
+        if rhs is not None:
+            info = m if isinstance(m, dict) else m.info()
+            states, inputs = list(info["states"]), list(info["inputs"])
+            dist = [d for d in info.get("disturbances", []) if d != "None"]
+            params = OrderedDict((str(k), float(v)) for k, v in dict(info.get("parameters", {})).items())
+            aux = (m.get("aux") if isinstance(m, dict) else getattr(m, "aux_expr", None)) or {}
+            if len(rhs) != len(states):
+                raise ValueError(f"custom_model: {len(rhs)} rhs expressions for {len(states)} states")
+            if not (1 <= len(states) <= abi.PCG_MAX_NX) or not (1 <= len(inputs) <= abi.PCG_MAX_NA) \
+                    or len(dist) > abi.PCG_MAX_NDM or len(params) > abi.PCG_MAX_USER_PARAMS:
+                raise ValueError(f"custom_model: at most {abi.PCG_MAX_NX} states, {abi.PCG_MAX_NA} inputs, "
+                                 f"{abi.PCG_MAX_NDM} disturbance inputs, {abi.PCG_MAX_USER_PARAMS} parameters")
+            for d in dist:
+                if d not in params:
+                    raise ValueError(f"custom_model: disturbance input '{d}' needs a parameter of the same name (its value "
+                                     "when no disturbance is configured; the reference's models do the same, "
+                                     "model_classes.py:43,51)")
+            import re
+
+            for k in aux:
+                if not re.fullmatch(r"[A-Za-z_][A-Za-z_0-9]*", str(k)) or str(k) in _EXPR_FUNCS | {"x", "u", "p", "dx"}:
+                    raise ValueError(f"custom_model: aux name {k!r} is not usable")
+            names = states + inputs + list(params) + [str(k) for k in aux]
+            if len(set(names)) != len(names):
+                raise ValueError(f"custom_model: state / input / parameter / aux names must be distinct: {names}")
+            self._rhs_exprs = ([str(e) for e in rhs], OrderedDict((str(k), str(v)) for k, v in aux.items()))
+            return M.ModelInfo(str(info.get("name", "custom_expr")), M.USER, states, inputs, dist, list(params.items()))
         info = m.info()
         cls = type(m).__name__
         reg = {"cstr": "cstr", "four_tank": "four_tank", "multistage_extraction": "multistage_extraction",
@@ -672,7 +721,9 @@ class EnvSpec:
             cfg.rew_nbox = len(self.rew_box_index)
             cfg.rew_box_index = pi(self.rew_box_index)
             cfg.rew_box_lo, cfg.rew_box_hi = pd(self.rew_box_lo), pd(self.rew_box_hi)
-        if self.user_cons_src is not None or self.user_reward_src is not None:
+        if self.user_rhs_src is not None:
+            cfg.user_rhs_src = self.user_rhs_src.encode()
+        if self.user_cons_src is not None or self.user_reward_src is not None or self.user_rhs_src is not None:
             import os
 
             cfg.user_cons_src = self.user_cons_src.encode() if self.user_cons_src is not None else None

@@ -29,12 +29,21 @@ Kernels kernels_complex_cstr(), kernels_disease(), kernels_batch(), kernels_phot
 Kernels kernels_distillation(), kernels_polymer(), kernels_biofilm(), kernels_heat_ex(), kernels_inv_batch();
 Kernels kernels_oscillators(), kernels_me_sq(), kernels_me_reactive_sq();
 
+// PCG_MODEL_USER has no ahead-of-time kernels: every launch of such a plan goes through its run-time compiled module
+static Kernels kernels_user_stub() {
+  Kernels k;
+  std::memset(&k, 0, sizeof(k));
+  k.nraw = -1;
+  return k;
+}
+
 static const Kernels& kernels(int id) {
   static const Kernels K[PCG_KID_COUNT] = {
       kernels_cstr(),        kernels_four_tank(),   kernels_me(),      kernels_me_reactive(), kernels_cryst(),
       kernels_affine(),      kernels_complex_cstr(), kernels_disease(), kernels_batch(),       kernels_photo(),
       kernels_cstr_series(), kernels_distillation(), kernels_polymer(), kernels_biofilm(),     kernels_heat_ex(),
-      kernels_inv_batch(),   kernels_oscillators(),  kernels_me_sq(),   kernels_me_reactive_sq()};
+      kernels_inv_batch(),   kernels_oscillators(),  kernels_user_stub(), kernels_me_sq(),     kernels_me_reactive_sq()};
+  static_assert(PCG_MODEL_USER == 17 && PCG_KID_ME_SQ == 18 && PCG_KID_COUNT == 20, "kernel table order");
   return K[id];
 }
 
@@ -61,7 +70,7 @@ static const double DEF_OSCILLATORS[] = {10, 1.0, 1.0};
 static const double* const DEFAULTS[] = {DEF_CSTR,        DEF_FOUR_TANK, DEF_ME,    DEF_ME_REACTIVE, DEF_CRYST,
                                          nullptr,         DEF_COMPLEX_CSTR, DEF_DISEASE, DEF_BATCH, DEF_PHOTO,
                                          DEF_CSTR_SERIES, DEF_DISTILLATION, DEF_POLYMER, DEF_BIOFILM,
-                                         DEF_HEAT_EX,     DEF_INV_BATCH,    DEF_OSCILLATORS};
+                                         DEF_HEAT_EX,     DEF_INV_BATCH,    DEF_OSCILLATORS, nullptr};
 
 }  // namespace pcg
 
@@ -89,6 +98,8 @@ struct pcg_plan {
   size_t sched_bytes;
   int cfg_nu;        // na + ndm as the caller counts them
   hipFunction_t jit_fn[2];  // run-time compiled general step kernel with user expressions [per_env_t] (or null)
+  hipFunction_t jit_integ, jit_rhs;  // PCG_MODEL_USER: the run-time compiled test hooks (pcg_integrate / pcg_rhs)
+  int nx;                   // states (the kernel table's for built-in models, the cfg's for PCG_MODEL_USER)
 };
 static constexpr uint32_t PLAN_MAGIC = 0x50434731u;  // 'PCG1'
 
@@ -149,9 +160,23 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   if (!c || !d) return PCG_E_NULL;
   if (c->model_id < 0 || c->model_id >= PCG_MODEL_COUNT) return PCG_E_MODEL;
   if (c->integrator_id < 0 || c->integrator_id >= PCG_INT_COUNT) return PCG_E_MODEL;
-  const Kernels& k = kernels(c->model_id);
+  const bool user = c->model_id == PCG_MODEL_USER;
+  Kernels ku = kernels(c->model_id);
+  if (user) {  // sizes come from the cfg; the right-hand side from cfg.user_rhs_src
+    ku.nx = c->nx; ku.na = c->na; ku.ndm = c->ndm; ku.nraw = c->n_params;
+  }
+  const Kernels& k = ku;
   const int nx = c->nx, na = c->na, ndm = c->ndm, nd = c->nd, nsp = c->nsp, ncon = c->ncon, nrew = c->nrew;
-  if (k.dynamic) {
+  if (user) {
+    if (!c->user_rhs_src) return PCG_E_NULL;
+    if (nx < 1 || nx > PCG_MAX_NX || na < 1 || na > PCG_MAX_NA || ndm < 0 || ndm > PCG_MAX_NDM) return PCG_E_DIM;
+    if (c->n_params < 0 || c->n_params > PCG_MAX_USER_PARAMS) return PCG_E_DIM;
+    if (c->nunc > 0) return PCG_E_UNSUPPORTED;
+  } else if (c->user_rhs_src) {
+    return PCG_E_UNSUPPORTED;
+  }
+  if (user) {
+  } else if (k.dynamic) {
     if (nx < 1 || nx > k.nx || na < 1 || na > k.na || ndm != 0) return PCG_E_DIM;
     if (c->n_params != nx * nx + nx * na + nx) return PCG_E_DIM;
   } else {
@@ -176,7 +201,7 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   if (c->integrator_id != PCG_INT_RK4 && (!(c->rtol > 0) || !(c->atol >= 0) || c->max_steps < 1))
     return PCG_E_VALUE;
   const int nobs = nx + nso + nd + nunc, cnu = na + ndm;
-  if (!c->params || !c->x0 || !c->a_low || !c->a_high || !c->o_low || !c->o_high) return PCG_E_NULL;
+  if ((!c->params && !(user && c->n_params == 0)) || !c->x0 || !c->a_low || !c->a_high || !c->o_low || !c->o_high) return PCG_E_NULL;
   if (nsp && (!c->sp_index || !c->sp)) return PCG_E_NULL;
   if ((nsp || nrew) && !c->r_scale) return PCG_E_NULL;
   if (nrew && !c->rew_index) return PCG_E_NULL;
@@ -190,7 +215,12 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
 
   std::memset(d, 0, sizeof(*d));
   double ddef[PCG_MAX_NDM] = {0, 0, 0, 0};
-  k.prep(c->params, nx, na, k.dynamic ? d->kp_big : d->kp, ddef);
+  if (user) {
+    static_assert(PCG_MAX_USER_PARAMS <= sizeof(d->kp_big) / sizeof(double), "user parameters live in kp_big");
+    for (int i = 0; i < c->n_params; ++i) d->kp_big[i] = c->params[i];
+  } else {
+    k.prep(c->params, nx, na, k.dynamic ? d->kp_big : d->kp, ddef);
+  }
   for (int j = 0; j < k.ndm; ++j) d->d_default[j] = ndm ? c->d_default[j] : ddef[j];
   const bool norm_a = c->flags & PCG_F_NORMALISE_A, norm_o = c->flags & PCG_F_NORMALISE_O;
   const bool compat = c->flags & PCG_F_REF_COMPAT;
@@ -324,7 +354,7 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
     d->con_b[r] = b;
   }
   d->nunc = nunc;
-  if (!k.dynamic)
+  if (!k.dynamic && !user)
     for (int i = 0; i < k.nraw && i < 32; ++i) d->raw[i] = c->params[i];
   for (int j = 0; j < nunc; ++j) {
     if (c->unc_index[j] < 0 || c->unc_index[j] >= k.nraw) return PCG_E_DIM;
@@ -363,11 +393,13 @@ static int kernel_id_for(const pcg_env_cfg* c) {
   return kid;
 }
 
-// ---- run-time compilation of user expressions (pcgym_hip.h: user_cons_src / user_reward_src) ---------------------
+// ---- run-time compilation of user source (pcgym_hip.h: user_cons_src / user_reward_src / user_rhs_src) --------------
 // The general one-env-per-lane step kernel of the plan's model is instantiated from the library's own headers with the
-// user's source spliced in as pcg_user_constraints / pcg_user_reward, compiled with hipRTC, loaded as a module.
+// user's source spliced in as pcg_user_constraints / pcg_user_reward / pcg_user_rhs, compiled with hipRTC, loaded as
+// a module.  A PCG_MODEL_USER plan has no ahead-of-time kernels at all: its module also carries the test hooks.
 struct JitModule {
-  hipFunction_t fn[2];
+  hipFunction_t fn[2];      // step_kernel [per_env_t]
+  hipFunction_t integ, rhs; // PCG_MODEL_USER only
 };
 static std::mutex g_jit_mu;
 static std::map<uint64_t, JitModule> g_jit_cache;
@@ -379,19 +411,26 @@ static uint64_t fnv1a(const std::string& s) {
   return h;
 }
 
-static int jit_step_kernels(const pcg_env_cfg* cfg, int kid, int device, hipFunction_t (&out)[2]) {
+static int jit_kernels(const pcg_env_cfg* cfg, int kid, int device, JitModule* out) {
   if (!cfg->jit_include_dir) return PCG_E_NULL;
+  const bool user = cfg->model_id == PCG_MODEL_USER;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   std::string arch = prop.gcnArchName;
   arch = arch.substr(0, arch.find(':'));
   std::ostringstream src;
+  if (user)
+    src << "#define PCG_USER_NX " << cfg->nx << "\n#define PCG_USER_NA " << cfg->na << "\n#define PCG_USER_NDM " << cfg->ndm
+        << "\n#define PCG_USER_NP " << cfg->n_params << "\n";
   if (cfg->user_cons_src) src << "#define PCG_USER_NCON " << cfg->ncon << "\n";
   if (cfg->user_reward_src) src << "#define PCG_USER_REWARD 1\n";
   src << "#include \"pcg_kernels.hpp\"\n"
       << "static_assert(sizeof(pcg::DevConst) == " << sizeof(DevConst) << " && sizeof(pcg::StepArgs) == " << sizeof(StepArgs)
       << ", \"kernel headers differ from the ones libpcgym_hip.so was built from\");\n"
       << "namespace pcg {\n";
+  if (user)
+    src << "__device__ void pcg_user_rhs(const double* x, const double* u, const double* p, double* dx) {\n"
+        << cfg->user_rhs_src << "\n}\n";
   if (cfg->user_cons_src)
     src << "__device__ void pcg_user_constraints(const double* x, const double* u, double* g) {\n" << cfg->user_cons_src
         << "\n}\n";
@@ -399,7 +438,8 @@ static int jit_step_kernels(const pcg_env_cfg* cfg, int kid, int device, hipFunc
     src << "__device__ double pcg_user_reward(const double* o, const double* x, const double* u, const double* sp, "
            "int violated, int t, int N) {\n  return (double)(" << cfg->user_reward_src << ");\n}\n";
   src << "}\n";
-  std::string names[2];
+  const int nfn = user ? 4 : 2;
+  std::string names[4];
   for (int pe = 0; pe < 2; ++pe) {
     std::ostringstream nm;
     nm << "pcg::step_kernel<pcg::Model<" << kid << ">, " << cfg->integrator_id << ", " << (pe ? "true" : "false")
@@ -407,35 +447,44 @@ static int jit_step_kernels(const pcg_env_cfg* cfg, int kid, int device, hipFunc
     names[pe] = nm.str();
     src << "template __global__ void " << names[pe] << "(const pcg::StepArgs);\n";
   }
+  if (user) {
+    std::ostringstream ni, nr;
+    ni << "pcg::integrate_kernel<pcg::Model<" << kid << ">, " << cfg->integrator_id << ", false>";
+    nr << "pcg::rhs_kernel<pcg::Model<" << kid << "> >";
+    names[2] = ni.str();
+    names[3] = nr.str();
+    src << "template __global__ void " << names[2] << "(pcg::CDevConst*, int64_t, int, double*, const double*, int32_t*);\n";
+    src << "template __global__ void " << names[3] << "(pcg::CDevConst*, int64_t, int, const double*, const double*, double*);\n";
+  }
   const std::string text = src.str();
   const uint64_t key = fnv1a(text + "|" + arch + "|" + std::to_string(PCG_ABI_VERSION) + "|" + std::to_string(device));
   std::lock_guard<std::mutex> lk(g_jit_mu);
   auto hit = g_jit_cache.find(key);
   if (hit != g_jit_cache.end()) {
-    out[0] = hit->second.fn[0];
-    out[1] = hit->second.fn[1];
+    *out = hit->second;
     return PCG_OK;
   }
-  // disk cache: code object + the two lowered kernel names
+  // disk cache: code object + the lowered kernel names
   const char* cdir = std::getenv("PCG_JIT_CACHE");
   std::string dir = cdir ? cdir : "/tmp/pcgym_amd_jit";
   char hex[32];
   std::snprintf(hex, sizeof(hex), "%016llx", (unsigned long long)fnv1a(text + "|" + arch + "|" + std::to_string(PCG_ABI_VERSION)));
   const std::string base = dir + "/" + hex;
-  std::string code, low[2];
+  std::string code, low[4];
   {
     std::ifstream fc(base + ".co", std::ios::binary), fn(base + ".names");
     if (fc && fn) {
       code.assign(std::istreambuf_iterator<char>(fc), std::istreambuf_iterator<char>());
-      std::getline(fn, low[0]);
-      std::getline(fn, low[1]);
-      if (low[0].empty() || low[1].empty()) code.clear();
+      for (int q = 0; q < nfn; ++q) {
+        std::getline(fn, low[q]);
+        if (low[q].empty()) code.clear();
+      }
     }
   }
   if (code.empty()) {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, text.c_str(), "pcg_user_step.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return PCG_E_JIT;
-    for (int pe = 0; pe < 2; ++pe) hiprtcAddNameExpression(prog, names[pe].c_str());
+    for (int q = 0; q < nfn; ++q) hiprtcAddNameExpression(prog, names[q].c_str());
     const std::string oarch = "--offload-arch=" + arch, oinc = std::string("-I") + cfg->jit_include_dir;
     const char* opts[] = {oarch.c_str(), "-O3", "-std=c++17", oinc.c_str()};
     const hiprtcResult cr = hiprtcCompileProgram(prog, 4, opts);
@@ -447,13 +496,13 @@ static int jit_step_kernels(const pcg_env_cfg* cfg, int kid, int device, hipFunc
       hiprtcDestroyProgram(&prog);
       return PCG_E_JIT;
     }
-    for (int pe = 0; pe < 2; ++pe) {
+    for (int q = 0; q < nfn; ++q) {
       const char* ln = nullptr;
-      if (hiprtcGetLoweredName(prog, names[pe].c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
+      if (hiprtcGetLoweredName(prog, names[q].c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
         hiprtcDestroyProgram(&prog);
         return PCG_E_JIT;
       }
-      low[pe] = ln;
+      low[q] = ln;
     }
     size_t cs = 0;
     hiprtcGetCodeSize(prog, &cs);
@@ -465,7 +514,7 @@ static int jit_step_kernels(const pcg_env_cfg* cfg, int kid, int device, hipFunc
     if (std::system(mk.c_str()) == 0) {
       std::ofstream fc(base + ".co.tmp", std::ios::binary), fn(base + ".names");
       fc.write(code.data(), (std::streamsize)code.size());
-      fn << low[0] << "\n" << low[1] << "\n";
+      for (int q = 0; q < nfn; ++q) fn << low[q] << "\n";
       fc.close();
       std::rename((base + ".co.tmp").c_str(), (base + ".co").c_str());
     }
@@ -473,10 +522,14 @@ static int jit_step_kernels(const pcg_env_cfg* cfg, int kid, int device, hipFunc
   hipModule_t mod;
   HIP_TRY(hipModuleLoadData(&mod, code.data()));
   JitModule jm;
+  jm.integ = jm.rhs = nullptr;
   for (int pe = 0; pe < 2; ++pe) HIP_TRY(hipModuleGetFunction(&jm.fn[pe], mod, low[pe].c_str()));
+  if (user) {
+    HIP_TRY(hipModuleGetFunction(&jm.integ, mod, low[2].c_str()));
+    HIP_TRY(hipModuleGetFunction(&jm.rhs, mod, low[3].c_str()));
+  }
   g_jit_cache[key] = jm;
-  out[0] = jm.fn[0];
-  out[1] = jm.fn[1];
+  *out = jm;
   return PCG_OK;
 }
 
@@ -507,6 +560,8 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   p->dC = nullptr;
   p->dsched = nullptr;
   p->jit_fn[0] = p->jit_fn[1] = nullptr;
+  p->jit_integ = p->jit_rhs = nullptr;
+  p->nx = cfg->nx;
   hipError_t e = hipGetDevice(&p->device);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&p->num_cus, hipDeviceAttributeMultiprocessorCount, p->device);
   if (e != hipSuccess) { delete p; return (int)e; }
@@ -531,14 +586,19 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
     delete p;
     return (int)e;
   }
-  if (cfg->user_cons_src || cfg->user_reward_src) {
-    rc = jit_step_kernels(cfg, p->kid, p->device, p->jit_fn);
+  if (cfg->user_cons_src || cfg->user_reward_src || cfg->user_rhs_src) {
+    JitModule jm;
+    rc = jit_kernels(cfg, p->kid, p->device, &jm);
     if (rc != PCG_OK) {
       (void)hipFree(p->dC);
       (void)hipFree(p->dsched);
       delete p;
       return rc;
     }
+    p->jit_fn[0] = jm.fn[0];
+    p->jit_fn[1] = jm.fn[1];
+    p->jit_integ = jm.integ;
+    p->jit_rhs = jm.rhs;
   }
   *out = p;
   return PCG_OK;
@@ -710,8 +770,9 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   const bool per_env_t = io->t != nullptr;
   const Kernels& k = kernels(p->kid);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
-  const int block = tb(lds_st, p->integrator_id, k.nx);
-  size_t shmem = sizeof(double) * integ_lds_doubles(k.nx, p->integrator_id, lds_st);
+  const int knx = p->model_id == PCG_MODEL_USER ? p->nx : k.nx;  // the kernels' compile-time state count
+  const int block = tb(lds_st, p->integrator_id, knx);
+  size_t shmem = sizeof(double) * integ_lds_doubles(knx, p->integrator_id, lds_st);
   const size_t integ_shmem = shmem;
   if (per_env_t) {
     const size_t sb = sizeof(double) * (size_t)(c.nsp + c.nd) * c.N;
@@ -1054,6 +1115,13 @@ int pcg_rhs(pcg_plan* p, int64_t B, const double* x, const double* u, double* dx
   if (!plan_ok(p)) return PCG_E_PLAN;
   if (!x || !u || !dx) return PCG_E_NULL;
   if (B <= 0) return B == 0 ? PCG_OK : PCG_E_DIM;
+  if (p->jit_rhs) {  // PCG_MODEL_USER: the run-time compiled hook
+    const PCG_CONSTANT DevConst* dc = (CDevConst*)p->dC;
+    int nu = p->cfg_nu;
+    void* argv[6] = {&dc, &B, &nu, &x, &u, &dx};
+    return (int)hipModuleLaunchKernel(p->jit_rhs, grid_for(B), 1, 1, BLOCK, 1, 1, 0, (hipStream_t)stream, argv, nullptr);
+  }
+  if (p->model_id == PCG_MODEL_USER) return PCG_E_PLAN;
   const Kernels& k = kernels(p->kid);
   hipLaunchKernelGGL(k.rhs, dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, (CDevConst*)p->dC, B, p->cfg_nu, x, u, dx);
   return (int)hipGetLastError();
@@ -1063,6 +1131,17 @@ int pcg_integrate(pcg_plan* p, int64_t B, double* x, const double* u, int32_t* n
   if (!plan_ok(p)) return PCG_E_PLAN;
   if (!x || !u) return PCG_E_NULL;
   if (B <= 0) return B == 0 ? PCG_OK : PCG_E_DIM;
+  if (p->jit_integ) {  // PCG_MODEL_USER: the run-time compiled hook
+    const int ub = tb(false, p->integrator_id, p->nx);
+    const size_t ush = sizeof(double) * integ_lds_doubles(p->nx, p->integrator_id, false);
+    if (ush > 48 * 1024) return PCG_E_UNSUPPORTED;
+    const PCG_CONSTANT DevConst* dc = (CDevConst*)p->dC;
+    int nu = p->cfg_nu;
+    void* argv[6] = {&dc, &B, &nu, &x, &u, &nsteps};
+    return (int)hipModuleLaunchKernel(p->jit_integ, grid_for(B, ub), 1, 1, ub, 1, 1, (unsigned)ush, (hipStream_t)stream, argv,
+                                      nullptr);
+  }
+  if (p->model_id == PCG_MODEL_USER) return PCG_E_PLAN;
   const Kernels& k = kernels(p->kid);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
   const int block = tb(lds_st, p->integrator_id, k.nx);

@@ -319,6 +319,16 @@ struct RhsFn {
   PCG_DEV void operator()(const R (&x)[M::NX], R (&dx)[M::NX]) const { M::rhs(kp, hold, x, dx); }
 };
 
+// where a model's constants live: the 16-double block, or the 136-double one (affine custom model, user models)
+template <class M, class = void>
+struct kp_is_big : tt::false_type {};
+template <class M>
+struct kp_is_big<M, tt::void_t<decltype(M::KP_BIG)>> : tt::true_type {};
+template <class M>
+PCG_DEV typename M::CKP& model_kp(CDevConst& c) {
+  return *(typename M::CKP*)((M::DYNAMIC || kp_is_big<M>::value) ? c.kp_big : c.kp);
+}
+
 #ifdef PCG_USER_NCON
 // user constraint expressions, defined by the run-time compiled translation unit (pcgym_hip.h: user_cons_src)
 __device__ void pcg_user_constraints(const double* x, const double* u, double* g);
@@ -712,7 +722,7 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
   const int64_t B = A.B;
   const int nx = M::DYNAMIC ? c.nx : NX;
-  typename M::CKP& kp = *(typename M::CKP*)(M::DYNAMIC ? c.kp_big : c.kp);
+  typename M::CKP& kp = model_kp<M>(c);
   EnvPre<M> pre;
   env_pre<M, PER_ENV_T, EXTRAS>(A, c, sched_l, e, t, a_in, x, pre);
   // ---- integrate over [0, dt], u held (pcgym.py:423-429, integrator.py:90-107,163-182) ----
@@ -880,7 +890,7 @@ PCG_DEV void env_step_lean(const StepArgs& A, CDevConst& c, int t, const Pack<W>
   const int na = M::DYNAMIC ? c.na : NA;
   const int N = c.N, nsp = c.nsp, nso = c.nsp_obs, nd = c.nd;
   const int tn = min(t + 1, N - 1), tc = min(t, N - 1);
-  typename M::CKP& kp = *(typename M::CKP*)(M::DYNAMIC ? c.kp_big : c.kp);
+  typename M::CKP& kp = model_kp<M>(c);
   // action map (pcgym.py:371-375) and held disturbance inputs (pcgym.py:386-404)
   R u[NA + NDM];
 #pragma unroll
@@ -1414,7 +1424,7 @@ __global__ __launch_bounds__(BLOCK) void rhs_kernel(CDevConst* C, int64_t B, int
   for (int i = 0; i < NA; ++i) u[i] = (i < na) ? ug[(size_t)i * B + e] : 0.0;
 #pragma unroll
   for (int j = 0; j < NDM; ++j) u[NA + j] = (na + j < nu_rows) ? ug[(size_t)(na + j) * B + e] : c.d_default[j];
-  typename M::CKP& kp = *(typename M::CKP*)(M::DYNAMIC ? c.kp_big : c.kp);
+  typename M::CKP& kp = model_kp<M>(c);
   const typename M::Hold hold = M::hold(kp, u);
   M::rhs(kp, hold, x, dx);
 #pragma unroll
@@ -1439,7 +1449,7 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX)) void integrate_kernel
   for (int i = 0; i < NA; ++i) u[i] = (i < na) ? ug[(size_t)i * B + e] : 0.0;
 #pragma unroll
   for (int j = 0; j < NDM; ++j) u[NA + j] = (na + j < nu_rows) ? ug[(size_t)(na + j) * B + e] : c.d_default[j];
-  typename M::CKP& kp = *(typename M::CKP*)(M::DYNAMIC ? c.kp_big : c.kp);
+  typename M::CKP& kp = model_kp<M>(c);
   const typename M::Hold hold = M::hold(kp, u);
   const RhsFn<M> f{kp, hold};
   if (INTEG == PCG_INT_RK4) {

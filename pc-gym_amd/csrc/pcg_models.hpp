@@ -856,4 +856,45 @@ struct Model<PCG_MODEL_OSCILLATORS> {
   }
 };
 
+// ---------------------------------------------------------------------------
+// PCG_MODEL_USER -- custom_model with an arbitrary right-hand side (pcgym.py:150-153: any object with
+// __call__(x, u) and info()).  Exists only inside a run-time compiled translation unit: pcg_abi.hip defines the sizes
+// as macros, splices the user's statements into pcg_user_rhs() and instantiates the general kernels for this model.
+// Parameters live in the 136-double constant block the affine custom model uses (DevConst::kp_big).
+// ---------------------------------------------------------------------------
+#ifdef PCG_USER_NX
+PCG_DEV void pcg_user_rhs(const double* x, const double* u, const double* p, double* dx);
+template <>
+struct Model<PCG_MODEL_USER> {
+  static constexpr int NX = PCG_USER_NX, NA = PCG_USER_NA, NDM = PCG_USER_NDM, NRAW = PCG_USER_NP;
+  static constexpr bool DYNAMIC = false;
+  static constexpr bool FULL = false;
+  static constexpr bool KP_BIG = true;
+  struct KP {
+    double p[NRAW > 0 ? NRAW : 1];
+  };
+  using CKP = const PCG_CONSTANT KP;
+  template <class R>
+  struct HoldT {
+    R u[NA + NDM];
+  };
+  using Hold = HoldT<double>;
+  PCG_HD static void prep(const double*, int, int, double*, double*) {}
+  template <class R, class K>
+  PCG_DEV static HoldT<R> hold(const K&, const R (&u)[NA + NDM]) {
+    HoldT<R> h;
+#pragma unroll
+    for (int i = 0; i < NA + NDM; ++i) h.u[i] = u[i];
+    return h;
+  }
+  template <class K>
+  PCG_DEV static void rhs(const K& k, const HoldT<double>& h, const double (&x)[NX], double (&dx)[NX]) {
+    double p[NRAW > 0 ? NRAW : 1];
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) p[i] = k.p[i];  // scalar loads from the constant block
+    pcg_user_rhs(x, h.u, p, dx);
+  }
+};
+#endif
+
 }  // namespace pcg

@@ -13,6 +13,7 @@ from collections import OrderedDict
 CSTR, FOUR_TANK, ME, ME_REACTIVE, CRYST, AFFINE = range(6)
 COMPLEX_CSTR, DISEASE, BATCH, PHOTO, CSTR_SERIES, DISTILLATION, POLYMER = range(6, 13)
 BIOFILM, HEAT_EX, INV_BATCH, OSCILLATORS = range(13, 17)
+USER = 17  # custom_model with a C-expression right-hand side, compiled at plan creation (config.py)
 
 
 class ModelInfo:

@@ -314,3 +314,55 @@ def test_reference_side_engine_has_the_reference_interface_and_no_cpu_path():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="GPU|libpcgym_hip"):
             hip_integration_engine(None, SC.scenarios()["cstr_canonical"]["env_params"])
+
+
+def test_custom_model_with_expression_rhs():
+    """custom_model (pcgym.py:150-153) in its declarative form: C expressions per state, compiled at plan creation"""
+    cm = {"states": ["X", "S"], "inputs": ["D"], "disturbances": ["Sf"],
+          "parameters": {"mumax": 0.5, "Ks": 0.2, "Y": 0.4, "Sf": 10.0},
+          "aux": {"mu": "mumax*S/(Ks+S)"}, "rhs": ["(mu - D)*X", "D*(Sf - S) - mu*X/Y"]}
+    p = {"custom_model": cm, "N": 20, "tsim": 10.0, "x0": np.array([1.0, 1.0, 1.2]), "SP": {"X": [1.2] * 20},
+         "a_space": {"low": np.array([0.0]), "high": np.array([0.4])},
+         "o_space": {"low": np.zeros(3), "high": np.array([5.0, 10.0, 5.0])}, "r_scale": {"X": 1.0}}
+    s = EnvSpec(copy.deepcopy(p))
+    assert s.model.model_id == M.USER == abi_model_user() and (s.nx, s.na, s.ndm) == (2, 1, 0)
+    assert s.integrator == "dopri5"
+    # without configured disturbances the disturbance input reads its parameter; with them, the held input vector
+    assert "p[3] - x[1]" in s.user_rhs_src and "const double mu = (double)(p[0]*x[1]/(p[1]+x[1]));" in s.user_rhs_src
+    cfg, _keep = s.to_cfg()
+    assert cfg.model_id == M.USER and cfg.n_params == 4 and cfg.user_rhs_src == s.user_rhs_src.encode()
+    assert cfg.jit_include_dir.decode().endswith("csrc")
+    q = copy.deepcopy(p)
+    q.update(disturbances={"Sf": np.full(20, 9.0)}, disturbance_bounds={"low": np.array([5.0]), "high": np.array([15.0])})
+    s2 = EnvSpec(q)
+    assert s2.ndm == 1 and "u[1] - x[1]" in s2.user_rhs_src
+    # an object in the reference's model protocol (info()) carrying the expressions works the same way
+    class chemostat:
+        rhs_expr = cm["rhs"]
+        aux_expr = cm["aux"]
+
+        def info(self):
+            return {k: cm[k] for k in ("states", "inputs", "disturbances", "parameters")}
+
+    q = copy.deepcopy(p)
+    q["custom_model"] = chemostat()
+    assert EnvSpec(q).user_rhs_src == s.user_rhs_src
+    for key, val, msg in [("rhs", ["(mu - D)*X"], "rhs expressions"), ("rhs", ["(mu - D)*Z", "0"], "unknown name"),
+                          ("rhs", ["X; S", "0"], "single expression"), ("aux", {"exp": "1"}, "not usable"),
+                          ("disturbances", ["Sg"], "same name")]:
+        bad = copy.deepcopy(p)
+        bad["custom_model"][key] = val
+        with pytest.raises(ValueError, match=msg):
+            EnvSpec(bad)
+    bad = copy.deepcopy(p)
+    bad["uncertainty_percentages"] = {"Ks": 0.1}
+    with pytest.raises(ValueError, match="uncertainty"):
+        EnvSpec(bad)
+
+
+def abi_model_user():
+    import os
+    import re
+
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pcgym_hip.h")).read()
+    return int(re.search(r"PCG_MODEL_USER = (\d+)", hdr).group(1))
