@@ -806,7 +806,8 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   }
   // Adaptive plans: the work-queue kernel (lanes that finish early pull the next env from an LDS tile).
   // PCG_OPT_VARIANT 1 keeps the classic one-env-per-lane kernel (A/B measurement), PCG_OPT_LDS_STAGES too.
-  if (p->integrator_id == PCG_INT_DOPRI5 && !lds_st && p->variant == 0 && k.queue[per_env_t ? 1 : 0]) {
+  if (p->integrator_id == PCG_INT_DOPRI5 && !lds_st && p->variant == 0 && k.queue[per_env_t ? 1 : 0] &&
+      (k.queue_default || std::getenv("PCG_Q_FORCE") != nullptr)) {
     const int pe = per_env_t ? 1 : 0;
     const size_t sb = (per_env_t && a.sched_in_lds) ? sizeof(double) * (size_t)(c.nsp + c.nd) * c.N : 0;
     rc = queue_geometry(p, k, pe, sb);

@@ -1520,6 +1520,7 @@ struct Kernels {
   StepFn stream[PCG_INT_COUNT][2];      // persistent streaming kernel [integrator][EPL-1] (entries may be null)
   StepFn step_unc[PCG_INT_COUNT][2]; // per-env parameter uncertainty [integrator][per_env_t] (null for affine)
   StepFn queue[2];                   // DOPRI5 with the in-workgroup work queue [per_env_t] (null for affine)
+  bool queue_default;                // route adaptive plans to it unless told otherwise (models with a cost key)
   size_t (*queue_lds)(int);          // LDS bytes of a tile of T slots
   StepFn pipe[2];                    // RK4 software-pipelined lean kernel [EPL-1] (may be null)
   StepFn pipe_ar[2];                 // the same with the same-launch auto-reset path compiled in [EPL-1]
@@ -1559,6 +1560,11 @@ Kernels make_kernels() {
     k.queue[0] = step_kernel_queue<M, false, true>;
     k.queue[1] = step_kernel_queue<M, true, true>;
     k.queue_lds = QLayout<M>::bytes;
+    // Measured (tools/user_model_probe.py, cstr B = 2^20 at 1e-8: ~4 attempts per env step): 90 us through the queue
+    // against 38 us for the classic kernel -- sorting, parking and refilling cost more than a cheap env's whole
+    // integration.  The queue is the default only where a model declares a cost key, i.e. where the step count is
+    // large and predictable from the input (the extraction models: 1.12-1.23x); PCG_Q_FORCE routes any model to it.
+    k.queue_default = has_cost_key<M>::value;
     k.step_unc[PCG_INT_RK4][0] = step_kernel<M, PCG_INT_RK4, false, false, true, true>;
     k.step_unc[PCG_INT_RK4][1] = step_kernel<M, PCG_INT_RK4, true, false, true, true>;
     k.step_unc[PCG_INT_DOPRI5][0] = step_kernel<M, PCG_INT_DOPRI5, false, false, true, true>;
