@@ -24,6 +24,10 @@ def run(p, B, variant=None, steps=59, reps=5):
     env = VecEnv(p, n_envs=B, seed=1, variant=variant, track_status=False)
     t_create = time.perf_counter() - t0
     acts = [torch.rand((env.spec.na, B), device=env.device, dtype=torch.float64) * 2 - 1 for _ in range(8)]
+    if not env.spec.normalise_a:  # physical actions: spread over the action box
+        lo = torch.tensor(env.spec.a_low, device=env.device)[:, None]
+        hi = torch.tensor(env.spec.a_high, device=env.device)[:, None]
+        acts = [lo + (a + 1) / 2 * (hi - lo) for a in acts]
     best = 1e9
     for r in range(reps):
         env.reset()
