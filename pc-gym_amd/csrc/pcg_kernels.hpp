@@ -702,9 +702,14 @@ PCG_DEV void env_post(const StepArgs& A, CDevConst& c, const double* sched_l, in
   for (int k = 0; k < PCG_MAX_NDM; ++k)
     if (k < nd) out.od[k] = (dv[k] - c.omap[nx + nso + k].lo) * c.omap[nx + nso + k].sc + c.omap[nx + nso + k].off;
   if constexpr (UNC) {
-    for (int j = 0; j < c.nunc; ++j) {
-      const int q = nx + nso + nd + j;
-      out.ounc[j] = (A.p_unc[(size_t)j * B + e] - c.omap[q].lo) * c.omap[q].sc + c.omap[q].off;
+    // static indices into the register array (a run-time trip count would put ounc[] -- and with it the lane's
+    // rebuilt parameter block -- into scratch memory: measured 31.0 -> see profiles/r2/unc_probe.txt)
+#pragma unroll
+    for (int j = 0; j < PCG_MAX_NUNC; ++j) {
+      if (j < c.nunc) {
+        const int q = nx + nso + nd + j;
+        out.ounc[j] = (A.p_unc[(size_t)j * B + e] - c.omap[q].lo) * c.omap[q].sc + c.omap[q].off;
+      }
     }
   }
 }
@@ -734,11 +739,14 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
     double raw[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) raw[i] = c.raw[i];
-    for (int j = 0; j < c.nunc; ++j) {
-      const double v = A.p_unc[(size_t)j * B + e];
-      const int idx = c.unc_index[j];
 #pragma unroll
-      for (int i = 0; i < NR; ++i) raw[i] = (i == idx) ? v : raw[i];
+    for (int j = 0; j < PCG_MAX_NUNC; ++j) {
+      if (j < c.nunc) {
+        const double v = A.p_unc[(size_t)j * B + e];
+        const int idx = c.unc_index[j];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) raw[i] = (i == idx) ? v : raw[i];
+      }
     }
     typename M::KP kpl;
     double dd[PCG_MAX_NDM] = {0.0, 0.0, 0.0, 0.0};
@@ -770,7 +778,9 @@ PCG_DEV void store_obs(const StepArgs& A, CDevConst& c, const EnvOut<M>& out, do
   for (int k = 0; k < PCG_MAX_NDM; ++k)
     if (k < nd) obs_base[(size_t)(nx + nso + k) * B] = out.od[k];
   if constexpr (UNC)
-    for (int j = 0; j < c.nunc; ++j) obs_base[(size_t)(nx + nso + nd + j) * B] = out.ounc[j];
+#pragma unroll
+    for (int j = 0; j < PCG_MAX_NUNC; ++j)
+      if (j < c.nunc) obs_base[(size_t)(nx + nso + nd + j) * B] = out.ounc[j];
 }
 
 template <class M, bool UNC = false>
@@ -790,7 +800,9 @@ PCG_DEV void store_out(const StepArgs& A, CDevConst& c, int64_t e, const EnvOut<
   for (int k = 0; k < PCG_MAX_NDM; ++k)
     if (k < nd) __builtin_nontemporal_store(out.od[k], obs_base + (size_t)(nx + nso + k) * B);
   if constexpr (UNC)
-    for (int j = 0; j < c.nunc; ++j) __builtin_nontemporal_store(out.ounc[j], obs_base + (size_t)(nx + nso + nd + j) * B);
+#pragma unroll
+    for (int j = 0; j < PCG_MAX_NUNC; ++j)
+      if (j < c.nunc) __builtin_nontemporal_store(out.ounc[j], obs_base + (size_t)(nx + nso + nd + j) * B);
   __builtin_nontemporal_store(out.rew, A.rew + e);
   A.done[e] = out.done ? 1 : 0;
   if (A.viol) A.viol[e] = out.viol ? 1 : 0;
