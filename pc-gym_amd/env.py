@@ -193,6 +193,24 @@ class VecEnv:
                    "pcg_reset")
         return self.obs, {}
 
+    def bind_outputs(self, obs_soa=None, rew=None):
+        """Make the kernels write observations / rewards into caller-provided storage from the next call on (zero-copy
+        recording: collect_rollouts hands in one (Nobs, B) / (B,) slice of its trajectory arrays per step).  Tensors must
+        be contiguous float64 on this device with the shapes of ``obs_soa`` / ``rew``; returns the previous pair."""
+        torch = _torch()
+        prev = (self.obs_soa, self.rew)
+        for t, ref in ((obs_soa, self.obs_soa), (rew, self.rew)):
+            if t is not None and (t.shape != ref.shape or t.dtype != torch.float64 or t.device != ref.device
+                                  or not t.is_contiguous()):
+                raise ValueError(f"bind_outputs: need a contiguous float64 tensor of shape {tuple(ref.shape)} on {ref.device}")
+        if obs_soa is not None:
+            self.obs_soa = obs_soa
+            self._buf.obs = obs_soa.data_ptr()
+        if rew is not None:
+            self.rew = rew
+            self._buf.rew = rew.data_ptr()
+        return prev
+
     def _as_soa(self, v, rows, what):
         torch = _torch()
         if what == "action" and self.spec.na_user == 0:  # model without inputs: the kernels' dummy action

@@ -32,28 +32,25 @@ def _torch():
     return torch
 
 
-def _denorm_obs(env, o_soa):
-    """(o + 1) * (high - low) / 2 + low, the inverse map policy_eval applies (:88-90); identity when
-    observations are not normalised."""
+def _affine(env, low, high, active):
+    """de-normalisation (v + 1) * (high - low) / 2 + low as v * half + mid: (half, mid) column tensors, or None"""
+    if not active:
+        return None
     torch = _torch()
-    s = env.spec
-    if not s.normalise_o:
-        return o_soa
-    shp = (-1,) + (1,) * (o_soa.dim() - 1)
-    lo = torch.as_tensor(s.o_low, device=env.device).reshape(shp)
-    hi = torch.as_tensor(s.o_high, device=env.device).reshape(shp)
-    return (o_soa + 1) * (hi - lo) / 2 + lo
+    lo = torch.as_tensor(np.asarray(low, dtype=np.float64), device=env.device)
+    hi = torch.as_tensor(np.asarray(high, dtype=np.float64), device=env.device)
+    return (hi - lo) / 2, (hi + lo) / 2
 
 
-def _denorm_act(env, a_soa):
+def _denorm_(t, hm, dim):
+    """in place, one pass over the data: t[..] = t[..] * half + mid with (half, mid) broadcast along `dim`"""
+    if hm is None:
+        return t
     torch = _torch()
-    s = env.spec
-    if not s.normalise_a:
-        return a_soa
-    shp = (-1,) + (1,) * (a_soa.dim() - 1)
-    lo = torch.as_tensor(s.a_low, device=env.device).reshape(shp)
-    hi = torch.as_tensor(s.a_high, device=env.device).reshape(shp)
-    return (a_soa + 1) * (hi - lo) / 2 + lo
+    shp = [1] * t.dim()
+    shp[dim] = -1
+    half, mid = hm[0].reshape(shp), hm[1].reshape(shp)
+    return torch.addcmul(mid, t, half, out=t)
 
 
 def collect_rollouts(env, policy=None, actions=None):
@@ -61,6 +58,11 @@ def collect_rollouts(env, policy=None, actions=None):
 
     policy  : callable obs(B,Nobs) -> action (B,na)|(na,B) tensor (closed loop), or
     actions : (N, na, B) tensor of policy outputs (open loop; row N-1 is only recorded in ``u``).
+
+    Recording is zero-copy: each step's kernel writes its observation / reward rows straight into the trajectory
+    storage (``VecEnv.bind_outputs``), and the de-normalisation to physical units (policy_evaluation.py:88-106) is one
+    in-place pass over the finished arrays.  ``x`` / ``u`` come back in the reference's axis order ``(Nx, N, B)`` as
+    views of step-major storage.  (Measured at B = 2^20, N = 60, profiles/r2/collector_probe.txt.)
     """
     torch = _torch()
     s = env.spec
@@ -70,12 +72,12 @@ def collect_rollouts(env, policy=None, actions=None):
     if env.per_env_t:
         raise ValueError("collect_rollouts needs a lock-stepped VecEnv")
     f64 = torch.float64
-    x = torch.zeros((s.nobs, N, B), dtype=f64, device=dev)
-    u = torch.zeros((s.na, N, B), dtype=f64, device=dev)
-    r = torch.zeros((1, N, B), dtype=f64, device=dev)
+    o_hm = _affine(env, s.o_low, s.o_high, s.normalise_o)
+    a_hm = _affine(env, s.a_low, s.a_high, s.normalise_a)
+    r = torch.empty((1, N, B), dtype=f64, device=dev)
+    r[0, 0] = 0.0
     g = torch.zeros((s.ncon, N, 1, B), dtype=f64, device=dev) if s.ncon else None
     obs, _ = env.reset()
-    x[:, 0] = _denorm_obs(env, env.obs_soa)
     # the fused rollout records observations and rewards, not the constraint rows; per-env parameters need the
     # per-step kernel; the 20-state DOPRI5 rollout kernel is slower than stepping (tools/rollout_probe.py)
     fused_ok = (not s.ncon and not s.nunc and s.integrator != "rodas3" and s.user_rhs_src is None
@@ -84,36 +86,46 @@ def collect_rollouts(env, policy=None, actions=None):
         actions = actions.to(device=dev, dtype=f64)
         if actions.shape != (N, s.na, B):
             raise ValueError(f"actions must have shape ({N},{s.na},{B})")
-        u[:] = _denorm_act(env, actions.permute(1, 0, 2))
-        if fused_ok:
-            # fused: the kernel writes normalised obs rows directly into x[:, 1:, :] / r[0, 1:, :]
-            a = actions.contiguous()
-            rc = env._lib.pcg_rollout_strided(
-                env._plan, env._bufp, 0, N - 1, a.data_ptr(), s.na * B, B,
-                x[:, 1:].data_ptr(), B, N * B, r[:, 1:].data_ptr(), B,
-                env._episode_seed(), env._stream())
-            _lib.check(rc, "pcg_rollout_strided")
-            env.t += N - 1
-            if s.normalise_o:
-                x[:, 1:] = _denorm_obs(env, x[:, 1:])
-            out = {"r": r, "x": x, "u": u}
-            return out
-        pol = None
-    for i in range(N - 1):
-        a = actions[i] if actions is not None else policy(obs)
-        a = env._as_soa(a, s.na, "action")
+    if actions is not None and fused_ok:
+        # fused: the kernel writes the observation rows directly into x[:, 1:, :] / r[0, 1:, :]
+        x = torch.empty((s.nobs, N, B), dtype=f64, device=dev)
+        x[:, 0] = env.obs_soa
+        a = actions.contiguous()
+        rc = env._lib.pcg_rollout_strided(
+            env._plan, env._bufp, 0, N - 1, a.data_ptr(), s.na * B, B,
+            x[:, 1:].data_ptr(), B, N * B, r[:, 1:].data_ptr(), B,
+            env._episode_seed(), env._stream())
+        _lib.check(rc, "pcg_rollout_strided")
+        env.t += N - 1
+        u = a if a_hm is None else _denorm_(a.clone(), a_hm, 1)  # never scale the caller's tensor in place
+        return {"r": r, "x": _denorm_(x, o_hm, 0), "u": u.permute(1, 0, 2)}
+    # per-step path: step-major storage, the env's kernels write into it
+    xs = torch.empty((N, s.nobs, B), dtype=f64, device=dev)
+    us = torch.empty((N, s.na, B), dtype=f64, device=dev)
+    xs[0] = env.obs_soa
+    rs = r[0]
+    saved = (env.obs_soa, env.rew)
+    try:
+        for i in range(N - 1):
+            a = actions[i] if actions is not None else policy(obs)
+            a = env._as_soa(a, s.na, "action")
+            us[i] = a
+            env.bind_outputs(xs[i + 1], rs[i + 1])
+            obs, rew, done, _, info = env.step(a)
+            if g is not None:
+                if i == 0:
+                    g[:, 0, 0] = env.g_pre
+                g[:, i + 1, 0] = env.g
         if actions is None:
-            u[:, i] = _denorm_act(env, a)
-        obs, rew, done, _, info = env.step(a)
-        x[:, i + 1] = _denorm_obs(env, env.obs_soa)
-        r[0, i + 1] = rew
-        if g is not None:
-            if i == 0:
-                g[:, 0, 0] = env.g_pre
-            g[:, i + 1, 0] = env.g
-    if actions is None:
-        u[:, N - 1] = _denorm_act(env, env._as_soa(policy(obs), s.na, "action"))
-    out = {"r": r, "x": x, "u": u}
+            us[N - 1] = env._as_soa(policy(obs), s.na, "action")
+        else:
+            us[N - 1] = actions[N - 1]
+    finally:
+        last_o, last_r = env.obs_soa, env.rew
+        env.bind_outputs(*saved)
+        env.obs_soa.copy_(last_o)  # the env keeps its own storage; its latest outputs stay readable there
+        env.rew.copy_(last_r)
+    out = {"r": r, "x": _denorm_(xs, o_hm, 1).permute(1, 0, 2), "u": _denorm_(us, a_hm, 1).permute(1, 0, 2)}
     if g is not None:
         out["g"] = g
     return out
