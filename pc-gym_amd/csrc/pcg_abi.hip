@@ -5,6 +5,7 @@
 #include "pcg_step_feat.hpp"
 
 #include <hip/hiprtc.h>
+#include <unistd.h>
 
 #include <fstream>
 #include <map>
@@ -512,11 +513,16 @@ static int jit_kernels(const pcg_env_cfg* cfg, int kid, int device, JitModule* o
     // best effort: a cache that cannot be written is only slower next time
     std::string mk = "mkdir -p '" + dir + "'";
     if (std::system(mk.c_str()) == 0) {
-      std::ofstream fc(base + ".co.tmp", std::ios::binary), fn(base + ".names");
-      fc.write(code.data(), (std::streamsize)code.size());
-      for (int q = 0; q < nfn; ++q) fn << low[q] << "\n";
-      fc.close();
-      std::rename((base + ".co.tmp").c_str(), (base + ".co").c_str());
+      // several processes (one per GPU) may compile the same source at once: private temporaries, both files complete
+      // and closed before they appear, the code object last (a reader needs both and opens the code object first)
+      const std::string tmp = base + "." + std::to_string((long long)getpid());
+      {
+        std::ofstream fc(tmp + ".co", std::ios::binary), fn(tmp + ".names");
+        fc.write(code.data(), (std::streamsize)code.size());
+        for (int q = 0; q < nfn; ++q) fn << low[q] << "\n";
+      }
+      std::rename((tmp + ".names").c_str(), (base + ".names").c_str());
+      std::rename((tmp + ".co").c_str(), (base + ".co").c_str());
     }
   }
   hipModule_t mod;

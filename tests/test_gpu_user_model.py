@@ -209,3 +209,40 @@ def test_user_model_facade_collector_and_errors():
     bad = _chemostat_params(uncertainty_percentages={"mumax": 0.1}, distribution="uniform")
     with pytest.raises(ValueError, match="uncertainty"):
         VecEnv(bad, n_envs=4)
+
+
+_WORKER = r"""
+import copy, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, os.path.join(sys.argv[1], "tests", "golden"))
+import torch
+from pcgym_amd import VecEnv
+from test_gpu_user_model import _chemostat_params
+env = VecEnv(_chemostat_params(), n_envs=512, seed=1)
+env.reset()
+for i in range(3):
+    env.step(torch.full((1, 512), 0.1 * i, dtype=torch.float64, device=env.device))
+torch.cuda.synchronize()
+print("SUM %.17g" % float(env.x.sum()))
+"""
+
+
+def test_concurrent_processes_share_one_jit_cache(tmp_path):
+    """one process per GPU is the deployment shape: several processes compiling the same source into one cache directory
+    at the same moment must all end up with a working module (private temporaries, atomic renames)"""
+    import os
+    import subprocess
+    import sys
+
+    _torch()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCG_JIT_CACHE=str(tmp_path / "jit"))
+    procs = [subprocess.Popen([sys.executable, "-c", _WORKER, root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for _ in range(4)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    sums = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+        sums.append([l for l in so.splitlines() if l.startswith("SUM")][0])
+    assert len(set(sums)) == 1, sums
+    files = sorted(os.listdir(tmp_path / "jit"))
+    assert len([f for f in files if f.endswith(".co")]) == 1 and len([f for f in files if f.endswith(".names")]) == 1, files
