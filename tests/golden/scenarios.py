@@ -315,6 +315,58 @@ def scenarios():
         "x0": np.array([340.0, 320.0, 300.0] * 8 + [330.0]), "r_scale": {"Tt8": 1e-2}, "model": "heat_exchanger"},
         steps=29, action_seed=26)
 
+    # ---- the remaining registry models (pcgym.py:128-148), one recorded make_env episode each --------------
+    S["disease_sp"] = dict(env_params={
+        "N": 30, "tsim": 30.0, "SP": {"I": _halves(30, 0.1, 0.05)},
+        "o_space": {"low": np.array([0.0, 0.0, 0.0, 0.0]), "high": np.array([1.0, 1.0, 1.0, 0.5])},
+        "a_space": {"low": np.array([0.0]), "high": np.array([0.1])},
+        "x0": np.array([0.9, 0.1, 0.0, 0.1]), "r_scale": {"I": 10.0}, "model": "disease"},
+        steps=29, action_seed=41)
+    S["batch_reward"] = dict(env_params={   # terminal reward on the intermediate product
+        "N": 20, "tsim": 10.0, "reward_states": ["Cb"], "maximise_reward": True,
+        "o_space": {"low": np.array([0.0, 0.0, 0.0, 280.0]), "high": np.array([1.0, 1.0, 1.0, 420.0])},
+        "a_space": {"low": np.array([290.0]), "high": np.array([350.0])},
+        "x0": np.array([1.0, 0.0, 0.0, 320.0]), "model": "batch"},
+        steps=19, action_seed=42)
+    S["cstr_series_sp"] = dict(env_params={
+        "N": 20, "tsim": 100.0, "SP": {"T2": _halves(20, 320.0, 325.0)},
+        "o_space": {"low": np.array([0.0, 280.0, 0.0, 280.0, 300.0]), "high": np.array([100.0, 360.0, 100.0, 360.0, 340.0])},
+        "a_space": {"low": np.array([1e-5, 1e-5, 290.0, 290.0]), "high": np.array([5e-5, 5e-5, 310.0, 310.0])},
+        "x0": np.array([50.0, 320.0, 40.0, 320.0, 320.0]), "r_scale": {"T2": 1e-2}, "model": "cstr_series_recycle"},
+        steps=19, action_seed=43)
+    S["polymer_sp"] = dict(env_params={   # short horizon: the reactor runs away thermally within ~10 time units
+        "N": 20, "tsim": 4.0, "SP": {"T": _halves(20, 306.0, 308.0)},
+        "o_space": {"low": np.array([280.0, 0.0, 0.0, 300.0]), "high": np.array([380.0, 10.0, 1.0, 340.0])},
+        "a_space": {"low": np.array([0.005, 290.0, 4.0, 0.3]), "high": np.array([0.01, 310.0, 8.0, 0.6])},
+        "x0": np.array([305.0, 5.0, 0.3, 306.0]), "r_scale": {"T": 1e-2}, "model": "polymerisation_reactor"},
+        steps=19, action_seed=44)
+    S["hydraulic_sp"] = dict(env_params={
+        "N": 30, "tsim": 15.0, "SP": {"q2": _halves(30, 1.0, 0.5)},
+        "o_space": {"low": np.array([-1.0, -1.0, 0.0]), "high": np.array([3.0, 3.0, 2.0])},
+        "a_space": {"low": np.array([-1.0]), "high": np.array([1.0])},
+        "x0": np.array([1.0, 1.0, 1.0]), "model": "hydraulic_tank"},
+        steps=29, action_seed=45)
+    S["nonsmooth_sp"] = dict(env_params={
+        "N": 30, "tsim": 15.0, "SP": {"X1": _halves(30, 0.5, -0.25)},
+        "o_space": {"low": np.array([-2.0, -2.0, -1.0]), "high": np.array([2.0, 2.0, 1.0])},
+        "a_space": {"low": np.array([-1.0]), "high": np.array([1.0])},
+        "x0": np.array([0.0, 0.0, 0.5]), "model": "nonsmooth_control"},
+        steps=29, action_seed=46)
+    # models without inputs: a 1-entry placeholder a_space is what runs through the reference unchanged
+    S["invariant_batch_reward"] = dict(env_params={
+        "N": 20, "tsim": 2.0, "reward_states": ["xC"], "maximise_reward": True,
+        "o_space": {"low": np.zeros(4), "high": np.ones(4)},
+        "a_space": {"low": np.array([0.0]), "high": np.array([1.0])},
+        "x0": np.array([1.0, 0.8, 0.0, 0.0]), "model": "invariant_batch"},
+        steps=19, action_seed=47)
+    S["oscillator_sp"] = dict(env_params={
+        "N": 20, "tsim": 10.0, "SP": {"x1": _halves(20, 0.0, 0.0)},
+        "o_space": {"low": np.array([-3.0] * 20 + [-1.0]), "high": np.array([3.0] * 20 + [1.0])},
+        "a_space": {"low": np.array([0.0]), "high": np.array([1.0])},
+        "x0": np.array([1.0, 0.5, 0.0, -0.5, -1.0, -0.5, 0.0, 0.5, 1.0, 0.5] + [0.0] * 10 + [0.0]),
+        "model": "coupled_oscillator"},
+        steps=19, action_seed=48)
+
     # ---- the custom_reward family of the paper scripts, declarative on our side ------------------------
     # (the reference run uses the callable named in ref_custom_reward, loaded by gen_golden.py from the
     # reference tree; the fixture only holds the recorded tuples)

@@ -48,6 +48,14 @@ TIGHT = {
     "first_order_system": dict(integrator="rk4", substeps=64),
     "biofilm_reactor": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
     "heat_exchanger": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
+    "disease": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
+    "batch": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
+    "cstr_series_recycle": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
+    "polymerisation_reactor": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
+    "hydraulic_tank": dict(integrator="rk4", substeps=64),
+    "nonsmooth_control": dict(integrator="rk4", substeps=64),
+    "invariant_batch": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
+    "coupled_oscillator": dict(integrator="dopri5", rtol=1e-12, atol=1e-14),
 }
 
 
