@@ -53,7 +53,21 @@ def test_engine_replays_the_trajectories_the_reference_ships(fix, model):
             assert xj.shape == (nx,) and np.array_equal(xj, xf[:, 0])
 
 
-@pytest.mark.parametrize("name", ["cstr_canonical", "four_tank_canonical", "me_canonical", "cstr_cons_pen_norm"])
+def _plain_scenarios():
+    """recorded scenarios whose uk is the mapped action alone (no disturbance inputs, no action increments) and whose
+    model has inputs -- the cases where uk can be rebuilt from the recording without re-implementing make_env.step"""
+    out = []
+    for k, v in SC.scenarios().items():
+        p = v["env_params"]
+        if p.get("model") is None or p.get("disturbances") is not None or p.get("a_delta") or "ref_env_params" in v:
+            continue
+        if not M.get_model(p["model"]).inputs:
+            continue
+        out.append(k)
+    return sorted(out)
+
+
+@pytest.mark.parametrize("name", _plain_scenarios())
 def test_engine_reproduces_make_env_recordings(name):
     """the recorded reference run: state[i] --(action map, pcgym.py:371-379)--> uk --engine--> state[i+1][:nx]"""
     from pcgym_amd import hip_integration_engine
@@ -72,7 +86,7 @@ def test_engine_reproduces_make_env_recordings(name):
         uk = (a + 1) * (spec.a_high - spec.a_low) / 2 + spec.a_low if spec.normalise_a else a
         xf = eng.casadi_step(st[i], uk)["xf"].full()[:, 0]
         want = st[i + 1][: spec.nx]
-        assert np.all(np.abs(xf - want) <= 2e-9 * np.maximum(np.abs(want), 1e-3)), (name, i)
+        assert np.all(np.abs(xf - want) <= 2e-9 * np.maximum(np.abs(want), 1e-3) + 5e-10), (name, i)
 
 
 def test_engine_argument_and_failure_behaviour():
