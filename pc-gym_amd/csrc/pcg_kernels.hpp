@@ -150,6 +150,7 @@ struct StepArgs {
   // element strides of the sequences: (step, component); the env index is always unit-stride
   int64_t a_ss, a_cs, o_ss, o_cs, r_ss;
   int32_t T;
+  float q_w;             // work-queue kernel: weight of ln(scaled |f(x0)|) in the sort key (the transient's share)
 };
 
 // ---------------------------------------------------------------------------

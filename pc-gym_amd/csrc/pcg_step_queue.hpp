@@ -61,12 +61,13 @@ struct DpLane {
 // k1 = f(x) and the initial step size (Hairer, Norsett & Wanner II.4) -- the statements of dopri5() before its loop
 template <int NX, class F>
 PCG_DEV double dopri5_h_init(const F& f, const double (&x)[NX], double (&k1)[NX], int n, double dt, double rtol,
-                             double atol) {
+                             double atol, double& d1_out) {
 #pragma clang fp contract(off)
   double y[NX], w[NX];
   f(x, k1);
   const double d0 = rms_scaled<NX>(x, x, x, n, rtol, atol);
   const double d1 = rms_scaled<NX>(k1, x, x, n, rtol, atol);
+  d1_out = d1;
   double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
   h0 = fmin(h0, dt);
 #pragma unroll
@@ -304,13 +305,19 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
         const typename M::Hold hold = M::hold(kp, pre.u);
         const RhsFn<M> f{kp, hold};
         double k1[NX];
-        const double h = dopri5_h_init<NX>(f, x, k1, NX, dt, rtol, atol);
+        double d1;
+        const double h = dopri5_h_init<NX>(f, x, k1, NX, dt, rtol, atol, d1);
 #pragma unroll
         for (int i = 0; i < NU; ++i) us[(size_t)i * T + s] = pre.u[i];
         hs[s] = h;
         flag[s] = pre.done_pre ? 4 : 0;
         float key;
-        if constexpr (has_cost_key<M>::value) key = (float)M::cost_key(kp, pre.u);
+        // stability-limited part (the model's rate x dt) + the initial transient's share (ln of the scaled |f(x0)|,
+        // already computed for the initial step size).  A least-squares fit on BASELINE configs[2] puts the weight at
+        // 33 (correlation with the measured step counts 0.84 -> 0.96, list-scheduling efficiency of independent lanes
+        // 0.836 -> 0.862); lock-stepped waves prefer less: measured optimum ~20 (pcg_abi.hip, profiles/r2/queue_w_sweep.txt)
+        if constexpr (has_cost_key<M>::value)
+          key = (float)(M::cost_key(kp, pre.u) * dt) + A.q_w * __builtin_logf(__builtin_fmaxf((float)d1, 1.0f));
         else key = (float)(dt / h);  // generic proxy: steps at the initial step size
         key = nosort ? 1.0f : __builtin_fmaxf(key, 1e-30f);
         word = ((__float_as_uint(key) >> QSLOT_BITS) << QSLOT_BITS) | (uint32_t)s;  // positive floats order like their bit patterns
