@@ -825,6 +825,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
         if (tv >= QBLOCK && tv <= a.q_tile) a.q_tile = tv;
       }
       if (std::getenv("PCG_Q_NOSORT")) a.q_tile |= 0x10000;  // measurement switch: FIFO order
+      if (const char* ev = std::getenv("PCG_Q_REFILL")) a.q_tile |= (std::atoi(ev) & 0x7F) << 20;  // measurement switch
       a.q_w = 20.0f;  // tools/queue_w_sweep.sh: 0 / 10 / 20 / 33 -> me10 0.689 / 0.684 / 0.683 / 0.719 ms, configs[4] shard 0.964 / 0.938 / 0.920 / 0.924 ms
       if (const char* ev = std::getenv("PCG_Q_W")) a.q_w = (float)std::atof(ev);  // measurement switch: key weight
       int64_t nwg = (int64_t)p->num_cus * p->q_bpc[pe];

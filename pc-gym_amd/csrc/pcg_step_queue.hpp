@@ -41,7 +41,7 @@ namespace pcg {
 constexpr int QBLOCK = 256;        // threads per workgroup (one wave per SIMD)
 constexpr int QSORT = 1024;        // maximum tile = maximum sort width: four envs per lane
 constexpr int QSLOT_BITS = 10;     // slot index bits below the cost key in a sort word
-constexpr int QREFILL = 8;         // idle lanes that trigger a refill (or: no busy lane left)
+constexpr int QREFILL = 8;         // idle lanes that trigger a refill in a well-filled tile (or: no busy lane left)
 
 // model hook: a cheap, monotone proxy of the number of RK steps an env step will take (the sort key)
 template <class M, class = void>
@@ -163,7 +163,7 @@ PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double d
 template <class M>
 PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, double* us, const double* hs,
                                                           const uint32_t* sortbuf, int32_t* accs, int32_t* rejs,
-                                                          int32_t* flag, int32_t* next, int T, int n, double dt, double dt_edge,
+                                                          int32_t* flag, int32_t* next, int T, int n, int refill, double dt, double dt_edge,
                                                           double h_floor, double rtol, double atol, int max_steps) {
   constexpr int NX = M::NX, NU = M::NA + M::NDM;
   typename M::CKP& kp = *kpp;
@@ -208,7 +208,7 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
     const int n_idle = 64 - __popcll(bm);
     // the shared queue head is only touched when this wave could use it (>= QREFILL idle lanes, or nothing left
     // in flight) and has not seen it empty yet: the steady-state iteration does no LDS access at all
-    if (!drained && (n_idle >= QREFILL || bm == 0ull)) {
+    if (!drained && (n_idle >= refill || bm == 0ull)) {
       // idle lanes pop: one LDS atomic per wave, lane r of the idle set takes sorted position head + r
       const unsigned long long im = ~bm;
       const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
@@ -265,6 +265,8 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM, NU = NA + NDM;
   const int T = A.q_tile & 0xFFFF;
   const bool nosort = (A.q_tile & 0x10000) != 0;  // measurement switch (PCG_Q_NOSORT)
+  const int refill_hi = (A.q_tile >> 20) & 0x7F;  // measurement switch (PCG_Q_REFILL); 0 = the default
+  // (the default depends on the tile: see where it is used)
   static_assert(QSORT == (1 << QSLOT_BITS), "slot index field");
   double* us = lds;
   double* hs = us + (size_t)NU * T;
@@ -342,7 +344,11 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
         __syncthreads();
       }
     // ---------------- phase 2: the work queue ----------------
-    queue_integrate<M>(&kp, A.x + base, B, us, hs, sortbuf, accs, rejs, flag, next, T, n, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps);
+    // idle lanes that trigger a refill: with at most two envs per lane every lane refills once and waiting for company
+    // only idles it (me10: 0.678 ms at 8, 0.656 at 2); with more envs per lane the refill code -- executed by the whole
+    // wave -- is worth batching (configs[4] shard: 0.916 ms at 8, 0.929 at 2; profiles/r2/queue_refill_sweep.txt)
+    const int refill = refill_hi ? refill_hi : (n <= 2 * QBLOCK ? 2 : QREFILL);
+    queue_integrate<M>(&kp, A.x + base, B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps);
     __syncthreads();
     // ---------------- phase 3: post-integration half, coalesced stores ----------------
     for (int s = tid; s < n; s += QBLOCK) {
