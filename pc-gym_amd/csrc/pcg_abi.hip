@@ -697,7 +697,7 @@ static int resident_blocks(StepFn fn) {
 }
 
 // Launch geometry of the DOPRI5 work-queue kernel (pcg_step_queue.hpp): resident 256-thread workgroups per CU by the
-// register allocation (= waves per SIMD), the largest tile (<= 512 slots, two per lane) whose LDS fits that many
+// register allocation (= waves per SIMD), the largest tile (<= 1024 slots, four per lane) whose LDS fits that many
 // workgroups in 160 KB.
 static int queue_geometry(pcg_plan* p, const Kernels& k, int pe, size_t sched_bytes) {
   if (p->q_tile[pe] != 0) return PCG_OK;

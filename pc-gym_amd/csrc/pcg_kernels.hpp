@@ -140,7 +140,7 @@ struct StepArgs {
   int32_t t_scalar;
   int32_t sched_in_lds;  // per-env-t kernels: schedules staged in LDS
   int32_t nt_stores;     // stream kernels: non-temporal stores for obs / reward
-  int32_t q_tile;        // work-queue kernel: slots of the LDS tile (<= 512)
+  int32_t q_tile;        // work-queue kernel: slots of the LDS tile (<= 1024) | measurement switches in the high bits
   int32_t auto_reset;    // per-env-t kernels: reset the envs that finished in this step (pcg_step_autoreset)
   uint64_t reset_seed;   // RNG key of those resets
   // rollout
