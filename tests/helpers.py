@@ -79,6 +79,9 @@ def tight_for(env_params):
 # identical counts and BIT-IDENTICAL states; the accuracy-limited models were at 100 % / 1e-13 throughout.
 # A model listed here would be compared statistically instead (none is).
 STABILITY_LIMITED = ()
+# models whose right-hand side is an exactly specified operation sequence with a bit-identical twin in the oracle: the
+# step sequences are identical by construction, for every env, always
+BIT_EXACT_RHS = ("multistage_extraction",)
 
 
 def adaptive_check(model_name, x_gpu, x_orc, ns_gpu, ns_orc, tag, tol=1e-11, x_truth=None):
@@ -94,7 +97,17 @@ def adaptive_check(model_name, x_gpu, x_orc, ns_gpu, ns_orc, tag, tol=1e-11, x_t
             et = np.max(np.abs(x_gpu - x_truth) / xs, axis=0)
             eo = np.max(np.abs(x_orc - x_truth) / xs, axis=0)
             assert et.max() <= 3e-6 and et.max() <= 3 * max(eo.max(), 1e-7), (tag, "vs 1e-12 solve", et.max(), eo.max())
-    else:
+    elif model_name in BIT_EXACT_RHS:
         assert same.all(), (tag, "identical step counts", same.mean())
         assert ex.max() <= tol, (tag, ex.max())
+    else:
+        # A right-hand side that is not bit-identical on the two sides (contraction, OCML vs libm) perturbs the error
+        # norm by ~1e-8 relative; a decision that lands that close to a threshold (E = 1, or an edge of the 6-bit factor
+        # grid) flips.  Soak run, 400 random configurations x 770 envs x ~20 steps (PCG_FUZZ_SEEDS=400): one env step
+        # with 8 instead of 9 accepted steps, its state 2.6e-13 from the oracle's.  So: (almost) every env identical,
+        # the rest within the integrator's own accuracy class.
+        assert same.mean() >= 0.998, (tag, "identical step counts", same.mean())
+        assert ex[same].max() <= tol, (tag, ex[same].max())
+        if not same.all():
+            assert ex[~same].max() <= max(1e3 * tol, 1e-9), (tag, "envs with another step sequence", ex[~same].max())
     return ex

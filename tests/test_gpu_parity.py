@@ -8,6 +8,8 @@ by using tight integrator settings so the epilogue is checked at ~1e-9.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -841,7 +843,7 @@ def test_mixed_model_batch_segments_match_single_model_envs():
     sh.close()
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PCG_FUZZ_SEEDS", "20"))))  # more seeds for a soak run
 def test_random_configurations_vs_oracle(seed):
     """random env_params (the generator of tests/test_oracle_vs_reference_live.py, which pins the oracle to the
     reference on the same family): every flag combination must reach a kernel that agrees with the oracle."""
@@ -890,7 +892,7 @@ def test_random_configurations_vs_oracle(seed):
     env.close()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PCG_FUZZ_SEEDS", "20")) // 2))
 def test_random_configurations_rollout_equals_stepping(seed):
     """pcg_rollout (T steps fused, state in registers) against T pcg_step launches on random configurations"""
     torch = _torch()
