@@ -1313,3 +1313,44 @@ def test_parameter_uncertainty_vs_oracle():
             # the parameters really differ between envs and matter for the dynamics
             assert np.std(env.x.cpu().numpy()[0]) > 0
             env.close()
+
+
+@pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("PCG_FUZZ_SEEDS", "20")) // 3)))
+def test_random_configurations_rosenbrock_vs_oracle(seed):
+    """the same random env_params family through the stiff-capable integrator: every step a one-step comparison from a
+    common state (the difference-quotient Jacobian amplifies last-bit differences, see ROS_TOL)"""
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+    from test_oracle_vs_reference_live import _random_params
+
+    rng = np.random.default_rng(9000 + seed)
+    p = _random_params(rng)
+    p.update(integrator="rodas3", rtol=1e-6, atol=1e-8)
+    per_env_t = bool(rng.integers(0, 2))
+    B = int(rng.choice([130, 257]))
+    try:
+        env = VecEnv(copy.deepcopy(p), n_envs=B, seed=seed, per_env_t=per_env_t)
+    except ValueError:
+        return
+    spec = env.spec
+    orc = O.OracleEnv(spec, B, seed=seed, per_env_t=per_env_t)
+    env.reset()
+    orc.reset()
+    for i in range(min(spec.N - 1, 12)):
+        a = rng.uniform(-1, 1, (spec.na, B))
+        if not spec.normalise_a:
+            a = (a + 1) * (spec.a_high - spec.a_low)[:, None] / 2 + spec.a_low[:, None]
+        og, rg, dg, _, _ = env.step(torch.tensor(a, device=env.device))
+        oc, rc, dc = orc.step(a)
+        same = np.all(env.nsteps.cpu().numpy() == orc.nsteps, axis=0)
+        xs = np.maximum(np.abs(orc.x), 1e-6 * np.max(np.abs(orc.x), axis=1, keepdims=True))
+        ex = np.max(np.abs(env.x.cpu().numpy() - orc.x) / xs, axis=0)
+        assert same.mean() >= 0.99, (seed, i, spec.model.name, same.mean())
+        assert ex[same].max() <= ROS_TOL * 4 and ex.max() <= 1e-5, (seed, i, spec.model.name, ex[same].max(), ex.max())
+        assert np.array_equal(env.status.cpu().numpy(), orc.status), (seed, i)
+        assert np.mean(dg.cpu().numpy().astype(np.uint8) == dc) >= 0.99, (seed, i)
+        env.x.copy_(torch.tensor(orc.x, device=env.device))
+    env.close()
