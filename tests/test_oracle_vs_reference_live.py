@@ -1,6 +1,7 @@
 """CPU, build container only: RANDOMISED differential test of the oracle against the reference itself.
 
-The committed fixtures pin the oracle on 26 hand-written scenarios; here env_params are drawn at random (model,
+The committed fixtures pin the oracle on 36 hand-written scenarios; here env_params are drawn at random (model --
+every registry model that has inputs --,
 set-point schedules, normalisation flags, a_delta, affine constraints with penalty / done-on-violation,
 disturbances, batch reward, partial observation) and the reference's own `make_env` -- imported from
 /root/reference behind the inert stubs of tests/golden/gen_golden.py, its CVODES call replaced by LSODA(1e-12) --
@@ -44,8 +45,12 @@ def _random_params(rng):
     import scenarios as SC
 
     S = SC.scenarios()
-    base = rng.choice(["cstr_canonical", "four_tank_canonical", "me_canonical", "cryst_adelta", "cstr_dist_Ti",
-                       "cstr_batch_reward"])
+    # (the first six entries are the original family: their share of the draws stays at one half)
+    star = ["cstr_canonical", "four_tank_canonical", "me_canonical", "cryst_adelta", "cstr_dist_Ti", "cstr_batch_reward"]
+    rest = ["complex_cstr_sp", "photo_batch_reward", "distillation_sp", "first_order_sp", "biofilm_sp",
+            "heat_exchanger_sp", "me_reactive", "disease_sp", "batch_reward", "cstr_series_sp", "polymer_sp",
+            "hydraulic_sp", "nonsmooth_sp"]
+    base = rng.choice(star) if rng.random() < 0.5 else rng.choice(rest)
     p = copy.deepcopy(S[base]["env_params"])
     N = int(rng.integers(8, 20))
     dt = float(p["tsim"]) / p["N"]
@@ -64,7 +69,9 @@ def _random_params(rng):
     p["normalise_o"] = bool(rng.integers(0, 2))
     if not p.get("a_delta"):
         p["normalise_a"] = norm_a
-    nx = {"cstr": 2, "four_tank": 4, "multistage_extraction": 10, "crystallization": 7}[p["model"]]
+    from pcgym_amd import models as _M
+
+    nx = len(_M.get_model(p["model"]).states)
     nobs = len(p["o_space"]["low"])
     na = len(p["a_space"]["low"])
     nu = na + (len(p["disturbances"]) if p.get("disturbances") is not None else 0)
@@ -89,7 +96,7 @@ def _random_params(rng):
     return p
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PCG_LIVE_SEEDS", "48"))))
 def test_random_config_oracle_matches_reference(ref, seed):
     from oracle import oracle as O
     from pcgym_amd.config import EnvSpec
