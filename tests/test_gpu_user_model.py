@@ -246,3 +246,63 @@ def test_concurrent_processes_share_one_jit_cache(tmp_path):
     assert len(set(sums)) == 1, sums
     files = sorted(os.listdir(tmp_path / "jit"))
     assert len([f for f in files if f.endswith(".co")]) == 1 and len([f for f in files if f.endswith(".names")]) == 1, files
+
+
+def test_user_model_at_the_size_limits():
+    """24 states, 5 inputs, 4 disturbance inputs, 64 parameters: a banded bilinear system generated programmatically;
+    RHS / integration / full steps against the oracle running the same statements"""
+    torch = _torch()
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+    from pcgym_amd import _abi as abi
+    from pcgym_amd.config import EnvSpec
+    from test_gpu_parity import _plan_for
+
+    nx, na, ndm, npar = abi.PCG_MAX_NX, abi.PCG_MAX_NA, abi.PCG_MAX_NDM, abi.PCG_MAX_USER_PARAMS
+    rng = np.random.default_rng(12)
+    states = [f"s{i}" for i in range(nx)]
+    inputs = [f"v{j}" for j in range(na)]
+    dist = [f"w{j}" for j in range(ndm)]
+    params = {f"k{q}": float(rng.uniform(0.2, 1.0)) for q in range(npar - ndm)}
+    params.update({d: 0.1 * (j + 1) for j, d in enumerate(dist)})
+    assert len(params) == npar
+    pk = list(params)
+    rhs = []
+    for i in range(nx):
+        a, b, c = pk[i % (npar - ndm)], pk[(2 * i + 7) % (npar - ndm)], pk[(3 * i + 11) % (npar - ndm)]
+        rhs.append(f"-{a}*s{i} + 0.3*{b}*(s{(i + 1) % nx} - s{i}) + 0.1*{c}*v{i % na}*s{(i + 5) % nx}/(1.0 + s{i}*s{i}) + {dist[i % ndm]}")
+    cm = {"states": states, "inputs": inputs, "disturbances": dist, "parameters": params, "rhs": rhs}
+    N = 12
+    p = {"custom_model": cm, "N": N, "tsim": 6.0, "x0": np.concatenate([rng.uniform(0.2, 1.0, nx), [0.5]]),
+         "SP": {"s3": [0.5] * N}, "a_space": {"low": -np.ones(na), "high": np.ones(na)},
+         "o_space": {"low": -5 * np.ones(nx + 1), "high": 5 * np.ones(nx + 1)},
+         "disturbances": {d: 0.1 * (j + 1) + 0.05 * np.sin(np.arange(N) + j) for j, d in enumerate(dist)},
+         "disturbance_bounds": {"low": -np.ones(ndm), "high": np.ones(ndm)}, "integrator": "dopri5", "rtol": 1e-9,
+         "atol": 1e-11, "normalise_a": False, "normalise_o": True}
+    spec = EnvSpec(copy.deepcopy(p))
+    assert (spec.nx, spec.na, spec.ndm, len(spec.param_vector())) == (nx, na, ndm, npar)
+    O.register_user_rhs(spec)
+    lib, plan = _plan_for(spec, torch)
+    B = 700
+    x = rng.uniform(-1, 1, (nx, B))
+    u = rng.uniform(-1, 1, (na + ndm, B))
+    xg, ug = torch.tensor(x, device="cuda"), torch.tensor(u, device="cuda")
+    dx = torch.zeros_like(xg)
+    assert lib.pcg_rhs(plan, B, xg.data_ptr(), ug.data_ptr(), dx.data_ptr(), None) == 0
+    want = O.rhs(spec.model.model_id, spec.param_vector(), x, u)
+    assert np.max(np.abs(dx.cpu().numpy() - want)) <= 1e-14 * max(1.0, np.max(np.abs(want)))
+    ns = torch.zeros((2, B), dtype=torch.int32, device="cuda")
+    assert lib.pcg_integrate(plan, B, xg.data_ptr(), ug.data_ptr(), ns.data_ptr(), None) == 0
+    xo, nso = O.integrate(spec, x, u)
+    H.adaptive_check("user", xg.cpu().numpy(), xo, ns.cpu().numpy(), nso, "max sizes", tol=1e-11)
+    lib.pcg_plan_destroy(plan)
+    env = VecEnv(copy.deepcopy(p), n_envs=B, seed=2)
+    orc = O.OracleEnv(env.spec, B, seed=2)
+    env.reset(), orc.reset()
+    for i in range(N - 1):
+        a = rng.uniform(-1, 1, (na, B))
+        o, r, d, _, _ = env.step(torch.tensor(a, device=env.device))
+        oc, rc, dc = orc.step(a)
+        H.adaptive_check("user", env.x.cpu().numpy(), orc.x, env.nsteps.cpu().numpy(), orc.nsteps, i, tol=1e-10)
+        assert np.max(np.abs(o.cpu().numpy().T - oc)) <= 1e-10 and np.allclose(r.cpu().numpy(), rc, rtol=1e-9, atol=1e-11)
+    env.close()
