@@ -227,29 +227,26 @@ PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double 
     for (int i = 0; i < NX; ++i)
       w[i] = h * lc6(e1, K.get(0, i), e3, K.get(2, i), e4, K.get(3, i), e5, K.get(4, i), e6, K.get(5, i), e7, kk[i]);
     const double E2 = ms_scaled<NX>(w, x, y, n, rtol, atol);  // accept iff E = sqrt(E2) < 1
-    if (E2 < 1.0) {
-      double fac = fmin(10.0, fmax(0.2, ctrl_pow(E2, 0.9)));
-      if (rejected_last && fac > 1.0) fac = 1.0;
-      t += h;
-      h *= fac;
+    // one evaluation of the controller for both outcomes, the outcome applied by selects (in a wave of 64 lanes some
+    // lane rejects in almost every iteration, so an if / else with the controller in both arms executed both; the
+    // values are the same, bit for bit)
+    const bool ok = E2 < 1.0;
+    double fac = (E2 == E2) ? fmax(0.2, ctrl_pow(E2, 0.9)) : 0.2;  // NaN -> hardest shrink
+    fac = fmin(ok ? (rejected_last ? 1.0 : 10.0) : 1.0, fac);
+    t = ok ? t + h : t;
+    h *= fac;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        x[i] = y[i];
-        K.set(0, i, kk[i]);
-      }
-      rejected_last = false;
-      ++acc;
-      if (last) break;
-    } else {
-      double fac = (E2 == E2) ? fmax(0.2, ctrl_pow(E2, 0.9)) : 0.2;  // NaN -> hardest shrink
-      if (fac > 1.0) fac = 1.0;
-      h *= fac;
-      rejected_last = true;
-      ++rej;
-      if (!(h > 1e-13 * dt)) {  // step-size underflow (NaN state / blow-up): give up on this lane
-        status = 2;
-        break;
-      }
+    for (int i = 0; i < NX; ++i) {
+      x[i] = ok ? y[i] : x[i];
+      K.set(0, i, ok ? kk[i] : K.get(0, i));
+    }
+    rejected_last = !ok;
+    acc += ok ? 1 : 0;
+    rej += ok ? 0 : 1;
+    if (ok && last) break;
+    if (!ok && !(h > 1e-13 * dt)) {  // step-size underflow (NaN state / blow-up): give up on this lane
+      status = 2;
+      break;
     }
   }
   nacc = acc;
