@@ -1043,7 +1043,7 @@ int pcg_graph_create(pcg_graph** out, pcg_plan* p, const pcg_buffers* io, const 
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) {
-    hipStreamDestroy(cs);
+    (void)hipStreamDestroy(cs);
     return (int)e;
   }
   if (with_reset) rc = pcg_reset(p, &b, nullptr, seed, cs);
@@ -1053,22 +1053,22 @@ int pcg_graph_create(pcg_graph** out, pcg_plan* p, const pcg_buffers* io, const 
     rc = pcg_step(p, &b, t0 + j, seed, cs);
   }
   e = hipStreamEndCapture(cs, &g);
-  hipStreamDestroy(cs);
+  (void)hipStreamDestroy(cs);
   if (rc != PCG_OK) {
-    if (g) hipGraphDestroy(g);
+    if (g) (void)hipGraphDestroy(g);
     return rc;
   }
   if (e != hipSuccess) return (int)e;
   hipGraphExec_t ex = nullptr;
   e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
   if (e != hipSuccess) {
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     return (int)e;
   }
   pcg_graph* q = new (std::nothrow) pcg_graph();
   if (!q) {
-    hipGraphExecDestroy(ex);
-    hipGraphDestroy(g);
+    (void)hipGraphExecDestroy(ex);
+    (void)hipGraphDestroy(g);
     return PCG_E_VALUE;
   }
   q->magic = GRAPH_MAGIC;
@@ -1114,8 +1114,8 @@ int pcg_graph_set_seed(pcg_graph* q, uint64_t seed) {
 int pcg_graph_destroy(pcg_graph* q) {
   if (!q) return PCG_OK;
   if (q->magic != GRAPH_MAGIC) return PCG_E_PLAN;
-  hipGraphExecDestroy(q->exec);
-  hipGraphDestroy(q->graph);
+  (void)hipGraphExecDestroy(q->exec);
+  (void)hipGraphDestroy(q->graph);
   q->magic = 0;
   delete q;
   return PCG_OK;
