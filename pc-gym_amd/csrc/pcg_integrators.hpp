@@ -378,16 +378,9 @@ PCG_DEV int rodas3(const F& f, const RosLds<NX>& L, double (&x)[NX], int n, doub
                    int max_steps, int& nacc, int& nrej) {
 #pragma clang fp contract(off)
   constexpr double gam = 0.5;
-  // Five vectors live at the widest point (x, A, B, C, T) instead of eight: the stage increments are folded into the
-  // running sums as soon as they are complete, and f(x) is re-evaluated after a rejection rather than kept across the
-  // stages.  Every value is formed by the same operations in the same order as in the oracle's statement-per-stage
-  // form (x + 2 k1, then + k3, then + k4; (k1 - k2) - 8/3 k3), so the results are the same bits.  (It does not cure
-  // the spills of the wide models -- 24 states: ~5 KB of scratch per lane before and after; those come from the
-  // unrolled triangular solves -- so their cost is unchanged: profiles/r2/rodas_probe.txt.)
-  double f0[NX], A[NX], B[NX], C[NX], T[NX];
+  double f0[NX], k1[NX], k2[NX], k3[NX], k4[NX], y[NX], fy[NX];
   int acc = 0, rej = 0, status = 0;
   f(x, f0);
-  bool need_f0 = false;
   double h;
   {  // initial step: h0 of Hairer, Norsett & Wanner II.4 (the first stage of dopri5()'s heuristic), quantised
     const double d0 = rms_scaled<NX>(x, x, x, n, rtol, atol);
@@ -407,10 +400,6 @@ PCG_DEV int rodas3(const F& f, const RosLds<NX>& L, double (&x)[NX], int n, doub
       h = dt - t;
       last = true;
     }
-    if (need_f0) {
-      f(x, f0);
-      need_f0 = false;
-    }
     // Jacobian by forward differences, W = I/(gamma h) - J
     // perturbation ~ sqrt(eps) / rtol x the error weight of the component (CVODES' difference quotient scales the
     // same way); the x_max term only keeps it non-zero when atol = 0 and x_j = 0
@@ -426,12 +415,12 @@ PCG_DEV int rodas3(const F& f, const RosLds<NX>& L, double (&x)[NX], int n, doub
       for (int i = 0; i < NX; ++i) xj = (i == j) ? x[i] : xj;
       const double del = 1.4901161193847656e-8 * (fabs(xj) + wfloor);
 #pragma unroll
-      for (int i = 0; i < NX; ++i) A[i] = (i == j) ? x[i] + del : x[i];
-      f(A, T);
+      for (int i = 0; i < NX; ++i) y[i] = (i == j) ? x[i] + del : x[i];
+      f(y, fy);
       const double idel = 1.0 / ((xj + del) - xj);  // the perturbation that was actually applied
 #pragma unroll
       for (int i = 0; i < NX; ++i)
-        if (i < n) L.w(i, j) = -(T[i] - f0[i]) * idel;
+        if (i < n) L.w(i, j) = -(fy[i] - f0[i]) * idel;
     }
     const double igh = 1.0 / (gam * h), ih = 1.0 / h;
     for (int i = 0; i < NX; ++i) {
@@ -441,41 +430,38 @@ PCG_DEV int rodas3(const F& f, const RosLds<NX>& L, double (&x)[NX], int n, doub
     const bool lu_ok = ros_lu<NX>(L, n);
     // stage 1 .. 4 (a21 = 0: stage 2 re-uses f(x))
 #pragma unroll
-    for (int i = 0; i < NX; ++i) A[i] = f0[i];
-    ros_solve<NX>(L, n, A);  // A = k1
+    for (int i = 0; i < NX; ++i) k1[i] = f0[i];
+    ros_solve<NX>(L, n, k1);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) B[i] = f0[i] + (4.0 * ih) * A[i];
-    ros_solve<NX>(L, n, B);  // B = k2; f(x) is not needed any more
+    for (int i = 0; i < NX; ++i) k2[i] = f0[i] + (4.0 * ih) * k1[i];
+    ros_solve<NX>(L, n, k2);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      B[i] = A[i] - B[i];        // k1 - k2
-      A[i] = x[i] + 2.0 * A[i];  // x + 2 k1
-    }
-    f(A, T);
+    for (int i = 0; i < NX; ++i) y[i] = x[i] + 2.0 * k1[i];
+    f(y, fy);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) C[i] = T[i] + ih * B[i];
-    ros_solve<NX>(L, n, C);  // C = k3
+    for (int i = 0; i < NX; ++i) k3[i] = fy[i] + ih * (k1[i] - k2[i]);
+    ros_solve<NX>(L, n, k3);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) A[i] = A[i] + C[i];  // x + 2 k1 + k3
-    f(A, T);
+    for (int i = 0; i < NX; ++i) y[i] = x[i] + 2.0 * k1[i] + k3[i];
+    f(y, fy);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) T[i] = T[i] + ih * (B[i] - (8.0 / 3.0) * C[i]);
-    ros_solve<NX>(L, n, T);  // T = k4 = the error estimate
+    for (int i = 0; i < NX; ++i) k4[i] = fy[i] + ih * (k1[i] - k2[i] - (8.0 / 3.0) * k3[i]);
+    ros_solve<NX>(L, n, k4);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) A[i] = A[i] + T[i];  // m = (2, 0, 1, 1)
-    double E2 = ms_scaled<NX>(T, x, A, n, rtol, atol);
+    for (int i = 0; i < NX; ++i) y[i] = x[i] + 2.0 * k1[i] + k3[i] + k4[i];  // m = (2, 0, 1, 1); error = k4
+    double E2 = ms_scaled<NX>(k4, x, y, n, rtol, atol);
     if (!lu_ok) E2 = __builtin_nan("");
-    need_f0 = true;  // after an accepted step x has moved; after a rejected one f(x) was given up above
     if (E2 < 1.0) {
       double fac = fmin(6.0, fmax(0.2, ctrl_pow_e(E2, 0.9, 1.0f / 6.0f, 1.0 / 6.0)));
       if (rejected_last && fac > 1.0) fac = 1.0;
       t += h;
       h *= fac;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) x[i] = A[i];
+      for (int i = 0; i < NX; ++i) x[i] = y[i];
       rejected_last = false;
       ++acc;
       if (last) break;
+      f(x, f0);
     } else {
       double fac = (E2 == E2) ? fmax(0.2, ctrl_pow_e(E2, 0.9, 1.0f / 6.0f, 1.0 / 6.0)) : 0.2;
       if (fac > 1.0) fac = 1.0;
