@@ -105,8 +105,8 @@ def adaptive_check(model_name, x_gpu, x_orc, ns_gpu, ns_orc, tag, tol=1e-11, x_t
         # norm by ~1e-8 relative; a decision that lands that close to a threshold (E = 1, or an edge of the 6-bit factor
         # grid) flips.  Soak run, 400 random configurations x 770 envs x ~20 steps (PCG_FUZZ_SEEDS=400): one env step
         # with 8 instead of 9 accepted steps, its state 2.6e-13 from the oracle's.  So: (almost) every env identical,
-        # the rest within the integrator's own accuracy class.
-        assert same.mean() >= 0.998, (tag, "identical step counts", same.mean())
+        # the rest (at most one env, or 0.2 % of a large batch) within the integrator's own accuracy class.
+        assert (~same).sum() <= max(1, int(0.002 * same.size)), (tag, "identical step counts", same.mean())
         assert ex[same].max() <= tol, (tag, ex[same].max())
         if not same.all():
             assert ex[~same].max() <= max(1e3 * tol, 1e-9), (tag, "envs with another step sequence", ex[~same].max())
