@@ -753,3 +753,26 @@ def test_rosenbrock_integrator_inside_a_run_time_compiled_step_kernel():
             got = info["g"].cpu().numpy()[:, ::37]
             assert np.allclose(got, want, rtol=1e-9, atol=1e-9 * np.max(np.abs(want))), (per_env_t, i)
         ea.close(), eb.close()
+
+
+@pytest.mark.parametrize("name,B", [("me_canonical", 1 << 17), ("me_canonical", 3000), ("me_reactive", 70000)])
+def test_step_graph_with_adaptive_kernels(name, B):
+    """pcg_graph_* around adaptive plans: the work-queue kernel (well-filled tiles) and the classic adaptive kernel (thin
+    ones) record and replay like the fixed-step kernels -- bit-identical to stepping"""
+    torch = _torch()
+    from pcgym_amd import VecEnv
+
+    p = copy.deepcopy(SC.scenarios()[name]["env_params"])
+    p["integrator"] = "dopri5"
+    e1, e2 = VecEnv(copy.deepcopy(p), n_envs=B, seed=1), VecEnv(copy.deepcopy(p), n_envs=B, seed=1)
+    e1.reset(), e2.reset()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    acts = [torch.rand((e1.spec.na, B), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1 for _ in range(4)]
+    g = e2.capture_steps(acts)
+    for a in acts:
+        e1.step(a)
+    g.replay()
+    assert torch.equal(e1.x, e2.x) and torch.equal(e1.nsteps, e2.nsteps) and torch.equal(e1.rew, e2.rew)
+    assert torch.equal(e1.obs_soa, e2.obs_soa) and not e2.status.any()
+    g.destroy()
+    e1.close(), e2.close()
