@@ -118,6 +118,112 @@ def probe_affine(fn, dims, sample_points, what):
     return A, c
 
 
+# ---- tracing a Python callable into C expressions ------------------------------------------------------------------
+# The reference's callables (custom_model.__call__(x, u), constraints(x, u)) are plain arithmetic over array elements,
+# model attributes and a few numpy functions (model_classes.py).  Calling one with symbolic scalars records that
+# arithmetic as a C expression; what cannot be recorded -- control flow on values -- raises.  The recorded expressions
+# are then evaluated numerically against the callable itself at random points before they are accepted.
+class _TraceError(TypeError):
+    pass
+
+
+class _Sym:
+    """a scalar whose value is a C expression over x[] / u[]"""
+    __slots__ = ("e",)
+    __array_priority__ = 1000.0
+
+    def __init__(self, e):
+        self.e = e
+
+    @staticmethod
+    def _lit(v):
+        if isinstance(v, _Sym):
+            return v.e
+        if isinstance(v, (bool, np.bool_)):
+            raise _TraceError("boolean in arithmetic")
+        f = float(v)
+        if not np.isfinite(f):
+            raise _TraceError("non-finite constant")
+        r = repr(f)
+        return f"({r})" if f < 0 else r
+
+    def _bin(self, o, op, rev=False):
+        a, b = (self._lit(o), self.e) if rev else (self.e, self._lit(o))
+        return _Sym(f"({a} {op} {b})")
+
+    def __add__(self, o): return self._bin(o, "+")
+    def __radd__(self, o): return self._bin(o, "+", True)
+    def __sub__(self, o): return self._bin(o, "-")
+    def __rsub__(self, o): return self._bin(o, "-", True)
+    def __mul__(self, o): return self._bin(o, "*")
+    def __rmul__(self, o): return self._bin(o, "*", True)
+    def __truediv__(self, o): return self._bin(o, "/")
+    def __rtruediv__(self, o): return self._bin(o, "/", True)
+    def __neg__(self): return _Sym(f"(-{self.e})")
+    def __pos__(self): return self
+    def __abs__(self): return _Sym(f"fabs({self.e})")
+
+    def __pow__(self, o):
+        if not isinstance(o, _Sym) and float(o) == 2.0:
+            return _Sym(f"({self.e} * {self.e})")
+        return _Sym(f"pow({self.e}, {self._lit(o)})")
+
+    def __rpow__(self, o): return _Sym(f"pow({self._lit(o)}, {self.e})")
+
+    # numpy ufuncs on object arrays call the method of the same name
+    def exp(self): return _Sym(f"exp({self.e})")
+    def log(self): return _Sym(f"log({self.e})")
+    def sqrt(self): return _Sym(f"sqrt({self.e})")
+    def sin(self): return _Sym(f"sin({self.e})")
+    def cos(self): return _Sym(f"cos({self.e})")
+    def tanh(self): return _Sym(f"tanh({self.e})")
+    def fabs(self): return _Sym(f"fabs({self.e})")
+    absolute = fabs
+
+    def _no(self, *a, **k):
+        raise _TraceError("the callable branches on (or converts) a value that depends on the state / input: "
+                          "control flow cannot be compiled into a kernel expression")
+    __bool__ = __float__ = __int__ = __index__ = _no
+    __lt__ = __le__ = __gt__ = __ge__ = __eq__ = __ne__ = _no
+    __hash__ = None
+
+
+def trace_callable(fn, dims, sample_points, what, arg_names=("x", "u")):
+    """Record ``fn(z_0, z_1, ...)`` (arguments of sizes ``dims``) as one C expression per output over ``x[i]`` /
+    ``u[j]``; checked numerically against ``fn`` itself at ``sample_points`` (concatenated arguments)."""
+    import math
+
+    args = [np.array([_Sym(f"{arg_names[k]}[{i}]") for i in range(d)], dtype=object) for k, d in enumerate(dims)]
+    try:
+        out = fn(*args)
+    except _TraceError as e:
+        raise ValueError(f"{what}: {e}") from None
+    except Exception as e:  # noqa: BLE001  (whatever numpy makes of an object array the callable did not expect)
+        raise ValueError(f"{what}: the callable could not be traced into expressions ({type(e).__name__}: {e})") from None
+    flat = list(np.asarray(out, dtype=object).reshape(-1)) if not isinstance(out, _Sym) else [out]
+    exprs = [v.e if isinstance(v, _Sym) else _Sym._lit(v) for v in flat]
+    env = {k: getattr(math, k) for k in ("exp", "log", "sqrt", "sin", "cos", "tanh", "fabs")}
+    env["pow"] = math.pow
+    for z in sample_points:
+        z = np.asarray(z, dtype=_f64).reshape(-1)
+        parts, o = [], 0
+        for d in dims:
+            parts.append(np.array(z[o:o + d], dtype=_f64))
+            o += d
+        with np.errstate(all="ignore"):
+            want = np.asarray(fn(*[q.copy() for q in parts]), dtype=_f64).reshape(-1)
+        scope = dict(env, **{arg_names[k]: list(map(float, parts[k])) for k in range(len(dims))})
+        try:
+            got = np.array([float(eval(e, {"__builtins__": {}}, scope)) for e in exprs])  # noqa: S307 (our own text)
+        except (ValueError, ZeroDivisionError, OverflowError):
+            continue  # outside the callable's domain at this probe point
+        ok = np.isfinite(want)
+        if want.shape != got.shape or not np.all(np.abs(want[ok] - got[ok]) <= 1e-9 * (np.abs(want[ok]) + 1e-12) + 1e-300):
+            raise ValueError(f"{what}: the traced expressions do not reproduce the callable (it probably contains "
+                             "control flow or state that tracing cannot see)")
+    return exprs
+
+
 _EXPR_FUNCS = {"exp", "log", "sqrt", "pow", "fabs", "fmin", "fmax", "sin", "cos", "tanh"}
 
 
@@ -361,6 +467,7 @@ class EnvSpec:
             self.r_penalty = bool(p["r_penalty"])
             self.constraint_active = True
             self._cons_exprs = None
+            self._cons_traced = None
             if isinstance(cons, dict) and "expr" in cons:
                 # non-affine g(x,u) as C expressions, one per row (compiled into the kernel, see compile_expr)
                 ex = cons["expr"]
@@ -377,8 +484,23 @@ class EnvSpec:
                     xs = self.x0_full() * (1 + 0.1 * rng.uniform(-1, 1, self.nobs)) + 0.01 * rng.uniform(-1, 1, self.nobs)
                     us = rng.uniform(-1, 1, self.nu)
                     pts.append(np.concatenate([xs, us]))
-                A, c = probe_affine(cons, [self.nobs, self.nu], pts, "constraints")
-                b = -c
+                try:
+                    A, c = probe_affine(cons, [self.nobs, self.nu], pts, "constraints")
+                    b = -c
+                except ValueError as not_affine:
+                    # not affine: record the callable's arithmetic as C expressions (trace_callable) and compile those
+                    # into the kernel, exactly as if the user had written {'expr': [...]}
+                    phys = []
+                    for _ in range(4):  # probe points in physical units: the state box and the action box
+                        xs = self.x0_full() * (1 + 0.05 * rng.uniform(-1, 1, self.nobs))
+                        us = np.resize(self.a_low + rng.uniform(0, 1, self.na) * (self.a_high - self.a_low), self.nu)
+                        phys.append(np.concatenate([xs, us]))
+                    try:
+                        self._cons_traced = trace_callable(cons, [self.nobs, self.nu], phys, "constraints")
+                    except ValueError as not_traceable:
+                        raise ValueError(f"{not_affine}; and {not_traceable}") from None
+                    A = np.zeros((len(self._cons_traced), self.nobs + self.nu))
+                    b = np.zeros(len(self._cons_traced))
             else:
                 raise ValueError("constraints must be a callable g(x,u) or {'A':..., 'b':...}")
             if A.shape[1] != self.nobs + self.nu:
@@ -415,6 +537,8 @@ class EnvSpec:
             for i, e in enumerate(rhs):
                 lines.append(f"  dx[{i}] = (double)({compile_expr(e, names, set(), local, f'custom_model rhs[{i}]')});")
             self.user_rhs_src = "\n".join(lines)
+        elif getattr(self, "_rhs_traced", None) is not None:  # a Python model recorded by trace_callable
+            self.user_rhs_src = "\n".join(f"  dx[{i}] = (double)({e});" for i, e in enumerate(self._rhs_traced))
         if getattr(self, "_cons_exprs", None):
             names = {n: f"x[{i}]" for i, n in enumerate(st_names)}
             names.update({n: f"u[{j}]" for j, n in enumerate(in_names)})
@@ -422,6 +546,8 @@ class EnvSpec:
             rows = [compile_expr(e, names, {"x", "u"}, set(), f"constraints['expr'][{r}]")
                     for r, e in enumerate(self._cons_exprs)]
             self.user_cons_src = "\n".join(f"  g[{r}] = (double)({e});" for r, e in enumerate(rows))
+        elif getattr(self, "_cons_traced", None):  # a Python callable recorded by trace_callable (already over x[] / u[])
+            self.user_cons_src = "\n".join(f"  g[{r}] = (double)({e});" for r, e in enumerate(self._cons_traced))
         if self._reward_expr is not None:
             names = {n: f"o[{i}]" for i, n in enumerate(st_names)}
             names.update({n: f"u[{j}]" for j, n in enumerate(in_names)})
@@ -618,13 +744,41 @@ class EnvSpec:
         dist = [d for d in info.get("disturbances", []) if d != "None"]
         if p.get("disturbances") is not None:
             nu += len(dist)
-        if nx > 8 or nu > abi.PCG_MAX_NU:
-            raise ValueError("affine custom_model supports nx<=8")
+        if nu > abi.PCG_MAX_NU or nx > abi.PCG_MAX_NX:
+            raise ValueError(f"custom_model: at most {abi.PCG_MAX_NX} states and {abi.PCG_MAX_NU} inputs")
         rng = np.random.default_rng(11)
         x0 = _arr(p["x0"])[:nx]
         pts = [np.concatenate([x0 * (1 + 0.1 * rng.uniform(-1, 1, nx)) + 0.01 * rng.uniform(-1, 1, nx),
                                rng.uniform(-1, 1, nu)]) for _ in range(3)]
-        A, c = probe_affine(lambda x, u: m(x, u), [nx, nu], pts, "custom_model")
+        not_affine = None
+        try:
+            A, c = probe_affine(lambda x, u: m(x, u), [nx, nu], pts, "custom_model")
+            if nx > 8 or nu > 4:  # beyond the compiled affine kernel's matrices: take the general route below
+                not_affine = ValueError("custom_model: affine, but larger than the affine kernel (8 states, 4 inputs)")
+        except ValueError as e:
+            not_affine = e
+        if not_affine is not None:
+            # (b) any other Python model: record its arithmetic as C expressions and compile those (PCG_MODEL_USER)
+            na = len(info["inputs"])
+            if not (1 <= nx <= abi.PCG_MAX_NX) or not (1 <= na <= abi.PCG_MAX_NA) or len(dist) > abi.PCG_MAX_NDM:
+                raise not_affine
+            for d in dist:
+                if d not in info.get("parameters", {}):
+                    raise ValueError(f"custom_model: disturbance input '{d}' needs a parameter of the same name") from None
+            lo, hi = self.a_low[:na], self.a_high[:na]
+            phys = []
+            for _ in range(4):
+                us = lo + rng.uniform(0, 1, na) * (hi - lo)
+                ds = np.array([float(info["parameters"][d]) * (1 + 0.05 * rng.uniform(-1, 1)) for d in dist])[: nu - na]
+                phys.append(np.concatenate([x0 * (1 + 0.05 * rng.uniform(-1, 1, nx)), us, ds]))
+            try:
+                self._rhs_traced = trace_callable(lambda x, u: m(x, u), [nx, nu], phys, "custom_model")
+            except ValueError as not_traceable:
+                raise ValueError(f"{not_affine}; and {not_traceable}") from None
+            if len(self._rhs_traced) != nx:
+                raise ValueError(f"custom_model returned {len(self._rhs_traced)} derivatives for {nx} states") from None
+            return M.ModelInfo(cls, M.USER, info["states"], info["inputs"], dist,
+                               [(d, float(info["parameters"][d])) for d in dist])
         mi = M.ModelInfo(cls, M.AFFINE, info["states"], info["inputs"], dist,
                          list(info.get("parameters", {}).items()))
         self.affine_AB = (A[:, :nx].copy(), A[:, nx:].copy(), c.copy())

@@ -89,14 +89,69 @@ def test_constraint_callable_is_probed_into_affine_rows():
     assert np.allclose(s.con_A[2], [0.5, 0.001, 0, 0]) and np.isclose(s.con_b[2], 0.8)
 
 
-def test_nonaffine_callables_are_rejected_loudly():
+def test_nonaffine_callables_are_traced_into_expressions_or_rejected_loudly():
+    """a Python callable that is not affine is recorded as C expressions (config.trace_callable: symbolic scalars through
+    the callable's own arithmetic, checked numerically against it) -- unless it has control flow on values"""
     p = P("cstr_cons_pen_raw")
-    p["constraints"] = lambda x, u: np.array([x[1] ** 2 - 1e5])
-    with pytest.raises(ValueError, match="not affine"):
+    p["constraints"] = lambda x, u: np.array([x[1] ** 2 - 1e5, np.log(x[0]) + 0.5 * abs(u[0] - 298.0) ** 1.5])
+    s = EnvSpec(p)
+    assert s.ncon == 2 and s.user_cons_src is not None and s.con_A.shape == (2, s.nobs + s.nu)
+    assert "g[0] = (double)(((x[1] * x[1]) - 100000.0));" in s.user_cons_src
+    assert "log(x[0])" in s.user_cons_src and "pow(fabs((u[0] - 298.0)), 1.5)" in s.user_cons_src
+    cfg, _keep = s.to_cfg()
+    assert cfg.user_cons_src == s.user_cons_src.encode() and cfg.ncon == 2
+    p["constraints"] = lambda x, u: np.array([x[1] - 330.0 if x[0] > 0.8 else x[1] - 320.0])  # branches on the state
+    with pytest.raises(ValueError, match="not affine.*control flow"):
         EnvSpec(p)
-    p["constraints"] = lambda x, u: np.array([np.log(x[0])])
-    with pytest.raises(ValueError, match="not affine"):
+    p["constraints"] = lambda x, u: np.array([max(x[1], 320.0) - 330.0])  # max() compares: control flow as well
+    with pytest.raises(ValueError, match="control flow"):
         EnvSpec(p)
+
+
+def test_python_custom_model_is_traced_into_a_user_model():
+    """the reference's model protocol (pcgym.py:150-153): any object with __call__(x, u) and info().  Non-affine ones are
+    traced into C expressions and become PCG_MODEL_USER -- no rewriting by the user"""
+
+    class chemostat:
+        mumax, Ks, Ki, Y, Sf = 0.53, 0.12, 22.0, 0.4, 4.0
+
+        def __call__(self, x, u):
+            X, S, D = x[0], x[1], u[0]
+            Sf = u[1] if u.shape[0] > 1 else self.Sf  # the reference models' own idiom (model_classes.py:47-51)
+            mu = self.mumax * S / (self.Ks + S + S ** 2 / self.Ki)
+            return np.array([(mu - D) * X, D * (Sf - S) - mu * X / self.Y])
+
+        def info(self):
+            return {"states": ["X", "S"], "inputs": ["D"], "disturbances": ["Sf"],
+                    "parameters": {"mumax": self.mumax, "Ks": self.Ks, "Ki": self.Ki, "Y": self.Y, "Sf": self.Sf}}
+
+    N = 20
+    p = {"custom_model": chemostat(), "N": N, "tsim": 10.0, "x0": np.array([1.2, 0.6, 1.4]), "SP": {"X": [1.4] * N},
+         "r_scale": {"X": 10.0}, "a_space": {"low": np.array([0.0]), "high": np.array([0.45])},
+         "o_space": {"low": np.zeros(3), "high": np.array([3.0, 6.0, 3.0])}}
+    s = EnvSpec(copy.deepcopy(p))
+    assert s.model.model_id == M.USER and (s.nx, s.na, s.ndm) == (2, 1, 0) and s.integrator == "dopri5"
+    assert "(4.0 - x[1])" in s.user_rhs_src and s.user_rhs_src.count("dx[") == 2
+    q = copy.deepcopy(p)
+    q.update(disturbances={"Sf": np.full(N, 4.5)}, disturbance_bounds={"low": np.array([2.0]), "high": np.array([6.0])})
+    s2 = EnvSpec(q)
+    assert s2.ndm == 1 and "(u[1] - x[1])" in s2.user_rhs_src and list(s2.d_default) == [4.0]
+    # the recorded expressions reproduce the callable (Python evaluation of the same text)
+    import math
+
+    x, u = [0.9, 1.3], [0.2]
+    scope = {"x": x, "u": u, "exp": math.exp, "pow": math.pow}
+    got = [eval(line.split("(double)")[1].rstrip(";"), {"__builtins__": {}}, scope) for line in s.user_rhs_src.splitlines()]
+    assert np.allclose(got, chemostat()(np.array(x), np.array(u)), rtol=1e-14)
+
+    class switching(chemostat):
+        def __call__(self, x, u):
+            return np.array([x[0] if x[1] > 1.0 else -x[0], u[0] * x[1] ** 2])
+
+    bad = copy.deepcopy(p)
+    bad["custom_model"] = switching()
+    with pytest.raises(ValueError, match="control flow"):
+        EnvSpec(bad)
 
 
 def test_declarative_constraints():

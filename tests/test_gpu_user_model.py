@@ -306,3 +306,83 @@ def test_user_model_at_the_size_limits():
         H.adaptive_check("user", env.x.cpu().numpy(), orc.x, env.nsteps.cpu().numpy(), orc.nsteps, i, tol=1e-10)
         assert np.max(np.abs(o.cpu().numpy().T - oc)) <= 1e-10 and np.allclose(r.cpu().numpy(), rc, rtol=1e-9, atol=1e-11)
     env.close()
+
+
+# ---- Python callables, traced (config.trace_callable): no rewriting by the user -------------------------------------
+def test_python_constraint_callable_is_traced_and_replays_the_reference_recording():
+    """the very callable the reference ran when the fixture was recorded (tests/golden/scenarios.py:
+    cons_cstr_nonaffine, a quadratic band and a curved floor) handed to VecEnv as-is"""
+    torch = _torch()
+    from pcgym_amd import VecEnv
+
+    name = "cstr_expr_cons_raw"
+    sc = SC.scenarios()[name]
+    g = H.gold("step_" + name)
+    p = copy.deepcopy(sc["ref_env_params"])  # constraints = the Python function
+    assert callable(p["constraints"])
+    p.update(H.tight_for(p))
+    B = 97
+    env = VecEnv(p, n_envs=B, seed=1)
+    assert env.spec.user_cons_src is not None and env.spec.ncon == 2
+    A = SC.actions_for(name, sc)
+    obs, _ = env.reset()
+    ci = g["cons_info"]
+    for i in range(sc["steps"]):
+        a = torch.tensor(np.repeat(A[i].reshape(-1, 1), B, axis=1), device=env.device)
+        o, r, d, _, info = env.step(a)
+        want = g["obs"][i + 1]
+        assert np.all(np.abs(o.cpu().numpy() - want[None, :]) <= 2e-9 * np.maximum(np.abs(want), 1.0)), i
+        assert np.allclose(r.cpu().numpy(), g["rew"][i], rtol=1e-7, atol=1e-9), i
+        assert np.allclose(info["g"].cpu().numpy(), ci[:, i + 1:i + 2], rtol=1e-8, atol=1e-9 * np.max(np.abs(ci))), i
+        assert np.array_equal(info["viol"].cpu().numpy(), np.full(B, int((ci[:, i + 1] > 0).any()), dtype=np.uint8))
+    env.close()
+
+
+class _ChemostatObject:
+    """a model in the reference's protocol: __call__(x, u) + info(); nothing about C anywhere"""
+    mumax, Ks, Ki, Y, Sf = 0.53, 0.12, 22.0, 0.4, 4.0
+
+    def __call__(self, x, u):
+        X, S, D = x[0], x[1], u[0]
+        Sf = u[1] if u.shape[0] > 1 else self.Sf
+        mu = self.mumax * S / (self.Ks + S + S ** 2 / self.Ki)
+        return np.array([(mu - D) * X, D * (Sf - S) - mu * X / self.Y])
+
+    def info(self):
+        return {"states": ["X", "S"], "inputs": ["D"], "disturbances": ["Sf"],
+                "parameters": {"mumax": self.mumax, "Ks": self.Ks, "Ki": self.Ki, "Y": self.Y, "Sf": self.Sf}}
+
+
+@pytest.mark.parametrize("with_dist", [False, True])
+def test_python_model_object_is_traced_and_equals_the_declarative_model(with_dist):
+    torch = _torch()
+    from scipy.integrate import solve_ivp
+
+    from pcgym_amd import VecEnv
+
+    kw = {}
+    if with_dist:
+        kw = dict(disturbances={"Sf": 4.0 + 0.8 * np.sin(np.arange(30) / 3.0)},
+                  disturbance_bounds={"low": np.array([2.0]), "high": np.array([6.0])})
+    pd = _chemostat_params(**kw)
+    po = _chemostat_params(**kw)
+    po["custom_model"] = _ChemostatObject()
+    B = 300
+    ed, eo = VecEnv(pd, n_envs=B, seed=5), VecEnv(po, n_envs=B, seed=5)
+    assert eo.spec.model.model_id == 17 and eo.spec.user_rhs_src != ed.spec.user_rhs_src  # traced text vs written text
+    ed.reset(), eo.reset()
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    x_prev = eo.x.cpu().numpy().copy()
+    for i in range(12):
+        a = torch.rand((1, B), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+        od, rd, _, _, _ = ed.step(a)
+        oo, ro, _, _, _ = eo.step(a)
+        assert torch.allclose(od, oo, rtol=1e-10, atol=1e-12) and torch.allclose(rd, ro, rtol=1e-9, atol=1e-11), i
+        if i == 0:  # and the truth: SciPy on the Python object itself
+            u0 = (a.cpu().numpy()[0] + 1) * 0.45 / 2
+            for b in range(0, B, 60):
+                uu = np.array([u0[b]] + ([float(kw["disturbances"]["Sf"][1])] if with_dist else []))
+                r = solve_ivp(lambda t, y: _ChemostatObject()(y, uu), (0.0, eo.spec.dt), x_prev[:, b], method="LSODA",
+                              rtol=1e-12, atol=1e-14)
+                assert np.all(np.abs(eo.x.cpu().numpy()[:, b] - r.y[:, -1]) <= 2e-7 * np.maximum(np.abs(r.y[:, -1]), 1e-2))
+    ed.close(), eo.close()
