@@ -141,7 +141,10 @@ class _Sym:
             return v.e
         if isinstance(v, (bool, np.bool_)):
             raise _TraceError("boolean in arithmetic")
-        f = float(v)
+        a = np.asarray(v)
+        if a.size != 1 or a.dtype == object:
+            raise _TraceError("a constant of the callable is not a scalar number")
+        f = float(a.reshape(-1)[0])
         if not np.isfinite(f):
             raise _TraceError("non-finite constant")
         r = repr(f)

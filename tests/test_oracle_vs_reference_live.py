@@ -137,3 +137,54 @@ def test_random_config_oracle_matches_reference(ref, seed):
         assert bool(d[0]) == bool(d_ref), (seed, i)
         if d_ref:
             break
+
+
+_REF_CLASSES = {"cstr": "cstr", "four_tank": "four_tank", "multistage_extraction": "multistage_extraction",
+                "multistage_extraction_reactive": "multistage_extraction_reactive", "crystallization": "crystallization",
+                "complex_cstr": "complex_cstr", "disease": "disease_model", "batch": "batch",
+                "photobioreactor": "photo_production", "cstr_series_recycle": "cstr_series_recycle",
+                "distillation_column": "distillation_column", "polymerisation_reactor": "polymerisation_reactor",
+                "hydraulic_tank": "hydraulic_tank", "first_order_system": "first_order_system",
+                "biofilm_reactor": "biofilm_reactor", "heat_exchanger": "heat_exchanger"}
+
+
+@pytest.mark.parametrize("fix", sorted(_REF_CLASSES))
+def test_reference_model_objects_trace_into_expressions(fix):
+    """the reference's OWN model classes (imported from /root/reference, nothing of them is stored here) go through
+    config.trace_callable: what a user gets when handing such an object to custom_model.  The recorded expressions,
+    evaluated as Python, reproduce the object on all 64 points of the model's RHS fixture."""
+    import math
+
+    import gen_golden as G
+    from pcgym_amd.config import trace_callable
+
+    import helpers as H
+
+    _P, M = G._import_reference()
+    m = getattr(M, _REF_CLASSES[fix])(int_method="casadi")
+    g = H.gold("rhs_" + fix)
+    x, u = g["x"], g["u"]
+    pts = [np.concatenate([x[i], u[i]]) for i in range(3)]
+    ex = trace_callable(lambda xx, uu: m(xx, uu), [x.shape[1], u.shape[1]], pts, fix)
+    assert len(ex) == x.shape[1]
+    env = {k: getattr(math, k) for k in ("exp", "log", "sqrt", "sin", "cos", "tanh", "fabs")}
+    env["pow"] = math.pow
+    dx = g["dx"].reshape(x.shape[0], -1)
+    scale = np.max(np.abs(dx), axis=0)
+    for i in range(x.shape[0]):
+        scope = dict(env, x=list(map(float, x[i])), u=list(map(float, u[i])))
+        got = np.array([eval(e, {"__builtins__": {}}, scope) for e in ex])
+        assert np.all(np.abs(got - dx[i]) <= 1e-12 * scale + 1e-300), (fix, i)
+
+
+def test_reference_model_with_value_dependent_control_flow_is_refused():
+    import gen_golden as G
+    from pcgym_amd.config import trace_callable
+
+    import helpers as H
+
+    _P, M = G._import_reference()
+    m = M.nonsmooth_control(int_method="casadi")
+    g = H.gold("rhs_nonsmooth_control")
+    with pytest.raises(ValueError, match="control flow"):
+        trace_callable(lambda xx, uu: m(xx, uu), [2, 1], [np.concatenate([g["x"][0], g["u"][0]])], "nonsmooth_control")
