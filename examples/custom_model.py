@@ -21,6 +21,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pcgym_amd import make_vec_env  # noqa: E402
 
 N = 60
+# The model can also be handed over as a plain Python object in the reference's protocol (__call__(x, u) + info()): its
+# arithmetic is then traced into the same kind of expressions automatically (pcgym_amd.config.trace_callable).
 CHEMOSTAT = {
     "states": ["X", "S"], "inputs": ["D"], "disturbances": ["Sf"],
     "parameters": {"mumax": 0.53, "Ks": 0.12, "Ki": 22.0, "Y": 0.4, "Sf": 4.0},
