@@ -421,3 +421,23 @@ def abi_model_user():
 
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pcgym_hip.h")).read()
     return int(re.search(r"PCG_MODEL_USER = (\d+)", hdr).group(1))
+
+
+def test_large_affine_python_model_takes_the_traced_route():
+    """the compiled affine kernel holds 8 states / 4 inputs; a bigger affine Python model is traced like any other"""
+
+    class chain:
+        def __call__(self, x, u):
+            n = len(x)
+            return np.array([-(i + 1) * 0.1 * x[i] + (x[i - 1] if i else u[0]) for i in range(n)])
+
+        def info(self):
+            return {"states": [f"z{i}" for i in range(10)], "inputs": ["v"], "disturbances": [], "parameters": {}}
+
+    N = 12
+    p = {"custom_model": chain(), "N": N, "tsim": 6.0, "x0": np.concatenate([np.ones(10), [0.5]]), "SP": {"z9": [0.5] * N},
+         "a_space": {"low": np.array([-1.0]), "high": np.array([1.0])},
+         "o_space": {"low": -5 * np.ones(11), "high": 5 * np.ones(11)}}
+    s = EnvSpec(p)
+    assert s.model.model_id == M.USER and s.nx == 10 and s.affine_AB is None
+    assert "dx[9] = (double)((((-1.0) * x[9]) + x[8]));" in s.user_rhs_src
