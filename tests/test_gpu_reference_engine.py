@@ -106,3 +106,23 @@ def test_engine_argument_and_failure_behaviour():
     assert np.isfinite(eng2.jax_step(x, np.array([500.0, 1000.0]))).all()
     with pytest.raises(ValueError):
         hip_integration_engine(None, None)
+
+
+def test_engine_with_a_python_custom_model():
+    """the reference hands its engine the env_params it was given, custom_model object included (integrator.py:19-31): a
+    non-affine Python model is traced and compiled, and the engine integrates it like the reference's CVODES would"""
+    from scipy.integrate import solve_ivp
+
+    from pcgym_amd import hip_integration_engine
+    from test_gpu_user_model import _ChemostatObject, _chemostat_params
+
+    p = _chemostat_params(integrator="dopri5", rtol=1e-10, atol=1e-12)
+    p["custom_model"] = _ChemostatObject()
+    eng = hip_integration_engine(None, p)
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        x = np.array([rng.uniform(0.2, 2.0), rng.uniform(0.05, 3.0)])
+        u = np.array([rng.uniform(0.0, 0.45)])
+        xf = eng.casadi_step(np.concatenate([x, [1.4]]), u)["xf"].full()[:, 0]
+        r = solve_ivp(lambda t, y: _ChemostatObject()(y, u), (0.0, eng.spec.dt), x, method="LSODA", rtol=1e-12, atol=1e-14)
+        assert np.all(np.abs(xf - r.y[:, -1]) <= 1e-8 * np.maximum(np.abs(r.y[:, -1]), 1e-3))
