@@ -57,7 +57,7 @@ class hip_integration_engine:
         self.spec = spec = EnvSpec(p)
         cfg, keep = spec.to_cfg()
         key = (spec.model.model_id, spec.integrator, spec.substeps, spec.rtol, spec.atol, spec.max_steps, spec.dt,
-               spec.nu, tuple(np.asarray(spec.param_vector()).ravel().tolist()))
+               spec.nu, tuple(np.asarray(spec.param_vector()).ravel().tolist()), spec.user_rhs_src)
         ent = _PLANS.get(key)
         if ent is None:
             plan = C.c_void_p()
