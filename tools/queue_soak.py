@@ -24,7 +24,9 @@ def main():
     names = ["me_canonical", "me_dist_cons", "me_reactive", "cstr_canonical", "complex_cstr_sp", "biofilm_sp"]
     for it in range(iters):
         name = names[it % len(names)]
-        B = int(rng.choice([rng.integers(1, 600), rng.integers(600, 6000), rng.integers(100000, 400000)], p=[0.45, 0.4, 0.15]))
+        # (past 524,288 envs a workgroup walks several 1024-slot tiles)
+        B = int(rng.choice([rng.integers(1, 600), rng.integers(600, 6000), rng.integers(100000, 400000),
+                            rng.integers(600000, 1600000)], p=[0.45, 0.37, 0.13, 0.05]))
         pe = bool(rng.integers(0, 2))
         ar = bool(rng.integers(0, 2))
         p = copy.deepcopy(S[name]["env_params"])
@@ -36,7 +38,7 @@ def main():
         if pe:  # spread the per-env counters so that some envs finish (and reset) inside the window
             t0 = torch.tensor(rng.integers(0, q.N - 1, B), dtype=torch.int32, device=q.device)
             q.t_env.copy_(t0), c.t_env.copy_(t0)
-        steps = 4 if B > 50000 else 8
+        steps = 2 if B > 500000 else 4 if B > 50000 else 8
         for i in range(steps):
             a = torch.tensor(rng.uniform(-1, 1, (q.spec.na, B)), device=q.device)
             if not q.spec.normalise_a:
