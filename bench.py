@@ -258,6 +258,23 @@ def clock_preheat(torch, dev, ms):
     return (time.perf_counter() - t0) * 1e3
 
 
+def self_launch(n):
+    """`python3 bench.py --gpus N` without a launcher: re-run this command line as N ranks of ONE node under
+    torch.distributed.run (the command the driver's contract names).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,9 +303,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed as `python3 bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on
+        # this node (rendezvous on 127.0.0.1, a free port), same argv; rank 0 of the children prints the JSON line
+        raise SystemExit(self_launch(args.gpus))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
-                         f"(WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         "(or without torch.distributed.run: bench.py starts its own ranks)")
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
     # PCG_BENCH_BACKEND=gloo is an explicit TEST switch: it lets the N-rank code path run on a box with fewer GPUs than
     # ranks (ranks share devices).  The default is RCCL with one rank per GPU; if RCCL cannot initialise the run FAILS

@@ -84,3 +84,16 @@ def test_two_rank_mixed_workload():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"] and d["config"]["sane"]
+
+
+def test_gpus_n_as_typed_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with no launcher and no WORLD_SIZE (how the driver types its N = 1 command): bench.py
+    becomes the launcher itself -- one JSON line, two ranks seen by the communicator."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PCG_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "70", "--warmup", "11",
+                        "--preheat-ms", "20"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["collective_backend"] == "gloo"
+    assert d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"] and d["config"]["sane"]
