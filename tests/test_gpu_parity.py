@@ -406,17 +406,13 @@ def test_batched_step_vs_oracle(name, kw, tol, per_env_t, B):
             env.x.copy_(torch.tensor(orc.x, device=env.device))
         elif adaptive:
             # quantised controller: both sides take the same step sequence for EVERY env, so the adaptive path is
-            # held to round-off like the fixed-step one, over the whole 12-step trajectory (no re-synchronisation);
-            # the stability-limited extraction model: helpers.adaptive_check
+            # held to round-off like the fixed-step one, over the whole 12-step trajectory (no re-synchronisation)
             ta = max(tol, 1e-11)
             H.adaptive_check(spec.model.name, env.x.cpu().numpy(), orc.x, env.nsteps.cpu().numpy(), orc.nsteps,
                              (name, i), tol=ta)
             assert not env.status.any()
-            if spec.model.name in H.STABILITY_LIMITED:
-                env.x.copy_(torch.tensor(orc.x, device=env.device))  # re-sync: every step is a one-step test
-            else:
-                assert np.max(eo) <= ta * 10, (name, i, np.max(eo))
-                assert np.max(er) <= max(ta * (1e3 if ta < 1e-9 else 20), 1e-9), (name, i)
+            assert np.max(eo) <= ta * 10, (name, i, np.max(eo))
+            assert np.max(er) <= max(ta * (1e3 if ta < 1e-9 else 20), 1e-9), (name, i)
         else:
             assert np.max(eo) <= tol * 10, (name, i)
             assert np.max(ex) <= tol, (name, i)
@@ -425,7 +421,7 @@ def test_batched_step_vs_oracle(name, kw, tol, per_env_t, B):
         if spec.ncon:
             assert np.mean(env.viol.cpu().numpy() == orc.viol) >= 0.999
             gs = np.maximum(np.abs(orc.g), 1e-3 * np.max(np.abs(orc.g)))
-            gtol = 2e-5 if (adaptive and spec.model.name in H.STABILITY_LIMITED) else max(tol * 100, 1e-10)
+            gtol = max(tol * 100, 1e-10)
             if spec.integrator == "rodas3":
                 gtol = 1e-4  # covers an env whose two sides took a different number of steps
             assert np.max(np.abs(env.g.cpu().numpy() - orc.g) / gs) <= gtol
@@ -891,14 +887,11 @@ def test_random_configurations_vs_oracle(seed):
             # tolerance is 1e-8)
             H.adaptive_check(spec.model.name, xg[:, ok], orc.x[:, ok], env.nsteps.cpu().numpy()[:, ok], orc.nsteps[:, ok],
                              (seed, i), tol=1e-9)
-        if adaptive and spec.model.name in H.STABILITY_LIMITED:
-            env.x.copy_(torch.tensor(orc.x, device=env.device))
-        else:
-            assert np.max(ex) <= (1e-9 if adaptive else 1e-10), (seed, i, spec.model.name)
-            ogn, rgn = og.cpu().numpy().T[:, ok], rg.cpu().numpy()[ok]
-            assert np.max(np.abs(ogn - oc[:, ok]) / np.maximum(np.abs(oc[:, ok]), 1e-3)) <= (1e-8 if adaptive else 1e-9), (seed, i)
-            assert np.allclose(rgn, rc[ok], rtol=1e-8, atol=1e-9), (seed, i)
-            assert np.mean(dg.cpu().numpy().astype(np.uint8)[ok] == dc[ok]) >= 0.999, (seed, i)
+        assert np.max(ex) <= (1e-9 if adaptive else 1e-10), (seed, i, spec.model.name)
+        ogn, rgn = og.cpu().numpy().T[:, ok], rg.cpu().numpy()[ok]
+        assert np.max(np.abs(ogn - oc[:, ok]) / np.maximum(np.abs(oc[:, ok]), 1e-3)) <= (1e-8 if adaptive else 1e-9), (seed, i)
+        assert np.allclose(rgn, rc[ok], rtol=1e-8, atol=1e-9), (seed, i)
+        assert np.mean(dg.cpu().numpy().astype(np.uint8)[ok] == dc[ok]) >= 0.999, (seed, i)
         if per_env_t:
             assert np.array_equal(env.t_env.cpu().numpy(), orc.t_env)
     env.close()
@@ -933,8 +926,6 @@ def test_random_configurations_rollout_equals_stepping(seed):
     e2.reset()
     obs_seq, rew_seq = e2.rollout(acts, collect_obs=True, collect_rew=True)
     tol = 1e-11  # adaptive plans included: same per-env step sequences in both kernels
-    if spec.integrator == "dopri5" and spec.model.name in H.STABILITY_LIMITED:
-        tol = 2e-6  # two differently compiled kernels: last-bit differences, chaotic step sequences (helpers.py)
     for i in range(T):
         o, r, d, _, _ = e1.step(acts[i])
         # (equal_nan: a random configuration can empty a tank -- sqrt of a negative level is NaN in the reference's RHS
@@ -971,8 +962,6 @@ def test_lock_stepped_auto_reset_in_the_last_step_launch(name, B):
     env.reset()
     orc.reset()
     tol = 1e-10 if env.spec.integrator == "dopri5" else 1e-11
-    if env.spec.model.name in H.STABILITY_LIMITED:
-        tol = 2e-6  # different, equally valid step sequences for a few % of the envs (helpers.py)
     for i in range(2 * (N - 1) + 3):
         a = np.random.default_rng(i).uniform(-1, 1, (env.spec.na, B))
         og, rg, dg, _, _ = env.step(torch.tensor(a, device=env.device))
@@ -1129,15 +1118,15 @@ def test_full_size_me_and_cryst_properties():
         orc.step(a[:, :n_or].cpu().numpy())
         tru.step(a[:, :n_or].cpu().numpy())
     assert torch.equal(env.x[:, perm], env2.x) and torch.equal(env.rew[perm], env2.rew)
-    ex = np.abs(env.x[:, :n_or].cpu().numpy() - orc.x) / np.maximum(np.abs(orc.x), 1e-6)
-    assert ex.max() <= 2e-6 and np.mean(ex.max(axis=0) <= 1e-9) >= 0.5, ex.max()  # stability-limited: helpers.py
-    # three steps without re-synchronisation: an env that left the common sequence once stays off it
-    assert np.mean(np.all(env.nsteps[:, :n_or].cpu().numpy() == orc.nsteps, axis=0)) >= 0.6
-    # both sides are equally close to the 1e-12 solution: the GPU's step sequences are as valid as the oracle's
+    # the 10-state model's right-hand side is an exactly specified operation sequence (helpers.BIT_EXACT_RHS): after
+    # three steps WITHOUT re-synchronisation every env of the slice is still on the oracle's step sequence -- identical
+    # accepted / rejected counts, states to round-off (H.adaptive_check asserts same.all() and <= 1e-11)
+    H.adaptive_check("multistage_extraction", env.x[:, :n_or].cpu().numpy(), orc.x,
+                     env.nsteps[:, :n_or].cpu().numpy(), orc.nsteps, "configs[2] full size, slice of 2048", tol=1e-11)
+    # and that common sequence is a valid solution of the step: within the tolerance class of the 1e-12 solve
     sc_t = np.maximum(np.abs(tru.x), 1e-6)
     et = (np.abs(env.x[:, :n_or].cpu().numpy() - tru.x) / sc_t).max()
-    eo = (np.abs(orc.x - tru.x) / sc_t).max()
-    assert et <= 3e-6 and et <= 3 * max(eo, 1e-7), (et, eo)
+    assert et <= 3e-6, et
     for i in range(150):  # hold the input: the cascade settles (time constants of a few model time units)
         env.step(a)
     assert torch.isfinite(env.x).all()
@@ -1146,8 +1135,10 @@ def test_full_size_me_and_cryst_properties():
     L, G = LG[0], LG[1]
     X0, Y6 = 0.6, 0.05  # model defaults, model_classes.py:366-367
     bal = L * (X0 - env.x[8]) - G * (env.x[1] - Y6)
-    # (over the full box the adaptive pair sits at its stability limit: the balance closes to ~1e-5 of the feed)
-    assert (bal.abs() / (L * X0)).max().item() <= 5e-5
+    # the balance closes to the integrator's absolute tolerance on the two concentrations it differences, times the
+    # flows that multiply them: |bal| <= k atol (L + G); k = 4.7 is the largest value over 32,768 envs on the oracle
+    # (same step sequences), 10 is asserted -- per env, so a loose lane cannot hide behind the feed of a large one
+    assert (bal.abs() <= 10 * 1e-8 * (L + G)).all(), (bal.abs() / (1e-8 * (L + G))).max().item()
     env.close()
     env2.close()
     # ---- crystallisation ---------------------------------------------------------------------
