@@ -293,6 +293,8 @@ def main():
     ap.add_argument("--substeps", type=int, default=None,
                     help="cstr workload: RK4 sub-steps per env step (1 = the headline; other values are probes)")
     ap.add_argument("--status", type=int, default=1, help="write the per-env status byte (0 = off, A/B)")
+    ap.add_argument("--integrator", default=None, choices=["dopri5", "rodas4", "rodas3"],
+                    help="me10 / me20 / mixed: integrator of the extraction envs (default: the workload's named one)")
     args = ap.parse_args()
 
     import numpy as np
@@ -346,6 +348,10 @@ def main():
 
         # global layout [cstr x world | four_tank x world | ME x world]; every rank owns the same slice of every segment
         segs_global = [(params, n * world) for params, n in mixed_segments(B)]
+        if args.integrator:
+            segs_global[2][0]["integrator"] = args.integrator
+            for k in ("rtol", "atol"):
+                segs_global[2][0].pop(k, None)
         K = args.steps if args.steps is not None else 118
         W = args.warmup if args.warmup is not None else 12
         menv = make_mixed_sharded_env(segs_global, rank=rank, world=world, device=dev, seed=1234, auto_reset=True,
@@ -369,6 +375,11 @@ def main():
         spec = envs[2].spec
     else:
         wl_name, params, Bd, (Kd, Wd), n_act = single_workload(args.workload)
+        if args.integrator and args.workload in ("me10", "me20"):
+            params["integrator"] = args.integrator
+            for k in ("rtol", "atol"):  # the integrator's own default tolerance for this model (config.ROS4_TOL)
+                params.pop(k, None)
+            wl_name = wl_name.replace("dopri5_1e-8", args.integrator)
         B = args.batch or Bd
         K = args.steps if args.steps is not None else Kd
         W = args.warmup if args.warmup is not None else Wd
@@ -531,7 +542,7 @@ def main():
             bpe = env.bytes_per_env_step  # SURVEY.md section 8d formula for this plan and buffer set
             alg_bytes = float(bpe) * B
             achieved = alg_bytes / kern_avg_s / 1e9
-            adaptive = spec.integrator == "dopri5"
+            adaptive = spec.integrator != "rk4"
             fp64 = spec.model.name in FLOP_PER_RHS
             rl = {
                 "bound": "hbm",

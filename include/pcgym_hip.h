@@ -49,7 +49,7 @@ typedef unsigned long uintptr_t;
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 7
+#define PCG_ABI_VERSION 8
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -127,7 +127,20 @@ enum pcg_integrator {
                           reference integrates with CVODES BDF (integrator.py:163-182).  Every model (nx <= 24);
                           pcg_step, pcg_step_autoreset, pcg_graph_* and pcg_integrate; pcg_rollout and plans with
                           per-env uncertain parameters return PCG_E_UNSUPPORTED */
-  PCG_INT_COUNT = 3
+  PCG_INT_RODAS4 = 3,  /* stiff-capable, fourth order: adaptive Rodas4 (Hairer & Wanner's RODAS: 6-stage linearly implicit
+                          Rosenbrock 4(3) pair, gamma = 1/4, L-stable, stiffly accurate), same controller family as
+                          Rodas3 (RMS norm, quantised factor 0.9 E^-1/4 in [0.2, 6]).  Linear algebra: models with a
+                          structured analytic Jacobian (the 10-state extraction cascade: block-bidiagonal in both
+                          directions) factor and solve W = I/(gamma h) - J in registers (6 reciprocals and ~230 flops per
+                          step); every other model uses the forward-difference Jacobian and the per-lane pivoted LU in
+                          LDS of Rodas3.  END-POINT ERROR CONTROL (cfg.ep_kmax > 0, models with a contraction-rate
+                          hook): an env step only hands x(dt) on, and an error committed at time t is damped by
+                          exp(-mu (dt - t)) on its way there, so the local tolerance of an attempted step ending at t'
+                          is multiplied by 2^k, k = min(ep_kmax, floor(ep_frac mu log2(e) (dt - t'))) -- exact powers of
+                          two, bit-identical in kernel and oracle.  The reference integrates with CVODES BDF
+                          (integrator.py:163-182).  pcg_step, pcg_step_autoreset, pcg_graph_*, pcg_integrate;
+                          pcg_rollout and per-env uncertain parameters: PCG_E_UNSUPPORTED */
+  PCG_INT_COUNT = 4
 };
 
 /* cfg.flags */
@@ -261,6 +274,10 @@ typedef struct pcg_env_cfg {
    * modes), pcg_integrate and pcg_rhs; any integrator; composes with user_cons_src / user_reward_src.  Not available:
    * pcg_rollout, per-env uncertain parameters. */
   const char* user_rhs_src;
+  /* PCG_INT_RODAS4, end-point error control (see enum pcg_integrator): 0 / 0 = classical local error control */
+  double ep_frac;         /* fraction of the model's contraction rate credited to the damping (0.5 by default: the cascade
+                             is non-normal -- a perturbation travels down the stages before it decays)                 */
+  int32_t ep_kmax;        /* largest exponent: tolerances are relaxed by at most 2^ep_kmax (10 by default, 0 = off)    */
 } pcg_env_cfg;
 
 /*

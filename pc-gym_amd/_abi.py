@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PCG_ABI_VERSION = 7
+PCG_ABI_VERSION = 8
 PCG_MAX_NX = 24
 PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
@@ -42,6 +42,7 @@ PCG_OPT_NT_STORES = 5
 PCG_INT_RK4 = 0
 PCG_INT_DOPRI5 = 1
 PCG_INT_RODAS3 = 2
+PCG_INT_RODAS4 = 3
 
 PCG_F_NORMALISE_A = 0x0001
 PCG_F_NORMALISE_O = 0x0002
@@ -124,6 +125,8 @@ class pcg_env_cfg(C.Structure):
         ("user_reward_src", C.c_char_p),
         ("jit_include_dir", C.c_char_p),
         ("user_rhs_src", C.c_char_p),
+        ("ep_frac", C.c_double),
+        ("ep_kmax", C.c_int32),
     ]
 
 

@@ -7,7 +7,10 @@ Mirrors the parsing done by the reference ``make_env.__init__`` and its
 C ABI.  Nothing numeric about the hot path happens here.
 
 New optional keys (do not exist in the reference):
-  integrator   'rk4' | 'dopri5' | 'rodas3' (stiff-capable Rosenbrock)   (default per model, see DEFAULT_INTEGRATOR)
+  integrator   'rk4' | 'dopri5' | 'rodas3' | 'rodas4' (stiff-capable Rosenbrock pairs)   (default per model, see
+               DEFAULT_INTEGRATOR)
+  endpoint_control  rodas4 only: {'frac': 0.5, 'kmax': 10} | False -- end-point error control (pcgym_hip.h,
+               PCG_INT_RODAS4); on by default, acts only on models with a contraction-rate hook (extraction cascades)
   substeps     RK4 sub-steps per env step
   rtol, atol   DOPRI5 tolerances (default 1e-8, integrator.py:61)
   max_steps    DOPRI5 step budget per env step
@@ -61,6 +64,10 @@ DEFAULT_RK4_H = {M.CSTR: 26.0 / 60.0 / 4, M.FOUR_TANK: 1000.0 / 60.0 / 4, M.ME: 
 # 6.5e-5 at 1e-8, 7.2e-6 at 1e-9, 3.5e-7 at 1e-10 -- the last is inside the 1e-6 class of the reference's CVODES
 # defaults everywhere, at ~1.8x the steps of 1e-8.
 DEFAULT_TOL = {M.CSTR: 1e-10}
+# integrator = 'rodas4' (fourth-order Rosenbrock pair with end-point error control): tolerance that keeps one env step
+# of the extraction cascade within 1e-6 of a 1e-13 solve over its whole action box (worst lanes: low liquid flow, high
+# gas flow -- 6.5e-7 at 3e-8; tests/test_rodas4.py), the class of the explicit pair at 1e-8 (5.5e-7)
+ROS4_TOL = {M.ME: 3e-8}
 
 
 def default_substeps(model_id, dt):
@@ -672,14 +679,23 @@ class EnvSpec:
         if self.integration_method == "jax":
             d_int = "dopri5"
         self.integrator = p.get("integrator", d_int)
-        if self.integrator not in ("rk4", "dopri5", "rodas3"):
-            raise ValueError("integrator must be 'rk4', 'dopri5' or 'rodas3'")
+        if self.integrator not in ("rk4", "dopri5", "rodas3", "rodas4"):
+            raise ValueError("integrator must be 'rk4', 'dopri5', 'rodas3' or 'rodas4'")
+        epc = p.get("endpoint_control", True)
+        self.ep_frac, self.ep_kmax = 0.0, 0
+        if self.integrator == "rodas4" and epc is not False and epc is not None:
+            epc = {} if epc is True else dict(epc)
+            self.ep_frac, self.ep_kmax = float(epc.get("frac", 0.5)), int(epc.get("kmax", 10))
+            if not (0.0 <= self.ep_frac <= 1.0) or not (0 <= self.ep_kmax <= 40):
+                raise ValueError("endpoint_control: frac must lie in [0, 1] and kmax in [0, 40]")
         d_sub = default_substeps(self.model.model_id, self.dt)
         if self.affine_AB is not None:
             # affine models: keep |A|_inf * h <= 0.05 (RK4 local error ~ (|A| h)^5 / 120)
             d_sub = max(8, int(np.ceil(self.dt * np.abs(self.affine_AB[0]).sum(axis=1).max() / 0.05)))
         self.substeps = int(p.get("substeps", d_sub))
         d_tol = 1e-8 if self.integration_method == "jax" else DEFAULT_TOL.get(self.model.model_id, 1e-8)
+        if self.integrator == "rodas4":
+            d_tol = ROS4_TOL.get(self.model.model_id, d_tol)
         self.rtol = float(p.get("rtol", d_tol))
         self.atol = float(p.get("atol", d_tol))
         self.max_steps = int(p.get("max_steps", 100000))
@@ -839,7 +855,9 @@ class EnvSpec:
         params = self.param_vector()
         cfg = abi.pcg_env_cfg()
         cfg.model_id = self.model.model_id
-        cfg.integrator_id = {"rk4": abi.PCG_INT_RK4, "dopri5": abi.PCG_INT_DOPRI5, "rodas3": abi.PCG_INT_RODAS3}[self.integrator]
+        cfg.integrator_id = {"rk4": abi.PCG_INT_RK4, "dopri5": abi.PCG_INT_DOPRI5, "rodas3": abi.PCG_INT_RODAS3,
+                             "rodas4": abi.PCG_INT_RODAS4}[self.integrator]
+        cfg.ep_frac, cfg.ep_kmax = self.ep_frac, self.ep_kmax
         cfg.nx, cfg.na, cfg.ndm, cfg.nd = self.nx, self.na, self.ndm, self.nd
         cfg.nsp, cfg.ncon, cfg.nrew, cfg.N = self.nsp, self.ncon, self.nrew, self.N
         cfg.nsp_obs = self.nsp_obs

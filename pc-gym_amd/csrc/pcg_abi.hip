@@ -92,6 +92,7 @@ struct pcg_plan {
   int feat_occ[MAX_FEAT];  // resident workgroups per CU of the feature-masked kernels (0 = not queried yet)
   int q_bpc[2], q_tile[2]; // work-queue kernel [per_env_t]: resident workgroups per CU, tile slots (0 = not chosen yet,
                            // -1 = does not fit)
+  int q_tile1[2];          // the largest tile with ONE workgroup per CU (Rodas4: launches that fit one tile per CU)
   int64_t env_offset;
   DevConst hc;       // host copy
   DevConst* dC;      // device copy
@@ -374,6 +375,13 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   d->rtol = c->rtol;
   d->dt_edge = c->dt * (1.0 - 1e-14);
   d->h_floor = 1e-13 * c->dt;
+  // end-point error control of PCG_INT_RODAS4 (pcgym_hip.h): exponent rate = ep_c x the model's contraction rate
+  if (c->integrator_id == PCG_INT_RODAS4) {
+    if (!(c->ep_frac >= 0.0 && c->ep_frac <= 1.0) || c->ep_kmax < 0 || c->ep_kmax > 40) return PCG_E_VALUE;
+    if (c->nunc > 0) return PCG_E_UNSUPPORTED;
+    d->ep_kmax = c->ep_kmax;
+    d->ep_c = c->ep_kmax > 0 ? c->ep_frac * 1.4426950408889634 : 0.0;
+  }
   d->atol = c->atol;
   d->nx = nx; d->na = na; d->ndm = ndm; d->nd = nd; d->nsp = nsp; d->nsp_obs = nso; d->ncon = ncon; d->nrew = nrew;
   d->N = c->N; d->substeps = c->substeps; d->max_steps = c->max_steps; d->nobs = nobs;
@@ -561,7 +569,7 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   p->stream_occ[0] = p->stream_occ[1] = 0;
   p->pipe_occ[0][0] = p->pipe_occ[0][1] = p->pipe_occ[1][0] = p->pipe_occ[1][1] = 0;
   for (int i = 0; i < MAX_FEAT; ++i) p->feat_occ[i] = 0;
-  p->q_bpc[0] = p->q_bpc[1] = p->q_tile[0] = p->q_tile[1] = 0;
+  p->q_bpc[0] = p->q_bpc[1] = p->q_tile[0] = p->q_tile[1] = p->q_tile1[0] = p->q_tile1[1] = 0;
   p->env_offset = 0;
   p->dC = nullptr;
   p->dsched = nullptr;
@@ -702,28 +710,39 @@ static int resident_blocks(StepFn fn) {
 static int queue_geometry(pcg_plan* p, const Kernels& k, int pe, size_t sched_bytes) {
   if (p->q_tile[pe] != 0) return PCG_OK;
   hipFuncAttributes fa;
-  hipError_t e = hipFuncGetAttributes(&fa, (const void*)k.queue[pe]);
+  const StepFn qfn = (p->integrator_id == PCG_INT_RODAS4 ? k.queue_r4 : k.queue)[pe];
+  hipError_t e = hipFuncGetAttributes(&fa, (const void*)qfn);
   if (e != hipSuccess) return (int)e;
   const int alloc = ((fa.numRegs + 7) / 8) * 8;
   int bpc = alloc > 0 ? 512 / alloc : 1;
   bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
+  if (const char* ev = std::getenv("PCG_Q_BPC")) {  // measurement switch: fewer resident workgroups per CU
+    const int v = std::atoi(ev);
+    if (v >= 1 && v < bpc) bpc = v;
+  }
   const size_t lds_cu = 160 * 1024 - 2048;
-  int best_t = 0, best_b = 1;
+  // tile cap: four envs per lane for the explicit pair (tuned in round 2); the Rosenbrock pair's attempts per env are
+  // heavy-tailed (median 17, 1 % above 70, maximum ~100 on BASELINE configs[2]) and want the largest pool
+  const int tcap = p->integrator_id == PCG_INT_RODAS4 ? QSORT : QSORT / 2;
+  int best_t = 0, best_b = 1, t1 = 0;
   for (int b = bpc; b >= 1; --b) {
-    int T = QSORT;
+    int T = tcap;
     while (T >= QBLOCK && k.queue_lds(T) + sched_bytes > lds_cu / b) T -= 64;
     if (T < QBLOCK) continue;
+    if (b == 1) t1 = T;
     if (b * T > best_b * best_t) {
       best_t = T;
       best_b = b;
     }
-    if (T == QSORT) break;  // the full tile at the highest occupancy that allows it
+    if (T == tcap && p->integrator_id != PCG_INT_RODAS4) break;  // the full tile at the highest occupancy that allows it
   }
   p->q_tile[pe] = best_t > 0 ? best_t : -1;
   p->q_bpc[pe] = best_b;
+  p->q_tile1[pe] = t1;
   if (best_t > 0) {
-    e = hipFuncSetAttribute((const void*)k.queue[pe], hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(k.queue_lds(best_t) + sched_bytes));
+    const int tmax = t1 > best_t ? t1 : best_t;
+    e = hipFuncSetAttribute((const void*)qfn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(k.queue_lds(tmax) + sched_bytes));
     if (e != hipSuccess) return (int)e;
   }
   return PCG_OK;
@@ -745,7 +764,7 @@ static int warm_occupancy(pcg_plan* p) {
       p->stream_occ[e] = q;
     }
   }
-  if (p->integrator_id == PCG_INT_DOPRI5 && k.queue[0]) {
+  if ((p->integrator_id == PCG_INT_DOPRI5 && k.queue[0]) || (p->integrator_id == PCG_INT_RODAS4 && k.queue_r4[0])) {
     const int rc = queue_geometry(p, k, 0, 0);
     if (rc != PCG_OK) return rc;
   }
@@ -777,8 +796,9 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   const Kernels& k = kernels(p->kid);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
   const int knx = p->model_id == PCG_MODEL_USER ? p->nx : k.nx;  // the kernels' compile-time state count
-  const int block = tb(lds_st, p->integrator_id, knx);
-  size_t shmem = sizeof(double) * integ_lds_doubles(knx, p->integrator_id, lds_st);
+  const bool rstr = p->model_id != PCG_MODEL_USER && k.ros_structured;  // Rodas4 with the model's own W: no LDS
+  const int block = tb(lds_st, p->integrator_id, knx, rstr);
+  size_t shmem = sizeof(double) * integ_lds_doubles(knx, p->integrator_id, lds_st, rstr);
   const size_t integ_shmem = shmem;
   if (per_env_t) {
     const size_t sb = sizeof(double) * (size_t)(c.nsp + c.nd) * c.N;
@@ -812,7 +832,9 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   }
   // Adaptive plans: the work-queue kernel (lanes that finish early pull the next env from an LDS tile).
   // PCG_OPT_VARIANT 1 keeps the classic one-env-per-lane kernel (A/B measurement), PCG_OPT_LDS_STAGES too.
-  if (p->integrator_id == PCG_INT_DOPRI5 && !lds_st && p->variant == 0 && k.queue[per_env_t ? 1 : 0] &&
+  const bool r4q = p->integrator_id == PCG_INT_RODAS4;
+  const StepFn* qtab = r4q ? k.queue_r4 : k.queue;
+  if ((p->integrator_id == PCG_INT_DOPRI5 || r4q) && !lds_st && p->variant == 0 && qtab[per_env_t ? 1 : 0] &&
       (k.queue_default || std::getenv("PCG_Q_FORCE") != nullptr)) {
     const int pe = per_env_t ? 1 : 0;
     const size_t sb = (per_env_t && a.sched_in_lds) ? sizeof(double) * (size_t)(c.nsp + c.nd) * c.N : 0;
@@ -826,9 +848,18 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       }
       if (std::getenv("PCG_Q_NOSORT")) a.q_tile |= 0x10000;  // measurement switch: FIFO order
       if (const char* ev = std::getenv("PCG_Q_REFILL")) a.q_tile |= (std::atoi(ev) & 0x7F) << 20;  // measurement switch
-      a.q_w = 20.0f;  // tools/queue_w_sweep.sh: 0 / 10 / 20 / 33 -> me10 0.689 / 0.684 / 0.683 / 0.719 ms, configs[4] shard 0.964 / 0.938 / 0.920 / 0.924 ms
+      a.q_w = r4q ? 3.56f : 20.0f;  // (Rodas4: the fit of MEImpl::cost_key_ros) tools/queue_w_sweep.sh: 0 / 10 / 20 / 33 -> me10 0.689 / 0.684 / 0.683 / 0.719 ms, configs[4] shard 0.964 / 0.938 / 0.920 / 0.924 ms
       if (const char* ev = std::getenv("PCG_Q_W")) a.q_w = (float)std::atof(ev);  // measurement switch: key weight
-      int64_t nwg = (int64_t)p->num_cus * p->q_bpc[pe];
+      int q_bpc = p->q_bpc[pe];
+      // Rodas4: a launch is as long as its heaviest env (~100 attempts against a mean of 22), and a wave that has its
+      // SIMD to itself runs an attempt in 2.9 us against 4.7 us when two share it: when the batch fits ONE tile per CU,
+      // one workgroup per CU with the whole pool in one tile beats two half pools (me10: 0.444 -> 0.375 ms)
+      if (r4q && p->q_tile1[pe] > 0 && !std::getenv("PCG_Q_BPC") &&
+          (io->B + p->num_cus - 1) / p->num_cus <= p->q_tile1[pe] && !std::getenv("PCG_Q_TILE")) {
+        q_bpc = 1;
+        a.q_tile = (a.q_tile & ~0xFFFF) | p->q_tile1[pe];
+      }
+      int64_t nwg = (int64_t)p->num_cus * q_bpc;
       const int64_t cap = (io->B + QBLOCK - 1) / QBLOCK;  // no workgroup with less than one env per lane
       if (nwg > cap) nwg = cap;
       // The queue only pays when its tiles are well filled: with fewer than ~1.75 envs per lane in a sub-tile the
@@ -839,7 +870,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       const int64_t nsub = (per + Tq - 1) / Tq;
       const bool filled = (per + nsub - 1) / nsub >= (7 * QBLOCK) / 4 || std::getenv("PCG_Q_FORCE") != nullptr;
       if (filled) {
-      hipLaunchKernelGGL(k.queue[pe], dim3((unsigned)nwg), dim3(QBLOCK), k.queue_lds(a.q_tile & 0xFFFF) + sb,
+      hipLaunchKernelGGL(qtab[pe], dim3((unsigned)nwg), dim3(QBLOCK), k.queue_lds(a.q_tile & 0xFFFF) + sb,
                          (hipStream_t)stream, a);
       return (int)hipGetLastError();
       }
@@ -1154,8 +1185,8 @@ int pcg_integrate(pcg_plan* p, int64_t B, double* x, const double* u, int32_t* n
   if (p->model_id == PCG_MODEL_USER) return PCG_E_PLAN;
   const Kernels& k = kernels(p->kid);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
-  const int block = tb(lds_st, p->integrator_id, k.nx);
-  const size_t shmem = sizeof(double) * integ_lds_doubles(k.nx, p->integrator_id, lds_st);
+  const int block = tb(lds_st, p->integrator_id, k.nx, k.ros_structured);
+  const size_t shmem = sizeof(double) * integ_lds_doubles(k.nx, p->integrator_id, lds_st, k.ros_structured);
   IntKFn fn = k.integ[p->integrator_id][lds_st ? 1 : 0];
   if (!fn) return PCG_E_UNSUPPORTED;
   if (shmem > 48 * 1024)

@@ -479,4 +479,288 @@ PCG_DEV int rodas3(const F& f, const RosLds<NX>& L, double (&x)[NX], int n, doub
   return status;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rodas4 -- the fourth-order stiff integrator (PCG_INT_RODAS4; the
+// reference solves with CVODES BDF, integrator.py:163-182).  Hairer & Wanner's RODAS, coefficient set of their code's
+// METH = 1: 6 stages, order 4 with an embedded order-3 solution, gamma = 1/4, L-stable, stiffly accurate.  Transformed
+// form (one matrix W = I/(gamma h) - J per step, no matrix-vector products):
+//     W U_i = f(x + sum_j a_ij U_j) + sum_j (c_ij / h) U_j,     y_5 = x + sum a_5j U_j,  y_6 = y_5 + U_5,
+//     x_new = y_6 + U_6,   error estimate = U_6.
+// The linear algebra is a POLICY:
+//   RosDense       forward-difference Jacobian + per-lane pivoted LU in LDS (the machinery of rodas3(): any model);
+//   RosStructured  models that export their W analytically with its structure (M::ROS_STRUCTURED: the 10-state
+//                  extraction cascade, two interleaved bidiagonal chains coupled stage by stage) factor and solve in
+//                  registers without pivoting -- 6 reciprocals + ~30 flops per factorisation, ~33 flops per solve,
+//                  no LDS, no extra RHS evaluations.  That is what makes an implicit step as cheap as an attempt of the
+//                  explicit pair (~1000 vector instructions for 10 states) while it takes 3x fewer of them.
+// END-POINT ERROR CONTROL: an env step hands only x(dt) on.  For a model that knows how fast it forgets
+// (M::EP_GROUPS: ep_exponents()) an error committed at time t' < dt arrives there damped by ~exp(-mu (dt - t')), so the
+// attempt that ends at t' is accepted against a tolerance 2^k times the user's, k = min(kmax, trunc(frac mu log2(e)
+// (dt - t'))): lanes whose dynamics forget fast (high through-flow) cross their transient in a few large L-stable
+// steps and tighten towards the end of the interval; lanes that remember (low flow) keep the plain local control.
+// The exponent is per component GROUP (two groups: the liquid and the gas chain of the 10-state cascade): the fast
+// chain's errors only reach the slow one through the mass-transfer coupling, attenuated by coupling rate x residence
+// time, and get that much more room (pcg_models.hpp, MEImpl::ep_exponents).  Powers of two, truncation and exponent
+// extraction: the weights are exact, so the kernel and the oracle take identical step sequences.
+// Controller as for the other pairs: RMS norm, factor Q(0.9 E^-1/4) in [0.2, 6] (<= 1 after a rejection), first step
+// min(Q(5 h0), dt), failure -> PCG_ST_MAX_STEPS / PCG_ST_UNDERFLOW (singular W: reject and shrink).
+// ---------------------------------------------------------------------------------------------------------------
+namespace r4 {
+constexpr double GAM = 0.25;
+constexpr double A21 = 0.1544000000000000e+01, A31 = 0.9466785280815826e+00, A32 = 0.2557011698983284e+00,
+                 A41 = 0.3314825187068521e+01, A42 = 0.2896124015972201e+01, A43 = 0.9986419139977817e+00,
+                 A51 = 0.1221224509226641e+01, A52 = 0.6019134481288629e+01, A53 = 0.1253708332932087e+02,
+                 A54 = -0.6878860361058950e+00;
+constexpr double C21 = -0.5668800000000000e+01, C31 = -0.2430093356833875e+01, C32 = -0.2063599157091915e+00,
+                 C41 = -0.1073529058151375e+00, C42 = -0.9594562251023355e+01, C43 = -0.2047028614809616e+02,
+                 C51 = 0.7496443313967647e+01, C52 = -0.1024680431464352e+02, C53 = -0.3399990352819905e+02,
+                 C54 = 0.1170890893206160e+02, C61 = 0.8083246795921522e+01, C62 = -0.7981132988064893e+01,
+                 C63 = -0.3152159432874371e+02, C64 = 0.1631930543123136e+02, C65 = -0.6058818238834054e+01;
+}  // namespace r4
+
+template <int NX, class F>
+struct RosDense {
+  const F& f;
+  const RosLds<NX>& L;
+  int n;
+  double rtol, atol;
+  // W = I igh - J_fd(x) into LDS, LU with partial pivoting; the statements of rodas3()
+  PCG_DEV bool factor(const double (&x)[NX], const double (&f0)[NX], double igh) const {
+#pragma clang fp contract(off)
+    double y[NX], fy[NX];
+    double xmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xmax = fmax(xmax, (i < n) ? fabs(x[i]) : 0.0);
+    const double wfloor = atol / rtol + 1e-12 * xmax + 1e-100;
+#pragma unroll 1
+    for (int j = 0; j < NX; ++j) {
+      if (j >= n) break;
+      double xj = 0.0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xj = (i == j) ? x[i] : xj;
+      const double del = 1.4901161193847656e-8 * (fabs(xj) + wfloor);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) y[i] = (i == j) ? x[i] + del : x[i];
+      f(y, fy);
+      const double idel = 1.0 / ((xj + del) - xj);
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        if (i < n) L.w(i, j) = -(fy[i] - f0[i]) * idel;
+    }
+    for (int i = 0; i < NX; ++i) {
+      if (i >= n) break;
+      L.w(i, i) = L.w(i, i) + igh;
+    }
+    return ros_lu<NX>(L, n);
+  }
+  PCG_DEV void solve(double (&b)[NX]) const { ros_solve<NX>(L, n, b); }
+};
+
+template <class M, class K>
+struct RosStructured {
+  const K& kp;
+  const typename M::Hold& hold;
+  mutable typename M::RosFac F;
+  PCG_DEV bool factor(const double (&x)[M::NX], const double (&)[M::NX], double igh) const {
+    M::ros_factor(kp, hold, x, igh, F);
+    return F.ok;
+  }
+  PCG_DEV void solve(double (&b)[M::NX]) const { M::ros_solve(F, b); }
+};
+
+// model hooks
+template <class M, class = void>
+struct ros_structured : tt::false_type {};
+template <class M>
+struct ros_structured<M, tt::void_t<decltype(M::ROS_STRUCTURED)>> : tt::true_type {};
+template <class M, class = void>
+struct has_ep_groups : tt::false_type {};
+template <class M>
+struct has_ep_groups<M, tt::void_t<decltype(M::EP_GROUPS)>> : tt::true_type {};
+
+// The end-point weights of one env: exponents of the (at most two) component groups at time-to-go tau.
+template <class M, class K>
+struct EpWeights {
+  const K& kp;
+  const double (&u)[M::NA + M::NDM];
+  double ep_c;
+  int kmax;
+  PCG_DEV void operator()(double tau, int (&kg)[2]) const {
+    kg[0] = kg[1] = 0;
+    if constexpr (has_ep_groups<M>::value) {
+      if (kmax > 0) M::ep_exponents(kp, u, ep_c, kmax, tau, kg);
+    }
+  }
+  PCG_DEV static constexpr int group(int i) {
+    if constexpr (has_ep_groups<M>::value) return M::ep_group(i);
+    else return 0;
+  }
+};
+// mean square of err_i / (atol + rtol max(|y0_i|, |y1_i|)), term i weighted by 4^-kg[group(i)]
+template <int NX, class EP>
+PCG_DEV double ms_scaled_ep(const EP& ep, double tau, const double (&v)[NX], const double (&y0)[NX],
+                            const double (&y1)[NX], int n, double rtol, double atol) {
+#pragma clang fp contract(off)
+  int kg[2];
+  ep(tau, kg);
+  const double sg[2] = {ldexp(1.0, -2 * kg[0]), ldexp(1.0, -2 * kg[1])};
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const double sc = atol + rtol * fmax(fabs(y0[i]), fabs(y1[i]));
+    const double r = v[i] * fast_rcp(sc);  // sc > 0
+    const double w = EP::group(i) ? sg[1] : sg[0];
+    s += (i < n) ? (r * r) * w : 0.0;
+  }
+  return s / n;
+}
+
+// One attempted step of size h from x (f0 = f(x)): the candidate solution in xn, the error estimate in err; returns
+// false when W could not be factorised.
+template <int NX, class F, class LS>
+PCG_DEV bool rodas4_try(const F& f, const LS& ls, const double (&x)[NX], const double (&f0)[NX], double h,
+                        double (&xn)[NX], double (&err)[NX]) {
+#pragma clang fp contract(off)
+  const double igh = 1.0 / (r4::GAM * h), ih = 1.0 / h;
+  const bool lu_ok = ls.factor(x, f0, igh);
+  double U1[NX], U2[NX], U3[NX], U4[NX], U5[NX], y[NX], fy[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) U1[i] = f0[i];
+  ls.solve(U1);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) y[i] = __builtin_fma(r4::A21, U1[i], x[i]);
+  f(y, fy);
+  {
+    const double c21 = r4::C21 * ih;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) U2[i] = __builtin_fma(c21, U1[i], fy[i]);
+  }
+  ls.solve(U2);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) y[i] = __builtin_fma(r4::A32, U2[i], __builtin_fma(r4::A31, U1[i], x[i]));
+  f(y, fy);
+  {
+    const double c31 = r4::C31 * ih, c32 = r4::C32 * ih;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) U3[i] = __builtin_fma(c32, U2[i], __builtin_fma(c31, U1[i], fy[i]));
+  }
+  ls.solve(U3);
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    y[i] = __builtin_fma(r4::A43, U3[i], __builtin_fma(r4::A42, U2[i], __builtin_fma(r4::A41, U1[i], x[i])));
+  f(y, fy);
+  {
+    const double c41 = r4::C41 * ih, c42 = r4::C42 * ih, c43 = r4::C43 * ih;
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      U4[i] = __builtin_fma(c43, U3[i], __builtin_fma(c42, U2[i], __builtin_fma(c41, U1[i], fy[i])));
+  }
+  ls.solve(U4);
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+    y[i] = __builtin_fma(r4::A54, U4[i],
+                         __builtin_fma(r4::A53, U3[i], __builtin_fma(r4::A52, U2[i], __builtin_fma(r4::A51, U1[i], x[i]))));
+  f(y, fy);
+  {
+    const double c51 = r4::C51 * ih, c52 = r4::C52 * ih, c53 = r4::C53 * ih, c54 = r4::C54 * ih;
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      U5[i] = __builtin_fma(c54, U4[i],
+                            __builtin_fma(c53, U3[i], __builtin_fma(c52, U2[i], __builtin_fma(c51, U1[i], fy[i]))));
+  }
+  ls.solve(U5);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) y[i] = y[i] + U5[i];
+  f(y, fy);
+  {
+    const double c61 = r4::C61 * ih, c62 = r4::C62 * ih, c63 = r4::C63 * ih, c64 = r4::C64 * ih, c65 = r4::C65 * ih;
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      fy[i] = __builtin_fma(
+          c65, U5[i],
+          __builtin_fma(c64, U4[i], __builtin_fma(c63, U3[i], __builtin_fma(c62, U2[i], __builtin_fma(c61, U1[i], fy[i])))));
+  }
+  ls.solve(fy);  // U6 = the error estimate
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    xn[i] = y[i] + fy[i];
+    err[i] = fy[i];
+  }
+  return lu_ok;
+}
+
+// the controller's verdict on one attempt, shared by the classic loop and the work-queue form: accept iff E2 < 1;
+// returns the step-size factor
+PCG_DEV double rodas4_factor(double E2, bool ok, bool rejected_last) {
+  double fac = (E2 == E2) ? fmax(0.2, ctrl_pow_e(E2, 0.9, 0.125f, 0.125)) : 0.2;  // NaN -> hardest shrink
+  const double cap = ok ? (rejected_last ? 1.0 : 6.0) : 1.0;
+  return fmin(cap, fac);
+}
+
+// first step size: h0 of Hairer, Norsett & Wanner II.4 (first stage) x 5, quantised.  (rodas3() starts at 100 h0; measured
+// over the action box of BASELINE configs[2] that costs this pair 3.9 rejected attempts per env step out of 22.5 -- the
+// transient of a freshly changed input needs h ~ 2-3 h0 -- against 0.5 out of 19.6 here, same worst-case error.)
+template <int NX>
+PCG_DEV double rodas4_h_init(const double (&x)[NX], const double (&f0)[NX], int n, double dt, double rtol, double atol,
+                             double& d1_out) {
+#pragma clang fp contract(off)
+  const double d0 = rms_scaled<NX>(x, x, x, n, rtol, atol);
+  const double d1 = rms_scaled<NX>(f0, x, x, n, rtol, atol);
+  d1_out = d1;
+  const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+  return fmin(qtrunc6(5.0 * h0), dt);
+}
+
+// returns PCG_ST_OK, PCG_ST_MAX_STEPS or PCG_ST_UNDERFLOW (the caller poisons the state on failure)
+template <int NX, class F, class LS, class EP>
+PCG_DEV int rodas4(const F& f, const LS& ls, const EP& ep, double (&x)[NX], int n, double dt, double rtol, double atol,
+                   int max_steps, int& nacc, int& nrej) {
+#pragma clang fp contract(off)
+  double f0[NX], xn[NX], err[NX];
+  int acc = 0, rej = 0, status = 0;
+  f(x, f0);
+  double d1;
+  double h = rodas4_h_init<NX>(x, f0, n, dt, rtol, atol, d1);
+  double t = 0.0;
+  bool rejected_last = false;
+  for (;;) {
+    bool last = false;
+    if (acc + rej >= max_steps) {
+      status = 1;
+      break;
+    }
+    if (t + h >= dt * (1.0 - 1e-14)) {
+      h = dt - t;
+      last = true;
+    }
+    const bool lu_ok = rodas4_try<NX>(f, ls, x, f0, h, xn, err);
+    double E2 = ms_scaled_ep<NX>(ep, dt - (t + h), err, x, xn, n, rtol, atol);
+    if (!lu_ok) E2 = __builtin_nan("");
+    const bool ok = E2 < 1.0;
+    const double fac = rodas4_factor(E2, ok, rejected_last);
+    if (ok) {
+      t += h;
+      h *= fac;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = xn[i];
+      rejected_last = false;
+      ++acc;
+      if (last) break;
+      f(x, f0);
+    } else {
+      h *= fac;
+      rejected_last = true;
+      ++rej;
+      if (!(h > 1e-13 * dt)) {
+        status = 2;
+        break;
+      }
+    }
+  }
+  nacc = acc;
+  nrej = rej;
+  return status;
+}
+
 }  // namespace pcg

@@ -51,18 +51,24 @@ constexpr int BLOCK = 256;      // threads per workgroup (4 waves, one per SIMD)
 constexpr int BLOCK_LDS = 64;   // LDS-staged DOPRI5: 6*NX*8 B of stage storage per lane
 // Adaptive (DOPRI5) kernels run one wave per workgroup: lanes take different numbers of steps, a 4-wave workgroup
 // holds its CU slots until its slowest wave ends, and single-wave workgroups let the dispatcher refill per wave.
-constexpr int tb(bool lds_stages, int integ, int nx = 0) {
-  return integ == PCG_INT_RODAS3 ? ros_threads(nx) : (lds_stages || integ == PCG_INT_DOPRI5) ? BLOCK_LDS : BLOCK;
+// Rosenbrock integrators with the dense per-lane LU in LDS: Rodas3 always, Rodas4 unless the model brings its own
+// structured linear algebra (M::ROS_STRUCTURED -> registers only, launched like the explicit adaptive pair)
+constexpr bool ros_dense(int integ, bool structured) {
+  return integ == PCG_INT_RODAS3 || (integ == PCG_INT_RODAS4 && !structured);
+}
+constexpr int tb(bool lds_stages, int integ, int nx = 0, bool structured = false) {
+  return ros_dense(integ, structured) ? ros_threads(nx)
+         : (lds_stages || integ == PCG_INT_DOPRI5 || integ == PCG_INT_RODAS4) ? BLOCK_LDS : BLOCK;
 }
 // doubles of dynamic LDS the integrator itself needs per workgroup (the schedules follow them)
-constexpr size_t integ_lds_doubles(int nx, int integ, bool lds_stages) {
-  return integ == PCG_INT_RODAS3 ? ros_lds_doubles(nx) : lds_stages ? (size_t)6 * nx * BLOCK_LDS : 0;
+constexpr size_t integ_lds_doubles(int nx, int integ, bool lds_stages, bool structured = false) {
+  return ros_dense(integ, structured) ? ros_lds_doubles(nx) : lds_stages ? (size_t)6 * nx * BLOCK_LDS : 0;
 }
 // Minimum waves per SIMD asked of the register allocator.  DOPRI5 with <= 10 states needs ~280 registers
 // when left alone (1 wave/SIMD, latency-bound: measured 14k cycles per attempted step against ~3.6k of
 // issue); capping it at 256 costs a few spills and doubles the resident waves.
-constexpr int wpe(int nx, int integ, bool lds_stages) {
-  return (integ == PCG_INT_DOPRI5 && !lds_stages && nx <= 10) ? 2 : 1;
+constexpr int wpe(int nx, int integ, bool lds_stages, bool structured = false) {
+  return ((integ == PCG_INT_DOPRI5 && !lds_stages && nx <= 10) || (integ == PCG_INT_RODAS4 && structured && nx <= 10)) ? 2 : 1;
 }
 constexpr int KNU = PCG_MAX_NA + PCG_MAX_NDM;                      // kernel-side u width
 constexpr int CON_W = PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + KNU; // padded constraint row
@@ -111,6 +117,9 @@ struct DevConst {
   double box_lon[PCG_MAX_RBOX], box_hin[PCG_MAX_RBOX];   // box bounds, normalised
   // user constraint expressions (run-time compiled): quirk Q3 as an affine map of the state / input vector they see
   double q3_mul[PCG_MAX_NOBS], q3_add[PCG_MAX_NOBS], q3u_mul[KNU], q3u_add[KNU];
+  // PCG_INT_RODAS4 end-point error control: ep_c = ep_frac log2(e) (0 when off), largest tolerance exponent
+  double ep_c;
+  int32_t ep_kmax;
 };
 
 using CDevConst = const PCG_CONSTANT DevConst;
@@ -454,6 +463,22 @@ PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const do
     int nacc = 0, nrej = 0;
     const RosLds<NX> Lm(stage_l);
     status = rodas3<NX>(f, Lm, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    if (A.nsteps) {
+      A.nsteps[e] = nacc;
+      A.nsteps[A.B + e] = nrej;
+    }
+    poison_if_failed<NX>(status, x);
+  } else if (INTEG == PCG_INT_RODAS4) {
+    int nacc = 0, nrej = 0;
+    const EpWeights<M, K> ep{kp, u, c.ep_c, c.ep_kmax};
+    if constexpr (ros_structured<M>::value) {
+      const RosStructured<M, K> ls{kp, hold, {}};
+      status = rodas4<NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    } else {
+      const RosLds<NX> Lm(stage_l);
+      const RosDense<NX, RhsFn<M, double, K>> ls{f, Lm, nx, c.rtol, c.atol};
+      status = rodas4<NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    }
     if (A.nsteps) {
       A.nsteps[e] = nacc;
       A.nsteps[A.B + e] = nrej;
@@ -820,14 +845,15 @@ PCG_DEV void stage_schedules(const StepArgs& A, CDevConst& c, double* sched_l) {
 }
 
 template <class M, int INTEG, bool PER_ENV_T, bool LDS_STAGES, bool EXTRAS, bool UNC = false>
-__global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX), wpe(M::NX, INTEG, LDS_STAGES)) void step_kernel(const StepArgs A) {
+__global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX, ros_structured<M>::value),
+                             wpe(M::NX, INTEG, LDS_STAGES, ros_structured<M>::value)) void step_kernel(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA;
   double* stage_l = lds;
-  double* sched_l = lds + integ_lds_doubles(NX, INTEG, LDS_STAGES);
+  double* sched_l = lds + integ_lds_doubles(NX, INTEG, LDS_STAGES, ros_structured<M>::value);
   if (PER_ENV_T) stage_schedules(A, c, sched_l);
-  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES, INTEG, M::NX) + threadIdx.x;
+  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES, INTEG, M::NX, ros_structured<M>::value) + threadIdx.x;
   if (e >= A.B) return;
   const int64_t B = A.B;
   const int nx = M::DYNAMIC ? c.nx : NX;
@@ -1446,12 +1472,12 @@ __global__ __launch_bounds__(BLOCK) void rhs_kernel(CDevConst* C, int64_t B, int
 }
 
 template <class M, int INTEG, bool LDS_STAGES>
-__global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX)) void integrate_kernel(CDevConst* C, int64_t B, int nu_rows,
+__global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX, ros_structured<M>::value)) void integrate_kernel(CDevConst* C, int64_t B, int nu_rows,
                                                                           double* xg, const double* ug, int32_t* nsteps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   CDevConst& c = *C;
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
-  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES, INTEG, NX) + threadIdx.x;
+  const int64_t e = (int64_t)blockIdx.x * tb(LDS_STAGES, INTEG, NX, ros_structured<M>::value) + threadIdx.x;
   if (e >= B) return;
   const int nx = M::DYNAMIC ? c.nx : NX;
   const int na = M::DYNAMIC ? c.na : NA;
@@ -1471,6 +1497,22 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX)) void integrate_kernel
     int nacc = 0, nrej = 0;
     const RosLds<NX> Lm(lds);
     const int status = rodas3<NX>(f, Lm, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    poison_if_failed<NX>(status, x);
+    if (nsteps) {
+      nsteps[e] = nacc;
+      nsteps[B + e] = nrej;
+    }
+  } else if (INTEG == PCG_INT_RODAS4) {
+    int nacc = 0, nrej = 0, status;
+    const EpWeights<M, typename M::CKP> ep{kp, u, c.ep_c, c.ep_kmax};
+    if constexpr (ros_structured<M>::value) {
+      const RosStructured<M, typename M::CKP> ls{kp, hold, {}};
+      status = rodas4<NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    } else {
+      const RosLds<NX> Lm(lds);
+      const RosDense<NX, RhsFn<M>> ls{f, Lm, nx, c.rtol, c.atol};
+      status = rodas4<NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    }
     poison_if_failed<NX>(status, x);
     if (nsteps) {
       nsteps[e] = nacc;
@@ -1533,6 +1575,8 @@ struct Kernels {
   StepFn stream[PCG_INT_COUNT][2];      // persistent streaming kernel [integrator][EPL-1] (entries may be null)
   StepFn step_unc[PCG_INT_COUNT][2]; // per-env parameter uncertainty [integrator][per_env_t] (null for affine)
   StepFn queue[2];                   // DOPRI5 with the in-workgroup work queue [per_env_t] (null for affine)
+  StepFn queue_r4[2];                // Rodas4 through the same work queue [per_env_t] (models with structured W only)
+  bool ros_structured;               // Rodas4 runs in registers (launch shape of the explicit adaptive pair)
   bool queue_default;                // route adaptive plans to it unless told otherwise (models with a cost key)
   size_t (*queue_lds)(int);          // LDS bytes of a tile of T slots
   StepFn pipe[2];                    // RK4 software-pipelined lean kernel [EPL-1] (may be null)
@@ -1568,6 +1612,16 @@ Kernels make_kernels() {
   k.step[PCG_INT_RODAS3][0][0][0] = k.step[PCG_INT_RODAS3][0][0][1] = step_kernel<M, PCG_INT_RODAS3, false, false, true>;
   k.step[PCG_INT_RODAS3][1][0][0] = k.step[PCG_INT_RODAS3][1][0][1] = step_kernel<M, PCG_INT_RODAS3, true, false, true>;
   k.integ[PCG_INT_RODAS3][0] = integrate_kernel<M, PCG_INT_RODAS3, false>;
+  // fourth-order Rosenbrock pair: general kernel (dense W in LDS, or the model's structured W in registers), and for
+  // the structured models the work-queue kernel
+  k.step[PCG_INT_RODAS4][0][0][0] = k.step[PCG_INT_RODAS4][0][0][1] = step_kernel<M, PCG_INT_RODAS4, false, false, true>;
+  k.step[PCG_INT_RODAS4][1][0][0] = k.step[PCG_INT_RODAS4][1][0][1] = step_kernel<M, PCG_INT_RODAS4, true, false, true>;
+  k.integ[PCG_INT_RODAS4][0] = integrate_kernel<M, PCG_INT_RODAS4, false>;
+  k.ros_structured = ros_structured<M>::value;
+  if constexpr (ros_structured<M>::value && !M::DYNAMIC) {
+    k.queue_r4[0] = step_kernel_queue<M, false, true, PCG_INT_RODAS4>;
+    k.queue_r4[1] = step_kernel_queue<M, true, true, PCG_INT_RODAS4>;
+  }
   k.rhs = rhs_kernel<M>;
   if constexpr (!M::DYNAMIC) {
     k.queue[0] = step_kernel_queue<M, false, true>;
@@ -1611,12 +1665,14 @@ Kernels make_kernels() {
     for (int ex = 0; ex < 2; ++ex) {
       k.step[PCG_INT_RK4][pe][1][ex] = k.step[PCG_INT_RK4][pe][0][ex];
       k.step[PCG_INT_RODAS3][pe][1][ex] = k.step[PCG_INT_RODAS3][pe][0][ex];
+      k.step[PCG_INT_RODAS4][pe][1][ex] = k.step[PCG_INT_RODAS4][pe][0][ex];
       if (!k.step[PCG_INT_DOPRI5][pe][1][ex]) k.step[PCG_INT_DOPRI5][pe][1][ex] = k.step[PCG_INT_DOPRI5][pe][0][ex];
     }
   k.rollout[PCG_INT_RK4][1] = k.rollout[PCG_INT_RK4][0];
   if (!k.rollout[PCG_INT_DOPRI5][1]) k.rollout[PCG_INT_DOPRI5][1] = k.rollout[PCG_INT_DOPRI5][0];
   k.integ[PCG_INT_RK4][1] = k.integ[PCG_INT_RK4][0];
   k.integ[PCG_INT_RODAS3][1] = k.integ[PCG_INT_RODAS3][0];
+  k.integ[PCG_INT_RODAS4][1] = k.integ[PCG_INT_RODAS4][0];
   if (!k.integ[PCG_INT_DOPRI5][1]) k.integ[PCG_INT_DOPRI5][1] = k.integ[PCG_INT_DOPRI5][0];
   k.nfeat = feat_fill<ID>(k.feat, MAX_FEAT);
   k.has_lds_stages = M::FULL;

@@ -37,6 +37,13 @@ using ::sqrt;
 template <int ID>
 struct Model;
 
+// helpers of the models' end-point exponent hooks (PCG_INT_RODAS4, pcg_integrators.hpp)
+PCG_DEV int ep_trunc(double v, int kmax) { return (v > 0.0) ? (int)__builtin_fmin(v, (double)kmax) : 0; }
+// floor(log2(v)) for v >= 1 (0 below): exponent extraction, exact
+PCG_DEV int ep_ilog2(double v) {
+  return (v >= 1.0) ? (int)((__double_as_longlong(v) >> 52) & 0x7FF) - 1023 : 0;
+}
+
 // ---------------------------------------------------------------------------
 // cstr -- model_classes.py:23-62.  raw = q,V,rho,C,deltaHr,EA_over_R,k0,UA,Ti,Caf
 // u = [Tc | Ti, Caf]
@@ -187,6 +194,102 @@ struct MEImpl {
   PCG_DEV static double cost_key(const K& k, const double (&u)[NA + NDM]) {
     return __builtin_fmax(u[0] * k.iVl, u[1] * k.iVg);
   }
+  // ---- hooks of the stiff integrator (PCG_INT_RODAS4, pcg_integrators.hpp) ----
+  // End-point exponents of the two component groups at time-to-go tau (pcg_integrators.hpp "END-POINT ERROR
+  // CONTROL"; twin: ep_exponents() in oracle/pcg_oracle.c).  Group 0 = liquid chain X (even components), group 1 = gas
+  // chain Y.  A perturbation decays with the slower of the two through-flow rates a = L/Vl, c = G/Vg:
+  //   k_s = trunc(min(kmax, ep_c min(a,c) tau)).
+  // An error in the FAST chain dies at its own rate and only reaches the slow chain through the mass-transfer coupling,
+  // attenuated by (coupling rate x residence time): kappa/c for Y -> X (kappa = Kla 2 Ymax / m with Ymax = 1, the top of
+  // the observation box) and e/(a + Kla) for X -> Y (e = Kla Vl/Vg); with a safety factor 2:
+  //   k_Y = min(trunc(min(kmax, ep_c c tau)), k_s + floor(log2(max(1, c/(2 kappa))))),  k_X likewise.
+  // Measured on the action box of BASELINE configs[2] (tests/test_rodas4.py): the heaviest envs (low liquid flow, high
+  // gas flow: the gas transient has to be resolved while the liquid barely forgets) drop from 136 to 102 attempts at
+  // the same worst-case error; they are the critical path of a launch.
+  static constexpr bool EP_GROUPS = true;
+  PCG_DEV static constexpr int ep_group(int i) { return i & 1; }
+  template <class K>
+  PCG_DEV static void ep_exponents(const K& k, const double (&u)[NA + NDM], double ep_c, int kmax, double tau,
+                                   int (&kg)[2]) {
+#pragma clang fp contract(off)
+    const double a = u[0] * k.iVl, c = u[1] * k.iVg;
+    const double ct = ep_c * tau;
+    const int ks = ep_trunc(ct * __builtin_fmin(a, c), kmax);
+    const double klap = k.iVl * k.KlaVl, e = k.iVg * k.KlaVl;
+    const double kappa2 = (klap * 2.0 * k.inv_m) * 2.0, e2 = e * 2.0;  // x safety 2
+    const int kX = ks + ep_ilog2((a + klap) / e2), kY = ks + ep_ilog2(c / kappa2);
+    const int kXd = ep_trunc(ct * a, kmax), kYd = ep_trunc(ct * c, kmax);
+    kg[0] = kX < kXd ? kX : kXd;
+    kg[1] = kY < kYd ? kY : kYd;
+  }
+  // sort key of the work-queue kernel for the Rosenbrock pair: least-squares fit of its attempted steps per env step
+  // over the action box (tools/ros4_costfit.py: correlation 0.92 with the ln d1 term the kernel adds); the expensive
+  // lanes are the ones whose SLOW chain barely damps (small min rate), not the stiff ones
+  template <class K>
+  PCG_DEV static float cost_key_ros(const K& k, const double (&u)[NA + NDM]) {
+    const float a = (float)(u[0] * k.iVl), c = (float)(u[1] * k.iVg);
+    const float mn = __builtin_fminf(a, c), mx = __builtin_fmaxf(a, c);
+    return 40.0f - 8.65f * __builtin_logf(mn) + 1.95f * __builtin_logf(mx) + 56.3f / mn;
+  }
+  // W = theta I - J, analytic, eliminated in the natural order (X1,Y1,...,X5,Y5) without pivoting.  Rows:
+  //   X_s:  DX X_s - alpha X_{s-1} - cx_s Y_s            alpha = L/Vl, Kla' = Kla, cx_s = Kla q_s, q_s = d(Y^e/m)/dY
+  //   Y_s:  -e X_s + DY_s Y_s - beta Y_{s+1}             beta = G/Vg, e = Kla Vl/Vg, DY_s = theta + beta + e q_s
+  // with DX = theta + alpha + Kla for every stage (the X pivots never change: fill-in only appears at (X_{s+1}, Y_s)).
+  // For Y >= 0 the matrix is an M-matrix: no pivoting needed; a non-positive pivot (unphysical state) rejects the step.
+  // Twin: me_ros_factor / me_ros_solve in oracle/pcg_oracle.c, operation for operation.
+  static constexpr bool ROS_STRUCTURED = true;
+  struct RosFac {
+    double iDX, aD, eD, beta;
+    double ct[5], iDY[5], m3[4];
+    bool ok;
+  };
+  template <class K>
+  PCG_DEV static void ros_factor(const K& k, const HoldT<double>& h, const double (&x)[NX], double theta, RosFac& F) {
+#pragma clang fp contract(off)
+    const double alpha = k.iVl * h.L, beta = k.iVg * h.G, klap = k.iVl * k.KlaVl, e = k.iVg * k.KlaVl;
+    const double DX = theta + (alpha + klap);
+    const double thb = theta + beta;
+    F.iDX = 1.0 / DX;
+    F.aD = alpha * F.iDX;
+    F.eD = e * F.iDX;
+    F.beta = beta;
+    bool ok = (DX > 0.0) && (DX < __builtin_inf());
+    double ct = 0.0;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const double Y = x[2 * s + 1];
+      double q;
+      if constexpr (SQ) q = (2.0 * Y) * k.inv_m;
+      else q = (k.e * pow(Y, k.e - 1.0)) * k.inv_m;
+      const double cx = klap * q;
+      ct = (s == 0) ? cx : __builtin_fma(F.m3[s > 0 ? s - 1 : 0], beta, cx);
+      const double DY = __builtin_fma(e, q, thb);
+      const double DYp = __builtin_fma(-F.eD, ct, DY);
+      ok = ok && (DYp > 0.0) && (DYp < __builtin_inf());
+      F.ct[s] = ct;
+      F.iDY[s] = 1.0 / DYp;
+      if (s < 4) F.m3[s] = (F.aD * ct) * F.iDY[s];
+    }
+    F.ok = ok;
+  }
+  PCG_DEV static void ros_solve(const RosFac& F, double (&b)[NX]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      b[2 * s + 1] = __builtin_fma(F.eD, b[2 * s], b[2 * s + 1]);
+      if (s < 4) {
+        b[2 * s + 2] = __builtin_fma(F.aD, b[2 * s], b[2 * s + 2]);
+        b[2 * s + 2] = __builtin_fma(F.m3[s], b[2 * s + 1], b[2 * s + 2]);
+      }
+    }
+#pragma unroll
+    for (int ss = 0; ss < 5; ++ss) {
+      const int s = 4 - ss;
+      const double yv = ((s == 4) ? b[2 * s + 1] : __builtin_fma(F.beta, b[s < 4 ? 2 * s + 3 : 0], b[2 * s + 1])) * F.iDY[s];
+      b[2 * s + 1] = yv;
+      b[2 * s] = __builtin_fma(F.ct[s], yv, b[2 * s]) * F.iDX;
+    }
+  }
   // With eq_exponent == 2 the right-hand side is an exactly specified sequence of IEEE operations (contraction off,
   // fused multiply-adds where written): this model runs the adaptive pair at its stability limit, where the
   // step-size sequence amplifies a last-bit difference (tests/helpers.py) -- with a fixed operation order every
@@ -257,6 +360,17 @@ struct MEReactiveImpl {
   template <class K>
   PCG_DEV static double cost_key(const K& k, const double (&u)[NA + NDM]) {
     return __builtin_fmax(u[0] * k.iVl, u[1] * k.iVg);
+  }
+  // end-point error control of PCG_INT_RODAS4 (dense linear algebra here): one exponent for every component, from the
+  // slower through-flow rate (see MEImpl::ep_exponents)
+  static constexpr bool EP_GROUPS = true;
+  PCG_DEV static constexpr int ep_group(int) { return 0; }
+  template <class K>
+  PCG_DEV static void ep_exponents(const K& k, const double (&u)[NA + NDM], double ep_c, int kmax, double tau,
+                                   int (&kg)[2]) {
+#pragma clang fp contract(off)
+    const double ct = ep_c * tau;
+    kg[0] = kg[1] = ep_trunc(ct * __builtin_fmin(u[0] * k.iVl, u[1] * k.iVg), kmax);
   }
   template <class R, class K>
   PCG_DEV static void rhs(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX]) {

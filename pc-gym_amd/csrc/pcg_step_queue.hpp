@@ -39,8 +39,8 @@ namespace pcg {
 // head in a register) was built and measured as well: 1.05x over the classic kernel on BASELINE configs[2] against
 // 1.13x for this shape -- the larger pool is worth more than the barriers cost (profiles/r2/queue_kernel.md).
 constexpr int QBLOCK = 256;        // threads per workgroup (one wave per SIMD)
-constexpr int QSORT = 1024;        // maximum tile = maximum sort width: four envs per lane
-constexpr int QSLOT_BITS = 10;     // slot index bits below the cost key in a sort word
+constexpr int QSORT = 2048;        // maximum tile = maximum sort width: eight envs per lane (the explicit pair stops at four)
+constexpr int QSLOT_BITS = 11;     // slot index bits below the cost key in a sort word
 constexpr int QREFILL = 8;         // idle lanes that trigger a refill in a well-filled tile (or: no busy lane left)
 
 // model hook: a cheap, monotone proxy of the number of RK steps an env step will take (the sort key)
@@ -156,17 +156,65 @@ PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double d
   return !(L.h > h_floor) ? PCG_ST_UNDERFLOW : -1;  // 1e-13 dt: step-size underflow (NaN state / blow-up)
 }
 
+// ---- Rodas4 in resumable form (models with structured W: pcg_integrators.hpp).  Between attempts a lane only carries
+// the state: f(x) is re-evaluated at the start of an attempt (the same bits as carrying it, one RHS evaluation more on
+// the rare rejected attempt, ten doubles fewer alive across the six stages).
+template <int NX>
+struct R4Lane {
+  double x[NX];
+  double t, h;
+  int acc, rej;
+  bool rejected_last;
+};
+template <int NX, int INTEG>
+struct QLaneSel { using type = DpLane<NX>; };
+template <int NX>
+struct QLaneSel<NX, PCG_INT_RODAS4> { using type = R4Lane<NX>; };
+
+// one attempted step: the body of rodas4()'s loop.  Returns -1 to continue, else the final PCG_ST_* status.
+template <class M, class K, class F, class EP>
+PCG_DEV int rodas4_attempt(const K& kp, const typename M::Hold& hold, const F& f, const EP& ep, R4Lane<M::NX>& L, int n,
+                           double dt, double dt_edge, double h_floor, double rtol, double atol, int max_steps) {
+#pragma clang fp contract(off)
+  constexpr int NX = M::NX;
+  if (L.acc + L.rej >= max_steps) return PCG_ST_MAX_STEPS;
+  bool last = false;
+  double h = L.h;
+  if (L.t + h >= dt_edge) {
+    h = dt - L.t;
+    last = true;
+  }
+  double f0[NX], xn[NX], err[NX];
+  f(L.x, f0);
+  const RosStructured<M, K> ls{kp, hold, {}};
+  const bool lu_ok = rodas4_try<NX>(f, ls, L.x, f0, h, xn, err);
+  double E2 = ms_scaled_ep<NX>(ep, dt - (L.t + h), err, L.x, xn, n, rtol, atol);
+  if (!lu_ok) E2 = __builtin_nan("");
+  const bool ok = E2 < 1.0;
+  const double fac = rodas4_factor(E2, ok, L.rejected_last);
+  L.t = ok ? L.t + h : L.t;
+  L.h = h * fac;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) L.x[i] = ok ? xn[i] : L.x[i];
+  L.rejected_last = !ok;
+  L.acc += ok ? 1 : 0;
+  L.rej += ok ? 0 : 1;
+  if (ok) return last ? PCG_ST_OK : -1;
+  return !(L.h > h_floor) ? PCG_ST_UNDERFLOW : -1;
+}
+
 // ---- phase 2: the work queue of one tile.  (Tried as a real, non-inlined function so that the loop would own the
 // whole register file: the call ABI's save / restore made it worse -- 772 B of scratch against 140.)
-template <class M>
+template <class M, int INTEG = PCG_INT_DOPRI5>
 PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, double* us, const double* hs,
                                                           const uint32_t* sortbuf, int32_t* accs, int32_t* rejs,
                                                           int32_t* flag, int32_t* next, int T, int n, int refill, double dt, double dt_edge,
-                                                          double h_floor, double rtol, double atol, int max_steps) {
+                                                          double h_floor, double rtol, double atol, int max_steps,
+                                                          double ep_c = 0.0, int ep_kmax = 0) {
   constexpr int NX = M::NX, NU = M::NA + M::NDM;
   typename M::CKP& kp = *kpp;
   const int tid = threadIdx.x;
-  DpLane<NX> L;
+  typename QLaneSel<NX, INTEG>::type L;
   int slot = tid < n ? (int)(sortbuf[tid] & (QSORT - 1)) : -1;  // QSORT - 1 == the QSLOT_BITS mask
   bool fresh = slot >= 0;
   bool drained = n <= QBLOCK;  // wave-uniform: the queue has nothing (left) for this wave
@@ -196,9 +244,11 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
       L.t = 0.0;
       L.acc = L.rej = 0;
       L.rejected_last = false;
-      const typename M::Hold hold = M::hold(kp, u);
-      const RhsFn<M> f{kp, hold};
-      f(L.x, L.k1);
+      if constexpr (INTEG == PCG_INT_DOPRI5) {
+        const typename M::Hold hold = M::hold(kp, u);
+        const RhsFn<M> f{kp, hold};
+        f(L.x, L.k1);
+      }
       fresh = false;
     }
     const bool busy = slot >= 0;
@@ -232,7 +282,13 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
       for (int i = 0; i < NU; ++i) u[i] = us[(size_t)i * T + slot];
       const typename M::Hold hold = M::hold(kp, u);
       const RhsFn<M> f{kp, hold};
-      const int st = dopri5_attempt<NX>(f, L, NX, dt, dt_edge, h_floor, rtol, atol, max_steps);
+      int st;
+      if constexpr (INTEG == PCG_INT_RODAS4) {
+        const EpWeights<M, typename M::CKP> ep{kp, u, ep_c, ep_kmax};
+        st = rodas4_attempt<M>(kp, hold, f, ep, L, NX, dt, dt_edge, h_floor, rtol, atol, max_steps);
+      } else {
+        st = dopri5_attempt<NX>(f, L, NX, dt, dt_edge, h_floor, rtol, atol, max_steps);
+      }
       if (st >= 0) {  // finished (or gave up): park the result, free the lane
         poison_if_failed<NX>(st, L.x);
 #pragma unroll
@@ -255,7 +311,7 @@ struct QLayout {
   }
 };
 
-template <class M, bool PER_ENV_T, bool EXTRAS>
+template <class M, bool PER_ENV_T, bool EXTRAS, int INTEG = PCG_INT_DOPRI5>
 __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void step_kernel_queue(const StepArgs A) {  // wpe = waves per SIMD = workgroups per CU
   extern __shared__ __attribute__((aligned(16))) double lds[];
   static_assert(!M::DYNAMIC, "the work-queue kernel is built for the fixed-size models");
@@ -289,7 +345,7 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
     const int64_t base = lo + (int64_t)isub * sub;
     const int n = (int)(min(hi, base + sub) - base);  // envs in this sub-tile
     // ---------------- phase 1: load, pre-integration half, park in LDS ----------------
-    const int S = n <= QSORT / 2 ? QSORT / 2 : QSORT;  // sort width
+    const int S = n <= QSORT / 4 ? QSORT / 4 : (n <= QSORT / 2 ? QSORT / 2 : QSORT);  // sort width
     for (int s = tid; s < S; s += QBLOCK) {
       uint32_t word = (uint32_t)s;  // padding: sorts behind every real slot
       if (s < n) {
@@ -305,8 +361,13 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
         const typename M::Hold hold = M::hold(kp, pre.u);
         const RhsFn<M> f{kp, hold};
         double k1[NX];
-        double d1;
-        const double h = dopri5_h_init<NX>(f, x, k1, NX, dt, rtol, atol, d1);
+        double d1, h;
+        if constexpr (INTEG == PCG_INT_RODAS4) {
+          f(x, k1);
+          h = rodas4_h_init<NX>(x, k1, NX, dt, rtol, atol, d1);
+        } else {
+          h = dopri5_h_init<NX>(f, x, k1, NX, dt, rtol, atol, d1);
+        }
 #pragma unroll
         for (int i = 0; i < NU; ++i) us[(size_t)i * T + s] = pre.u[i];
         hs[s] = h;
@@ -316,7 +377,9 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
         // already computed for the initial step size).  A least-squares fit on BASELINE configs[2] puts the weight at
         // 33 (correlation with the measured step counts 0.84 -> 0.96, list-scheduling efficiency of independent lanes
         // 0.836 -> 0.862); lock-stepped waves prefer less: measured optimum ~20 (pcg_abi.hip, profiles/r2/queue_w_sweep.txt)
-        if constexpr (has_cost_key<M>::value)
+        if constexpr (INTEG == PCG_INT_RODAS4)  // fitted attempts per env step of the Rosenbrock pair (pcg_models.hpp)
+          key = M::cost_key_ros(kp, pre.u) + A.q_w * __builtin_logf(__builtin_fmaxf((float)d1, 1.0f));
+        else if constexpr (has_cost_key<M>::value)
           key = (float)(M::cost_key(kp, pre.u) * dt) + A.q_w * __builtin_logf(__builtin_fmaxf((float)d1, 1.0f));
         else key = (float)(dt / h);  // generic proxy: steps at the initial step size
         key = nosort ? 1.0f : __builtin_fmaxf(key, 1e-30f);
@@ -346,7 +409,7 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
     // only idles it (me10: 0.678 ms at 8, 0.656 at 2); with more envs per lane the refill code -- executed by the whole
     // wave -- is worth batching (configs[4] shard: 0.916 ms at 8, 0.929 at 2; profiles/r2/queue_refill_sweep.txt)
     const int refill = refill_hi ? refill_hi : (n <= 2 * QBLOCK ? 2 : QREFILL);
-    queue_integrate<M>(&kp, A.x + base, B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps);
+    queue_integrate<M, INTEG>(&kp, A.x + base, B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax);
     __syncthreads();
     // ---------------- phase 3: post-integration half, coalesced stores ----------------
     for (int s = tid; s < n; s += QBLOCK) {
