@@ -14,6 +14,9 @@ launch, pcg_step_autoreset).  value = total env-steps / wall time (max over rank
   four_tank  four_tank B = 2^20, RK4 x4 per dt = 1000/60 (HBM-bound)
   me10       configs[2]: multistage_extraction (10 states) B = 262,144, adaptive DOPRI5 rtol = atol = 1e-8, dt = 1,
              (L, G) per env over the FULL action box [5,10]..[500,1000], x0 = doc ICs x (1 + 0.05 U(-1,1))
+  me10_ros4  the same envs, actions and starts through the stiff pair the engine now defaults to for this model (Rodas4 with
+             the cascade's structured linear algebra and end-point error control, rtol = atol = 3e-8): beside the named
+             RK45 line, not instead of it
   me20       the 20-state reactive variant, same protocol
   cryst      configs[3]: crystallization B = 262,144, RK4 x32 per dt = 1, a_delta on
   mixed      configs[4], one shard: 1,048,572 envs = 349,524 each of cstr + Ti ~ N(350, 2) / four_tank /
@@ -44,6 +47,18 @@ METRIC = "env-steps/sec at batch 2^20 CSTR, 1/2/4/8 MI355X; achieved HBM GB/s vs
 # algorithmic fp64 flops per right-hand-side evaluation -- for the fp64-bound workloads
 FLOP_PER_RHS = {"multistage_extraction": 65, "multistage_extraction_reactive": 150,
                 "crystallization": 60 + 4 * 25 + 12 + 6 * 10}
+
+
+def flops_per_env_step(model, nx, integrator, attempts, substeps=1):
+    """algorithmic fp64 flops of one env step.  RK4: 4 RHS per sub-step; DOPRI5: 2 + 6 per attempt, each with its
+    stage combination (2 x 6 nx); Rodas4 on the 10-state cascade: per attempt 6 RHS + 25 stage axpys (2 nx each) + one
+    structured factorisation (~60) + 6 structured solves (33 fused multiply-adds = 66 each) + the error norm (4 nx)."""
+    f = FLOP_PER_RHS[model]
+    if integrator == "rk4":
+        return 4 * substeps * (f + 2 * 6 * nx)
+    if integrator == "rodas4":
+        return attempts * (6 * f + 25 * 2 * nx + 60 + 6 * 66 + 4 * nx)
+    return (2 + 6 * attempts) * (f + 2 * 6 * nx)
 
 
 def _thirds(n, a, b, c):
@@ -79,7 +94,8 @@ def mixed_segments(B_shard):
       cstr with Ti ~ N(350, 2) clipped to [320, 360] (set-point thirds 0.85/0.9/0.87, canonical dt = 26/60, RK4 x4),
       four_tank (set-point step changes h3 0.5 -> 0.1, h4 0.2 -> 0.3, 4tank_train.py:54-57), undisturbed: the model has
         no disturbance input (model_classes.py:926 lists ["None"]),
-      multistage_extraction with X0 ~ N(0.6, 0.02) clipped to [0.5, 0.8] (X5 0.3 -> 0.4 -> 0.3, adaptive DOPRI5).
+      multistage_extraction with X0 ~ N(0.6, 0.02) clipped to [0.5, 0.8] (X5 0.3 -> 0.4 -> 0.3; the model's default
+        integrator: Rodas4, rtol = atol = 3e-8 -- configs[4] names none; --integrator dopri5 gives round 2's line).
     Returns [(env_params, n_envs)] in the global layout [cstr | four_tank | ME]."""
     import numpy as np
 
@@ -98,8 +114,7 @@ def mixed_segments(B_shard):
         m.pop(k, None)
     m.update(N=N, tsim=60.0, SP={"X5": _thirds(N, 0.3, 0.4, 0.3)}, disturbances={"X0": np.full(N, 0.6)},
              disturbance_bounds={"low": np.array([0.5]), "high": np.array([0.8])},
-             gaussian_disturbances={"X0": 0.02}, normalise_a=True, normalise_o=True, integrator="dopri5",
-             rtol=1e-8, atol=1e-8)
+             gaussian_disturbances={"X0": 0.02}, normalise_a=True, normalise_o=True)
     return [(c, n), (f, n), (m, n)]
 
 
@@ -114,6 +129,11 @@ def single_workload(name):
         return "cstr_b2^20_rk4_fp64", workload_params(), 1 << 20, (5900, 590), 64
     if name == "four_tank":
         return "four_tank_b2^20_rk4x4_fp64", copy.deepcopy(S["four_tank_canonical"]["env_params"]), 1 << 20, (1180, 118), 16
+    if name == "me10_ros4":
+        wl, p, B, kw, na = single_workload("me10")
+        p.update(integrator="rodas4")
+        p.pop("rtol"), p.pop("atol")  # the integrator's own default for this model (config.ROS4_TOL: 3e-8)
+        return wl.replace("dopri5_1e-8", "rodas4_3e-8_endpoint"), p, B, kw, na
     if name in ("me10", "me20"):
         p = copy.deepcopy(S["me_canonical" if name == "me10" else "me_reactive"]["env_params"])
         nx = 10 if name == "me10" else 20
@@ -280,7 +300,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cstr", choices=["cstr", "four_tank", "me10", "me20", "cryst", "mixed"])
+    ap.add_argument("--workload", default="cstr", choices=["cstr", "four_tank", "me10", "me10_ros4", "me20", "cryst", "mixed"])
     ap.add_argument("--batch", type=int, default=None, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=None, help="fixed OpenMP team of the cpu_baseline leg (default min(16, avail))")
@@ -350,8 +370,8 @@ def main():
         segs_global = [(params, n * world) for params, n in mixed_segments(B)]
         if args.integrator:
             segs_global[2][0]["integrator"] = args.integrator
-            for k in ("rtol", "atol"):
-                segs_global[2][0].pop(k, None)
+            if args.integrator == "dopri5":
+                segs_global[2][0].update(rtol=1e-8, atol=1e-8)
         K = args.steps if args.steps is not None else 118
         W = args.warmup if args.warmup is not None else 12
         menv = make_mixed_sharded_env(segs_global, rank=rank, world=world, device=dev, seed=1234, auto_reset=True,
@@ -518,7 +538,7 @@ def main():
                 if e.nsteps is not None:
                     ns = e.nsteps.to(torch.float64).mean(dim=1)
                     att = float(ns.sum().item())
-                    fl = (2 + 6 * att) * (FLOP_PER_RHS[e.spec.model.name] + 2 * 6 * e.spec.nx) * e.B
+                    fl = flops_per_env_step(e.spec.model.name, e.spec.nx, e.spec.integrator, att) * e.B
                     d.update(attempted_steps_mean=att, fp64_TFLOPs=fl / kern_s / 1e12,
                              fp64_frac=fl / kern_s / 1e12 / FP64_PEAK_TFLOPS)
                 segs_out.append(d)
@@ -558,14 +578,15 @@ def main():
             }
             if fp64:
                 # fp64-issue-bound kernels: algorithmic flops = RHS evaluations x (flop per RHS + RK stage combination)
+                att = 0.0
                 if adaptive:
                     att = (stepsum[0] + stepsum[1]) / max(stepsum[2], 1)
-                    rhs = 2 + 6 * att
+                    rhs = (2 + 6 * att) if spec.integrator == "dopri5" else 6 * att
                     rl["attempted_steps_mean"] = att
                     rl["accepted_steps_mean"] = stepsum[0] / max(stepsum[2], 1)
                 else:
                     rhs = 4 * spec.substeps
-                fl = rhs * (FLOP_PER_RHS[spec.model.name] + 2 * 6 * spec.nx) * B
+                fl = flops_per_env_step(spec.model.name, spec.nx, spec.integrator, att, spec.substeps) * B
                 tf = fl / kern_avg_s / 1e12
                 rl.update(bound="fp64_valu", achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
                           frac=tf / FP64_PEAK_TFLOPS, hbm_GBps=achieved, algorithmic_flops_per_launch=fl,

@@ -1621,6 +1621,8 @@ Kernels make_kernels() {
   if constexpr (ros_structured<M>::value && !M::DYNAMIC) {
     k.queue_r4[0] = step_kernel_queue<M, false, true, PCG_INT_RODAS4>;
     k.queue_r4[1] = step_kernel_queue<M, true, true, PCG_INT_RODAS4>;
+    // registers only: the fused rollout works as for the explicit pair (64-thread workgroups, no LDS)
+    k.rollout[PCG_INT_RODAS4][0] = k.rollout[PCG_INT_RODAS4][1] = rollout_kernel<M, PCG_INT_RODAS4, false>;
   }
   k.rhs = rhs_kernel<M>;
   if constexpr (!M::DYNAMIC) {

@@ -204,7 +204,14 @@ def test_integrator_selection():
     p4["integrator"] = "rk4"
     assert EnvSpec(p4).integrator == "rk4" and EnvSpec(p4).substeps == 4   # dt = 26/60
     assert EnvSpec(P("four_tank_canonical")).integrator == "rk4"
-    assert EnvSpec(P("me_canonical")).integrator == "dopri5"   # stiff: adaptive by default
+    sm = EnvSpec(P("me_canonical"))                            # stiff: the Rosenbrock pair with end-point control
+    assert sm.integrator == "rodas4" and sm.rtol == 3e-8 and sm.atol == 3e-8 and (sm.ep_frac, sm.ep_kmax) == (0.5, 10)
+    pj = P("me_canonical")
+    pj["integration_method"] = "jax"                           # the reference's explicit 5(4) path keeps its semantic
+    assert EnvSpec(pj).integrator == "dopri5" and EnvSpec(pj).rtol == 1e-8 and EnvSpec(pj).ep_kmax == 0
+    pu = P("me_canonical")
+    pu.update(uncertainty_percentages={"Kla": 0.1}, uncertainty_bounds={"low": [4.0], "high": [6.0]})
+    assert EnvSpec(pu).integrator == "dopri5"                  # per-env parameters: general explicit kernel
     p = P("cstr_canonical")
     p["integration_method"] = "jax"                            # reference's adaptive 5(4) path
     s = EnvSpec(p)

@@ -221,15 +221,31 @@ def test_full_size_configs2_rodas4():
     env.close()
 
 
-def test_unsupported_combinations_are_refused():
+def test_fused_rollout_equals_stepping_and_dense_path_is_refused():
+    """pcg_rollout with the structured pair (state in registers over T steps) == T pcg_step launches, bitwise; the
+    dense-W path (LDS matrices) steps through pcg_step only"""
     torch = _torch()
     from pcgym_amd import VecEnv
 
     p = copy.deepcopy(SC.scenarios()["me_canonical"]["env_params"])
+    B, T = 700, 6
+    e1, e2 = VecEnv(p, n_envs=B, seed=3), VecEnv(p, n_envs=B, seed=3)
+    assert e1.spec.integrator == "rodas4"
+    e1.reset()
+    e2.reset()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    acts = 2 * torch.rand((T, 2, B), generator=gen, device="cuda", dtype=torch.float64) - 1
+    obs_seq, rew_seq = e2.rollout(acts, collect_obs=True, collect_rew=True)
+    for i in range(T):
+        o, r, d, _, _ = e1.step(acts[i])
+        assert torch.equal(o.t().contiguous(), obs_seq[i]) and torch.equal(r, rew_seq[i]), i
+    assert torch.equal(e1.x, e2.x) and torch.equal(e1.status, e2.status)
+    e1.close()
+    e2.close()
+    p = copy.deepcopy(SC.scenarios()["four_tank_canonical"]["env_params"])
     p.update(integrator="rodas4")
     env = VecEnv(p, n_envs=64)
     env.reset()
-    a = torch.zeros((3, 2, 64), device="cuda", dtype=torch.float64)
     with pytest.raises(Exception):
-        env.rollout(a)  # PCG_E_UNSUPPORTED: the Rosenbrock pairs step through pcg_step only
+        env.rollout(torch.zeros((3, 2, 64), device="cuda", dtype=torch.float64))  # PCG_E_UNSUPPORTED
     env.close()

@@ -59,7 +59,7 @@ def test_mixed_batch_with_gaussian_disturbances_vs_oracle():
     mixed = MixedVecEnv(segs, seed=21, env_offset=5 * 10**9, auto_reset=True)
     orcs = [O.OracleEnv(e.spec, e.B, seed=21, env_offset=off) for e, off in zip(mixed.envs, mixed.offsets)]
     assert [e.spec.model.name for e in mixed.envs] == ["cstr", "four_tank", "multistage_extraction"]
-    assert mixed.envs[0].spec.gauss and mixed.envs[2].spec.gauss and mixed.envs[2].spec.integrator == "dopri5"
+    assert mixed.envs[0].spec.gauss and mixed.envs[2].spec.gauss and mixed.envs[2].spec.integrator == "rodas4"
     mixed.reset()
     for o in orcs:
         o.reset()
