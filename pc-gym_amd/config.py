@@ -219,6 +219,7 @@ def trace_callable(fn, dims, sample_points, what, arg_names=("x", "u")):
     exprs = [v.e if isinstance(v, _Sym) else _Sym._lit(v) for v in flat]
     env = {k: getattr(math, k) for k in ("exp", "log", "sqrt", "sin", "cos", "tanh", "fabs")}
     env["pow"] = math.pow
+    verified = 0
     for z in sample_points:
         z = np.asarray(z, dtype=_f64).reshape(-1)
         parts, o = [], 0
@@ -236,6 +237,10 @@ def trace_callable(fn, dims, sample_points, what, arg_names=("x", "u")):
         if want.shape != got.shape or not np.all(np.abs(want[ok] - got[ok]) <= 1e-9 * (np.abs(want[ok]) + 1e-12) + 1e-300):
             raise ValueError(f"{what}: the traced expressions do not reproduce the callable (it probably contains "
                              "control flow or state that tracing cannot see)")
+        verified += int(ok.any())
+    if verified == 0:  # never compile a trace that no probe point could confirm
+        raise ValueError(f"{what}: the traced expressions could not be checked against the callable at any probe point "
+                         "(every evaluation left its domain); write the expressions out instead")
     return exprs
 
 

@@ -5,7 +5,13 @@
 #include "pcg_step_feat.hpp"
 
 #include <hip/hiprtc.h>
+#include <dirent.h>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
 
 #include <fstream>
 #include <map>
@@ -420,6 +426,119 @@ static uint64_t fnv1a(const std::string& s) {
   return h;
 }
 
+static uint64_t fnv1a_seed(const std::string& s, uint64_t seed) {
+  uint64_t h = 1469598103934665603ull ^ seed;
+  for (unsigned char ch : s) h = (h ^ ch) * 1099511628211ull;
+  return h;
+}
+#ifndef PCG_SRC_HASH
+#define PCG_SRC_HASH "unknown-build"  // the Makefile passes a digest of csrc/*.hpp + include/pcgym_hip.h
+#endif
+
+// digest of the headers a run-time compilation will see: every *.hpp of the include directory and the ABI header
+// next to it (../../include/pcgym_hip.h), by content.  Cached per directory for the life of the process.
+static std::string jit_header_digest(const char* inc_dir) {
+  static std::map<std::string, std::string> memo;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = memo.find(inc_dir);
+  if (it != memo.end()) return it->second;
+  std::vector<std::string> files;
+  if (DIR* d = ::opendir(inc_dir)) {
+    while (dirent* e = ::readdir(d)) {
+      const std::string n = e->d_name;
+      if (n.size() > 4 && n.compare(n.size() - 4, 4, ".hpp") == 0) files.push_back(std::string(inc_dir) + "/" + n);
+    }
+    ::closedir(d);
+  }
+  std::sort(files.begin(), files.end());
+  files.push_back(std::string(inc_dir) + "/../../include/pcgym_hip.h");
+  uint64_t h1 = 0, h2 = 0;
+  for (const std::string& f : files) {
+    std::ifstream in(f, std::ios::binary);
+    const std::string body((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    const std::string tag = f.substr(f.find_last_of('/') + 1) + ":" + std::to_string(body.size()) + ":";
+    h1 = fnv1a_seed(tag + body, h1);
+    h2 = fnv1a_seed(tag + body, h2 ^ 0x9E3779B97F4A7C15ull);
+  }
+  char hex[40];
+  std::snprintf(hex, sizeof(hex), "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
+  return memo[inc_dir] = hex;
+}
+
+// The disk cache lives in a directory only its owner can write: $PCG_JIT_CACHE, else $XDG_CACHE_HOME/pcgym_amd, else
+// ~/.cache/pcgym_amd -- created with mkdir(2), mode 0700, no shell.  A directory (or file) that belongs to somebody
+// else, or that group / others can write, is not used: code objects found there would run inside this process.
+// Returns "" when there is no usable directory (the in-process cache still works).
+static bool jit_path_private(const std::string& p, bool want_dir) {
+  struct stat st;
+  if (::lstat(p.c_str(), &st) != 0) return false;
+  if (want_dir ? !S_ISDIR(st.st_mode) : !S_ISREG(st.st_mode)) return false;
+  return st.st_uid == ::geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+static std::string jit_cache_dir() {
+  std::string dir;
+  if (const char* e = std::getenv("PCG_JIT_CACHE")) dir = e;
+  else if (const char* x = std::getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/pcgym_amd";
+  else if (const char* h = std::getenv("HOME")) dir = std::string(h) + "/.cache/pcgym_amd";
+  if (dir.empty() || dir[0] != '/') return std::string();
+  for (size_t i = 1; i <= dir.size(); ++i)  // mkdir -p, without a shell
+    if (i == dir.size() || dir[i] == '/') {
+      const std::string part = dir.substr(0, i);
+      if (::mkdir(part.c_str(), 0700) != 0 && errno != EEXIST) return std::string();
+    }
+  return jit_path_private(dir, true) ? dir : std::string();
+}
+// file = "PCGJIT2\n" nfn lowered names (one per line) code size, two 64-bit digests of (names + code) "\n" code
+static bool jit_cache_read(const std::string& path, int nfn, std::string* code, std::string* low) {
+  if (!jit_path_private(path, false)) return false;
+  std::ifstream in(path, std::ios::binary);
+  std::string magic, line;
+  if (!std::getline(in, magic) || magic != "PCGJIT2") return false;
+  std::string all;
+  for (int q = 0; q < nfn; ++q) {
+    if (!std::getline(in, low[q]) || low[q].empty()) return false;
+    all += low[q] + "\n";
+  }
+  unsigned long long sz = 0, d1 = 0, d2 = 0;
+  if (!std::getline(in, line) || std::sscanf(line.c_str(), "%llu %llx %llx", &sz, &d1, &d2) != 3 || sz == 0 || sz > (1ull << 30))
+    return false;
+  std::string body((size_t)sz, '\0');
+  in.read(&body[0], (std::streamsize)sz);
+  if ((unsigned long long)in.gcount() != sz) return false;
+  all += body;
+  if (fnv1a(all) != d1 || fnv1a_seed(all, 0x9E3779B97F4A7C15ull) != d2) return false;  // truncated / corrupted / edited
+  *code = std::move(body);
+  return true;
+}
+static void jit_cache_write(const std::string& path, int nfn, const std::string& code, const std::string* low) {
+  // several processes (one per GPU) may compile the same source at once: a private temporary, complete and closed
+  // before it appears under the final name; a write error never publishes a file
+  const std::string tmp = path + "." + std::to_string((long long)getpid()) + ".tmp";
+  const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+  if (fd < 0) return;
+  std::string all;
+  for (int q = 0; q < nfn; ++q) all += low[q] + "\n";
+  std::string head = "PCGJIT2\n" + all;
+  all += code;
+  char meta[96];
+  std::snprintf(meta, sizeof(meta), "%llu %016llx %016llx\n", (unsigned long long)code.size(), (unsigned long long)fnv1a(all),
+                (unsigned long long)fnv1a_seed(all, 0x9E3779B97F4A7C15ull));
+  head += meta;
+  bool ok = true;
+  const std::string* parts[2] = {&head, &code};
+  for (const std::string* part : parts) {
+    size_t off = 0;
+    while (ok && off < part->size()) {
+      const ssize_t w = ::write(fd, part->data() + off, part->size() - off);
+      if (w <= 0) ok = false;
+      else off += (size_t)w;
+    }
+  }
+  ok = (::close(fd) == 0) && ok;
+  if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) ::unlink(tmp.c_str());
+}
+
 static int jit_kernels(const pcg_env_cfg* cfg, int kid, int device, JitModule* out) {
   if (!cfg->jit_include_dir) return PCG_E_NULL;
   const bool user = cfg->model_id == PCG_MODEL_USER;
@@ -466,85 +585,80 @@ static int jit_kernels(const pcg_env_cfg* cfg, int kid, int device, JitModule* o
     src << "template __global__ void " << names[3] << "(pcg::CDevConst*, int64_t, int, const double*, const double*, double*);\n";
   }
   const std::string text = src.str();
-  const uint64_t key = fnv1a(text + "|" + arch + "|" + std::to_string(PCG_ABI_VERSION) + "|" + std::to_string(device));
+  // The translation unit only says `#include "pcg_kernels.hpp"`: the CONTENT of the kernel headers it will be compiled
+  // against has to be part of the key too (a changed integrator or model with unchanged struct sizes must not find an
+  // old code object) -- hash of every header in the include directory + the ABI header + the library's own build id.
+  const std::string hdr = jit_header_digest(cfg->jit_include_dir);
+  const std::string ident = text + "|" + arch + "|" + std::to_string(PCG_ABI_VERSION) + "|" + hdr + "|" PCG_SRC_HASH;
+  const uint64_t key = fnv1a(ident + "|" + std::to_string(device));
   std::lock_guard<std::mutex> lk(g_jit_mu);
   auto hit = g_jit_cache.find(key);
   if (hit != g_jit_cache.end()) {
     *out = hit->second;
     return PCG_OK;
   }
-  // disk cache: code object + the lowered kernel names
-  const char* cdir = std::getenv("PCG_JIT_CACHE");
-  std::string dir = cdir ? cdir : "/tmp/pcgym_amd_jit";
-  char hex[32];
-  std::snprintf(hex, sizeof(hex), "%016llx", (unsigned long long)fnv1a(text + "|" + arch + "|" + std::to_string(PCG_ABI_VERSION)));
-  const std::string base = dir + "/" + hex;
+  // disk cache: one file per source = lowered kernel names + code object, with a digest of both
+  const std::string dir = jit_cache_dir();
+  char hex[40];
+  std::snprintf(hex, sizeof(hex), "%016llx%016llx", (unsigned long long)fnv1a(ident), (unsigned long long)fnv1a_seed(ident, 0x9E3779B97F4A7C15ull));
+  const std::string path = dir.empty() ? std::string() : dir + "/" + hex + ".pco";
   std::string code, low[4];
-  {
-    std::ifstream fc(base + ".co", std::ios::binary), fn(base + ".names");
-    if (fc && fn) {
-      code.assign(std::istreambuf_iterator<char>(fc), std::istreambuf_iterator<char>());
-      for (int q = 0; q < nfn; ++q) {
-        std::getline(fn, low[q]);
-        if (low[q].empty()) code.clear();
-      }
-    }
-  }
-  if (code.empty()) {
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, text.c_str(), "pcg_user_step.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return PCG_E_JIT;
-    for (int q = 0; q < nfn; ++q) hiprtcAddNameExpression(prog, names[q].c_str());
-    const std::string oarch = "--offload-arch=" + arch, oinc = std::string("-I") + cfg->jit_include_dir;
-    const char* opts[] = {oarch.c_str(), "-O3", "-std=c++17", oinc.c_str()};
-    const hiprtcResult cr = hiprtcCompileProgram(prog, 4, opts);
-    size_t ls = 0;
-    hiprtcGetProgramLogSize(prog, &ls);
-    g_jit_log.assign(ls, '\0');
-    if (ls) hiprtcGetProgramLog(prog, &g_jit_log[0]);
-    if (cr != HIPRTC_SUCCESS) {
-      hiprtcDestroyProgram(&prog);
-      return PCG_E_JIT;
-    }
-    for (int q = 0; q < nfn; ++q) {
-      const char* ln = nullptr;
-      if (hiprtcGetLoweredName(prog, names[q].c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
+  bool from_disk = !path.empty() && jit_cache_read(path, nfn, &code, low);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (code.empty()) {
+      hiprtcProgram prog;
+      if (hiprtcCreateProgram(&prog, text.c_str(), "pcg_user_step.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return PCG_E_JIT;
+      for (int q = 0; q < nfn; ++q) hiprtcAddNameExpression(prog, names[q].c_str());
+      const std::string oarch = "--offload-arch=" + arch, oinc = std::string("-I") + cfg->jit_include_dir;
+      const char* opts[] = {oarch.c_str(), "-O3", "-std=c++17", oinc.c_str()};
+      const hiprtcResult cr = hiprtcCompileProgram(prog, 4, opts);
+      size_t ls = 0;
+      hiprtcGetProgramLogSize(prog, &ls);
+      g_jit_log.assign(ls, '\0');
+      if (ls) hiprtcGetProgramLog(prog, &g_jit_log[0]);
+      if (cr != HIPRTC_SUCCESS) {
         hiprtcDestroyProgram(&prog);
         return PCG_E_JIT;
       }
-      low[q] = ln;
-    }
-    size_t cs = 0;
-    hiprtcGetCodeSize(prog, &cs);
-    code.assign(cs, '\0');
-    hiprtcGetCode(prog, &code[0]);
-    hiprtcDestroyProgram(&prog);
-    // best effort: a cache that cannot be written is only slower next time
-    std::string mk = "mkdir -p '" + dir + "'";
-    if (std::system(mk.c_str()) == 0) {
-      // several processes (one per GPU) may compile the same source at once: private temporaries, both files complete
-      // and closed before they appear, the code object last (a reader needs both and opens the code object first)
-      const std::string tmp = base + "." + std::to_string((long long)getpid());
-      {
-        std::ofstream fc(tmp + ".co", std::ios::binary), fn(tmp + ".names");
-        fc.write(code.data(), (std::streamsize)code.size());
-        for (int q = 0; q < nfn; ++q) fn << low[q] << "\n";
+      for (int q = 0; q < nfn; ++q) {
+        const char* ln = nullptr;
+        if (hiprtcGetLoweredName(prog, names[q].c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
+          hiprtcDestroyProgram(&prog);
+          return PCG_E_JIT;
+        }
+        low[q] = ln;
       }
-      std::rename((tmp + ".names").c_str(), (base + ".names").c_str());
-      std::rename((tmp + ".co").c_str(), (base + ".co").c_str());
+      size_t cs = 0;
+      hiprtcGetCodeSize(prog, &cs);
+      code.assign(cs, '\0');
+      hiprtcGetCode(prog, &code[0]);
+      hiprtcDestroyProgram(&prog);
+      if (!path.empty()) jit_cache_write(path, nfn, code, low);  // best effort: an unwritable cache is only slower next time
     }
+    hipModule_t mod;
+    const hipError_t le = hipModuleLoadData(&mod, code.data());
+    if (le != hipSuccess) {
+      if (from_disk && attempt == 0) {  // a cached object the driver refuses: drop it and compile afresh
+        (void)hipGetLastError();
+        ::unlink(path.c_str());
+        code.clear();
+        from_disk = false;
+        continue;
+      }
+      return (int)le;
+    }
+    JitModule jm;
+    jm.integ = jm.rhs = nullptr;
+    for (int pe = 0; pe < 2; ++pe) HIP_TRY(hipModuleGetFunction(&jm.fn[pe], mod, low[pe].c_str()));
+    if (user) {
+      HIP_TRY(hipModuleGetFunction(&jm.integ, mod, low[2].c_str()));
+      HIP_TRY(hipModuleGetFunction(&jm.rhs, mod, low[3].c_str()));
+    }
+    g_jit_cache[key] = jm;
+    *out = jm;
+    return PCG_OK;
   }
-  hipModule_t mod;
-  HIP_TRY(hipModuleLoadData(&mod, code.data()));
-  JitModule jm;
-  jm.integ = jm.rhs = nullptr;
-  for (int pe = 0; pe < 2; ++pe) HIP_TRY(hipModuleGetFunction(&jm.fn[pe], mod, low[pe].c_str()));
-  if (user) {
-    HIP_TRY(hipModuleGetFunction(&jm.integ, mod, low[2].c_str()));
-    HIP_TRY(hipModuleGetFunction(&jm.rhs, mod, low[3].c_str()));
-  }
-  g_jit_cache[key] = jm;
-  *out = jm;
-  return PCG_OK;
+  return PCG_E_JIT;
 }
 
 int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
@@ -613,6 +727,26 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
     p->jit_fn[1] = jm.fn[1];
     p->jit_integ = jm.integ;
     p->jit_rhs = jm.rhs;
+    // Rosenbrock pairs keep nx^2 doubles per lane in LDS: past 48 KB per workgroup (nx >= 10) a kernel has to be told.
+    // Decided HERE, so that a plan that cannot run says so at creation and not at its first step.
+    const int jnx = cfg->model_id == PCG_MODEL_USER ? cfg->nx : kernels(p->kid).nx;
+    const size_t need = sizeof(double) * integ_lds_doubles(jnx, cfg->integrator_id, false) +
+                        sizeof(double) * (size_t)(p->hc.nsp + p->hc.nd) * p->hc.N;
+    if (need > 48 * 1024) {
+      hipFunction_t fns[3] = {jm.fn[0], jm.fn[1], jm.integ};
+      for (hipFunction_t f : fns) {
+        if (!f) continue;
+        const hipError_t ae = hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)(need < 160 * 1024 ? need : 160 * 1024));
+        if (ae != hipSuccess) {
+          (void)hipGetLastError();
+          (void)hipFree(p->dC);
+          (void)hipFree(p->dsched);
+          delete p;
+          return PCG_E_UNSUPPORTED;
+        }
+      }
+    }
   }
   *out = p;
   return PCG_OK;
@@ -808,7 +942,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
     }
   }
   if (p->jit_fn[0]) {  // run-time compiled general kernel with the plan's user expressions
-    if (lds_st || integ_shmem > 48 * 1024) return PCG_E_UNSUPPORTED;
+    if (lds_st) return PCG_E_UNSUPPORTED;
     void* argv[1] = {&a};
     const size_t sh = (per_env_t && a.sched_in_lds) ? shmem : integ_shmem;
     return (int)hipModuleLaunchKernel(p->jit_fn[per_env_t ? 1 : 0], grid_for(io->B, block), 1, 1, block, 1, 1, (unsigned)sh,
@@ -1175,7 +1309,6 @@ int pcg_integrate(pcg_plan* p, int64_t B, double* x, const double* u, int32_t* n
   if (p->jit_integ) {  // PCG_MODEL_USER: the run-time compiled hook
     const int ub = tb(false, p->integrator_id, p->nx);
     const size_t ush = sizeof(double) * integ_lds_doubles(p->nx, p->integrator_id, false);
-    if (ush > 48 * 1024) return PCG_E_UNSUPPORTED;
     const PCG_CONSTANT DevConst* dc = (CDevConst*)p->dC;
     int nu = p->cfg_nu;
     void* argv[6] = {&dc, &B, &nu, &x, &u, &nsteps};

@@ -203,6 +203,8 @@ class VecEnv:
             if t is not None and (t.shape != ref.shape or t.dtype != torch.float64 or t.device != ref.device
                                   or not t.is_contiguous()):
                 raise ValueError(f"bind_outputs: need a contiguous float64 tensor of shape {tuple(ref.shape)} on {ref.device}")
+        # captured HIP graphs hold the OLD pointers: they refuse to replay after a re-binding (StepGraph.replay)
+        self._binding_epoch = getattr(self, "_binding_epoch", 0) + 1
         if obs_soa is not None:
             self.obs_soa = obs_soa
             self._buf.obs = obs_soa.data_ptr()
@@ -350,6 +352,7 @@ class StepGraph:
                 raise ValueError("one disturbance slab per recorded step")
             self._d = [env._as_soa(d, s.nd, "disturbance") for d in disturbances]
             dp = (C.c_void_p * T)(*[d.data_ptr() for d in self._d])
+        self._epoch = getattr(env, "_binding_epoch", 0)
         self._uses_rng = bool(s.noise or s.gauss or (with_reset and (s.nunc or s.x0_unc is not None)))
         self._seed = (env.seed0 + env.episode + (1 if with_reset else 0)) & 0xFFFFFFFFFFFFFFFF
         g = C.c_void_p()
@@ -363,6 +366,9 @@ class StepGraph:
         env = self.env
         if self._g is None:
             raise RuntimeError("StepGraph was destroyed")
+        if getattr(env, "_binding_epoch", 0) != self._epoch:
+            raise RuntimeError("the env's output buffers were re-bound (bind_outputs) after this graph was captured: the "
+                               "graph would write to the old storage -- capture again")
         if self.with_reset:
             env.episode += 1
         elif env.t != self.t0:

@@ -20,8 +20,7 @@ class HostGather:
         self.env = env
         self.torch = torch
         self.fields = tuple(fields)
-        src = {"obs": env.obs_soa, "rew": env.rew, "done": env.done, "x": env.x}
-        self._src = [src[f] for f in self.fields]
+        self._src = self._sources()
         self._stage = [[torch.empty_like(t) for t in self._src] for _ in range(2)]
         self._host = [[torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in self._src] for _ in range(2)]
         self._copy = torch.cuda.Stream(device=env.device)
@@ -30,6 +29,12 @@ class HostGather:
         self._k = 0
         self.bytes_per_step = sum(t.numel() * t.element_size() for t in self._src)
 
+    def _sources(self):
+        # resolved on every push: VecEnv.bind_outputs may have pointed obs / rew at other storage since the last step
+        env = self.env
+        src = {"obs": env.obs_soa, "rew": env.rew, "done": env.done, "x": env.x}
+        return [src[f] for f in self.fields]
+
     def push(self):
         """Call after env.step(): snapshot this step's outputs and start their D2H copy.  Returns the slot index."""
         torch = self.torch
@@ -37,6 +42,7 @@ class HostGather:
         main = torch.cuda.current_stream(self.env.device)
         if self._k >= 2:
             main.wait_event(self._done[k])  # staging[k] is free once its previous D2H has finished
+        self._src = self._sources()
         for s, d in zip(self._src, self._stage[k]):
             d.copy_(s, non_blocking=True)
         self._snap[k].record(main)

@@ -56,8 +56,10 @@ class hip_integration_engine:
             p["integration_method"] = "hip"
         self.spec = spec = EnvSpec(p)
         cfg, keep = spec.to_cfg()
-        key = (spec.model.model_id, spec.integrator, spec.substeps, spec.rtol, spec.atol, spec.max_steps, spec.dt,
-               spec.nu, tuple(np.asarray(spec.param_vector()).ravel().tolist()), spec.user_rhs_src)
+        # (plans are bound to the device they were created on: the device is part of the key)
+        key = (torch.cuda.current_device(), spec.model.model_id, spec.integrator, spec.substeps, spec.rtol, spec.atol,
+               spec.max_steps, spec.dt, spec.nu, tuple(np.asarray(spec.param_vector()).ravel().tolist()),
+               spec.user_rhs_src, spec.ep_frac, spec.ep_kmax)
         ent = _PLANS.get(key)
         if ent is None:
             plan = C.c_void_p()

@@ -11,6 +11,12 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # run-time compiled kernels: a cache of this session only, so that a green run never validates code objects left
+    # behind by an earlier build (the key covers the kernel headers since round 3; this is belt and braces)
+    if "PCG_JIT_CACHE" not in os.environ:
+        import tempfile
+
+        os.environ["PCG_JIT_CACHE"] = tempfile.mkdtemp(prefix="pcg_jit_test_")
 
 
 def _has_gpu():
