@@ -203,7 +203,7 @@ def cpu_baseline(spec, seconds_target=10.0, threads=None):
     e2.reset()
     worst = 0.0
     for i in range(10):
-        a = rng.uniform(-1, 1, (spec.na, nb))
+        a = act_box(spec) * rng.uniform(-1, 1, (spec.na, nb)) + act_shift(spec)  # the bench's own action distribution
         e2.x[:] = e1.x
         e2.t = e1.t
         e1.step(a)
@@ -262,6 +262,36 @@ def act_box(spec):
 
 def act_shift(spec):
     return 0.25 if spec.model.name == "four_tank" else 0.0
+
+
+def x0_box(spec):
+    """[low, high] of the initial states the reset kernel draws (x0 (1 +- pct), uniform), or the single x0"""
+    import numpy as np
+
+    x0 = np.asarray(spec.x0[:spec.nx], dtype=float)
+    if spec.x0_unc is None:
+        return [x0.tolist(), x0.tolist()]
+    pct = np.asarray(spec.x0_unc, dtype=float)
+    return [(x0 * (1 - pct)).round(6).tolist(), (x0 * (1 + pct)).round(6).tolist()]
+
+
+_PMC = None
+
+
+def committed_pmc(workload):
+    """per-launch counters of this workload's dominant kernel from the committed rocprofv3 PMC passes (profiles/r3/pmc.json,
+    made by tools/prof_all.sh + tools/pmc_json.py on the GPU box; FETCH_SIZE x 2 per MI355X_MICROARCH.md's gfx950 note).
+    NOT measured in this run: hardware counters cannot be read from inside the process."""
+    global _PMC
+    if _PMC is None:
+        _PMC = {}
+        for tp in ("profiles/r3/pmc.json",):
+            tpath = os.path.join(ROOT, tp)
+            if os.path.exists(tpath):
+                with open(tpath) as fh:
+                    _PMC = json.load(fh)
+                break
+    return _PMC.get(workload)
 
 
 def clock_preheat(torch, dev, ms):
@@ -518,6 +548,8 @@ def main():
             "envs_per_gpu": B_eff,
             "global_envs": B_eff * world,
             "episode_len": spec.N - 1,
+            "dt_model_units": spec.dt,
+            "x0_box": x0_box(spec),
             "parallelism": f"env-shard x{world} (no collective on the hot path)",
             "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none (single process)",
             "ranks_seen": ranks_seen,
@@ -542,6 +574,14 @@ def main():
                     d.update(attempted_steps_mean=att, fp64_TFLOPs=fl / kern_s / 1e12,
                              fp64_frac=fl / kern_s / 1e12 / FP64_PEAK_TFLOPS)
                 segs_out.append(d)
+            pmx = committed_pmc("mixed") if B == (1 << 20) and not args.integrator else None
+            if pmx:
+                for d in segs_out:
+                    q = pmx.get("segments", {}).get(d["segment"])
+                    if q:
+                        d["traffic"] = q["traffic_bytes_per_launch"]
+                        if "valu_issue_frac" in q:
+                            d["valu_issue_frac"] = q["valu_issue_frac"]
             dom = max(segs_out, key=lambda d: d["kernel_avg_us"])
             out["roofline"] = {
                 "bound": "fp64_valu" if "fp64_frac" in dom else "hbm",
@@ -549,7 +589,7 @@ def main():
                 "peak": FP64_PEAK_TFLOPS if "fp64_frac" in dom else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if "fp64_frac" in dom else "GB/s",
                 "frac": dom.get("fp64_frac", dom["hbm_frac"]),
-                "traffic": None,
+                "traffic": dom.get("traffic"),
                 "traffic_measured_in_run": False,
                 "kernel": f"dominant segment: {dom['segment']} ({dom['integrator']}); the three segments run concurrently "
                           "on their own streams",
@@ -593,14 +633,24 @@ def main():
                           rhs_evals_per_env_step=rhs)
             # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside
             # this process): the committed measurement of this kernel + workload, if present -- NOT measured in this run
-            for tp in ("profiles/r2/traffic.json", "profiles/r1/traffic.json"):
-                tpath = os.path.join(ROOT, tp)
-                if (os.path.exists(tpath) and args.workload == "cstr" and B == (1 << 20) and args.substeps is None):
-                    with open(tpath) as fh:
-                        tj = json.load(fh)
-                    rl["traffic"] = tj["traffic_bytes_per_launch"]
-                    rl["traffic_source"] = tp + ": " + tj["source"]
-                    break
+            pm = committed_pmc(args.workload) if (B == Bd and args.substeps is None and not args.integrator) else None
+            if pm:
+                rl["traffic"] = pm["traffic_bytes_per_launch"]
+                rl["traffic_over_algorithmic"] = pm["traffic_bytes_per_launch"] / alg_bytes
+                rl["traffic_source"] = pm["source"]
+                if "valu_issue_frac" in pm:
+                    # instruction-issue view of the same kernel: 4 cycles per wave64 VALU instruction on a 16-lane SIMD,
+                    # 1024 SIMDs, cycles = GRBM_GUI_ACTIVE of the dispatch -- independent of any flop weighting
+                    rl["valu_issue_frac"] = pm["valu_issue_frac"]
+                    rl["valu_insts_per_launch"] = pm["SQ_INSTS_VALU_per_launch"]
+            if fp64:
+                f_survey = {"crystallization": 80 + 2 + 3 + 1 + 6}.get(spec.model.name)  # "~80 flop + 2 exp + 3 pow + 1 sqrt + ~6 div" counted as one flop each
+                rl["flop_weighting"] = ("flop per RHS evaluation = SURVEY.md section 8(a)'s count" if f_survey is None else
+                                        "crystallization: 232 flop per RHS = 60 plain + 4 exp/pow at 25 + sqrt 12 + 6 divides "
+                                        "at 10 (instruction-level cost of the transcendentals); SURVEY.md section 8(a) counts "
+                                        f"every operation once: {f_survey} flop -> frac_at_survey_flop_count")
+                if f_survey is not None:
+                    rl["frac_at_survey_flop_count"] = rl["frac"] * (4 * spec.substeps * (f_survey + 12 * spec.nx) * B) / fl
             out["roofline"] = rl
             out["config"]["launch"] = ("eager pcg_step launches" if graph is None else
                                        f"HIP graph of one {last_t}-step episode (pcg_graph_*)")

@@ -49,7 +49,7 @@ typedef unsigned long uintptr_t;
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 8
+#define PCG_ABI_VERSION 9
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -140,7 +140,11 @@ enum pcg_integrator {
                           two, bit-identical in kernel and oracle.  The reference integrates with CVODES BDF
                           (integrator.py:163-182).  pcg_step, pcg_step_autoreset, pcg_graph_*, pcg_integrate;
                           pcg_rollout and per-env uncertain parameters: PCG_E_UNSUPPORTED */
-  PCG_INT_COUNT = 4
+  PCG_INT_TSIT5 = 4,   /* Tsitouras 5(4), FSAL: the method of the reference's jax path (integrator.py:56-61, diffrax.Tsit5 with
+                          PIDController(rtol = atol = 1e-8)); controller, norm, initial step and failure semantics of
+                          PCG_INT_DOPRI5.  General kernel (both counter modes), pcg_step_autoreset, pcg_graph_*,
+                          pcg_integrate; pcg_rollout and per-env uncertain parameters: PCG_E_UNSUPPORTED */
+  PCG_INT_COUNT = 5
 };
 
 /* cfg.flags */

@@ -566,6 +566,100 @@ static int dopri5(const orc_model* m, double* x, const double* u, double dt, dou
   return status;
 }
 
+static double lc7(double c1, double k1, double c2, double k2, double c3, double k3, double c4, double k4, double c5,
+                  double k5, double c6, double k6, double c7, double k7) {
+  return fma(c7, k7, lc6(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5, c6, k6));
+}
+/* Tsit5 -- Tsitouras (2011) 5(4) pair, FSAL: the method of the reference's jax path (integrator.py:56-61, diffrax.Tsit5
+ * under PIDController(rtol = atol = 1e-8)).  Controller, norm, initial step and failure semantics of dopri5() above; twin
+ * of tsit5() in pc-gym_amd/csrc/pcg_integrators.hpp, statement by statement.  The coefficients are pinned by their order
+ * conditions (tests/test_tsit5.py: 17 rooted trees up to order 5 for b, 8 up to order 4 for the embedded weights). */
+static const double T5_A[7][6] = {
+    {0},
+    {0.161},
+    {-0.008480655492356989, 0.335480655492357},
+    {2.8971530571054935, -6.359448489975075, 4.3622954328695815},
+    {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525},
+    {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383},
+    {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}};
+static const double T5_E[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629,
+                               0.5823571654525552, -0.45808210592918697, 0.015151515151515152};
+ORC_EXPORT void orc_tsit5_tableau(double* a42, double* e7) {
+  memcpy(a42, T5_A, sizeof T5_A);
+  memcpy(e7, T5_E, sizeof T5_E);
+}
+static int tsit5(const orc_model* m, double* x, const double* u, double dt, double rtol, double atol, int max_steps,
+                 int32_t* nacc, int32_t* nrej) {
+  int nx = m->nx;
+  double k1[MAXNX], k2[MAXNX], k3[MAXNX], k4[MAXNX], k5[MAXNX], k6[MAXNX], k7[MAXNX];
+  double y[MAXNX], ynew[MAXNX], err[MAXNX];
+  const double(*a)[6] = T5_A;
+  const double* e = T5_E;
+  int acc = 0, rej = 0;
+  rhs_int(m, x, u, k1);
+  double h;
+  {
+    double d0 = rms_scaled(x, x, x, nx, rtol, atol);
+    double d1 = rms_scaled(k1, x, x, nx, rtol, atol);
+    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    if (h0 > dt) h0 = dt;
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h0, k1[i], x[i]);
+    rhs_int(m, y, u, k2);
+    for (int i = 0; i < nx; ++i) err[i] = k2[i] - k1[i];
+    double d2 = rms_scaled(err, x, x, nx, rtol, atol) / h0;
+    double dm = d1 > d2 ? d1 : d2;
+    double h1 = (dm <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : qtrunc6(pow(0.01 / dm, 0.2));
+    h = qtrunc6(fmin(100.0 * h0, h1));
+    if (h > dt) h = dt;
+  }
+  double t = 0.0;
+  int rejected_last = 0, status = 0;
+  for (;;) {
+    int last = 0;
+    if (acc + rej >= max_steps) { status = 1; break; }
+    if (t + h >= dt * (1.0 - 1e-14)) { h = dt - t; last = 1; }
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc1(a[1][0], k1[i]), x[i]);
+    rhs_int(m, y, u, k2);
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc2(a[2][0], k1[i], a[2][1], k2[i]), x[i]);
+    rhs_int(m, y, u, k3);
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc3(a[3][0], k1[i], a[3][1], k2[i], a[3][2], k3[i]), x[i]);
+    rhs_int(m, y, u, k4);
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc4(a[4][0], k1[i], a[4][1], k2[i], a[4][2], k3[i], a[4][3], k4[i]), x[i]);
+    rhs_int(m, y, u, k5);
+    for (int i = 0; i < nx; ++i)
+      y[i] = axpy(h, lc5(a[5][0], k1[i], a[5][1], k2[i], a[5][2], k3[i], a[5][3], k4[i], a[5][4], k5[i]), x[i]);
+    rhs_int(m, y, u, k6);
+    for (int i = 0; i < nx; ++i)
+      ynew[i] = axpy(h, lc6(a[6][0], k1[i], a[6][1], k2[i], a[6][2], k3[i], a[6][3], k4[i], a[6][4], k5[i], a[6][5], k6[i]), x[i]);
+    rhs_int(m, ynew, u, k7);
+    for (int i = 0; i < nx; ++i)
+      err[i] = h * lc7(e[0], k1[i], e[1], k2[i], e[2], k3[i], e[3], k4[i], e[4], k5[i], e[5], k6[i], e[6], k7[i]);
+    double E = rms_scaled(err, x, ynew, nx, rtol, atol);
+    if (E < 1.0) {
+      double f = (E == 0.0) ? 10.0 : fmin(10.0, fmax(0.2, qtrunc6(0.9 * pow(E, -0.2))));
+      if (rejected_last && f > 1.0) f = 1.0;
+      t += h;
+      h *= f;
+      for (int i = 0; i < nx; ++i) { x[i] = ynew[i]; k1[i] = k7[i]; }
+      rejected_last = 0;
+      ++acc;
+      if (last) break;
+    } else {
+      double f = (E == E) ? fmax(0.2, qtrunc6(0.9 * pow(E, -0.2))) : 0.2;
+      if (f > 1.0) f = 1.0;
+      h *= f;
+      rejected_last = 1;
+      ++rej;
+      if (!(h > 1e-13 * dt)) { status = 2; break; }
+    }
+  }
+  if (nacc) *nacc = acc;
+  if (nrej) *nrej = rej;
+  if (status != 0)
+    for (int i = 0; i < nx; ++i) x[i] = NAN;
+  return status;
+}
+
 /* Rodas3 (Sandu et al. 1997): 4-stage linearly implicit Rosenbrock 3(2) pair, gamma = 1/2, L-stable, stiffly accurate
  * -- the stiff-capable integrator of the engine (the reference solves with CVODES BDF, integrator.py:163-182; its
  * recorded LSODA trajectories are the accuracy pin, tests/test_oracle_golden.py).  Twin of rodas3() in
@@ -1157,6 +1251,8 @@ static void env_step(const pcg_env_cfg* c, orc_env* e, const double* action_in, 
   if (c->integrator_id == PCG_INT_RK4) rk4(&m, e->state, uk, c->dt, c->substeps);
   else if (c->integrator_id == PCG_INT_RODAS3)
     ist = rodas3(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
+  else if (c->integrator_id == PCG_INT_TSIT5)
+    ist = tsit5(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
   else if (c->integrator_id == PCG_INT_RODAS4)
     ist = rodas4(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, &o->nacc, &o->nrej);
   else ist = dopri5(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
@@ -1312,6 +1408,7 @@ ORC_EXPORT int orc_integrate(const pcg_env_cfg* c, int64_t B, double* x, const d
     for (int i = 0; i < nu; ++i) ui[i] = u[(size_t)i * B + b];
     if (c->integrator_id == PCG_INT_RK4) rk4(&m, xi, ui, c->dt, c->substeps);
     else if (c->integrator_id == PCG_INT_RODAS3) rodas3(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, &na_, &nr_);
+    else if (c->integrator_id == PCG_INT_TSIT5) tsit5(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, &na_, &nr_);
     else if (c->integrator_id == PCG_INT_RODAS4)
       rodas4(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, &na_, &nr_);
     else dopri5(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, &na_, &nr_);

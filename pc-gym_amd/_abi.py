@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PCG_ABI_VERSION = 8
+PCG_ABI_VERSION = 9
 PCG_MAX_NX = 24
 PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
@@ -43,6 +43,7 @@ PCG_INT_RK4 = 0
 PCG_INT_DOPRI5 = 1
 PCG_INT_RODAS3 = 2
 PCG_INT_RODAS4 = 3
+PCG_INT_TSIT5 = 4
 
 PCG_F_NORMALISE_A = 0x0001
 PCG_F_NORMALISE_O = 0x0002

@@ -7,8 +7,8 @@ Mirrors the parsing done by the reference ``make_env.__init__`` and its
 C ABI.  Nothing numeric about the hot path happens here.
 
 New optional keys (do not exist in the reference):
-  integrator   'rk4' | 'dopri5' | 'rodas3' | 'rodas4' (stiff-capable Rosenbrock pairs)   (default per model, see
-               DEFAULT_INTEGRATOR)
+  integrator   'rk4' | 'dopri5' | 'tsit5' | 'rodas3' | 'rodas4' (stiff-capable Rosenbrock pairs)   (default per model,
+               see DEFAULT_INTEGRATOR; integration_method='jax' -> 'tsit5', the reference's own method, integrator.py:56-61)
   endpoint_control  rodas4 only: {'frac': 0.5, 'kmax': 10} | False -- end-point error control (pcgym_hip.h,
                PCG_INT_RODAS4); on by default, acts only on models with a contraction-rate hook (extraction cascades)
   substeps     RK4 sub-steps per env step
@@ -686,11 +686,15 @@ class EnvSpec:
 
         # --- integrator selection (new keys) -------------------------------------------
         d_int = DEFAULT_INTEGRATOR[self.model.model_id]
-        if self.integration_method == "jax" or (d_int == "rodas4" and self.nunc > 0):
+        if self.integration_method == "jax":
+            # diffrax.Tsit5 + PIDController(rtol = atol = 1e-8): the same tableau, tolerances and step-size controller
+            # family here; plans it has no kernel for (per-env parameters) use the Dormand-Prince pair of the same class
+            d_int = "tsit5" if self.nunc == 0 else "dopri5"
+        elif d_int == "rodas4" and self.nunc > 0:
             d_int = "dopri5"
         self.integrator = p.get("integrator", d_int)
-        if self.integrator not in ("rk4", "dopri5", "rodas3", "rodas4"):
-            raise ValueError("integrator must be 'rk4', 'dopri5', 'rodas3' or 'rodas4'")
+        if self.integrator not in ("rk4", "dopri5", "tsit5", "rodas3", "rodas4"):
+            raise ValueError("integrator must be 'rk4', 'dopri5', 'tsit5', 'rodas3' or 'rodas4'")
         epc = p.get("endpoint_control", True)
         self.ep_frac, self.ep_kmax = 0.0, 0
         if self.integrator == "rodas4" and epc is not False and epc is not None:
@@ -866,7 +870,7 @@ class EnvSpec:
         cfg = abi.pcg_env_cfg()
         cfg.model_id = self.model.model_id
         cfg.integrator_id = {"rk4": abi.PCG_INT_RK4, "dopri5": abi.PCG_INT_DOPRI5, "rodas3": abi.PCG_INT_RODAS3,
-                             "rodas4": abi.PCG_INT_RODAS4}[self.integrator]
+                             "rodas4": abi.PCG_INT_RODAS4, "tsit5": abi.PCG_INT_TSIT5}[self.integrator]
         cfg.ep_frac, cfg.ep_kmax = self.ep_frac, self.ep_kmax
         cfg.nx, cfg.na, cfg.ndm, cfg.nd = self.nx, self.na, self.ndm, self.nd
         cfg.nsp, cfg.ncon, cfg.nrew, cfg.N = self.nsp, self.ncon, self.nrew, self.N

@@ -58,7 +58,7 @@ constexpr bool ros_dense(int integ, bool structured) {
 }
 constexpr int tb(bool lds_stages, int integ, int nx = 0, bool structured = false) {
   return ros_dense(integ, structured) ? ros_threads(nx)
-         : (lds_stages || integ == PCG_INT_DOPRI5 || integ == PCG_INT_RODAS4) ? BLOCK_LDS : BLOCK;
+         : (lds_stages || integ == PCG_INT_DOPRI5 || integ == PCG_INT_RODAS4 || integ == PCG_INT_TSIT5) ? BLOCK_LDS : BLOCK;
 }
 // doubles of dynamic LDS the integrator itself needs per workgroup (the schedules follow them)
 constexpr size_t integ_lds_doubles(int nx, int integ, bool lds_stages, bool structured = false) {
@@ -68,7 +68,8 @@ constexpr size_t integ_lds_doubles(int nx, int integ, bool lds_stages, bool stru
 // when left alone (1 wave/SIMD, latency-bound: measured 14k cycles per attempted step against ~3.6k of
 // issue); capping it at 256 costs a few spills and doubles the resident waves.
 constexpr int wpe(int nx, int integ, bool lds_stages, bool structured = false) {
-  return ((integ == PCG_INT_DOPRI5 && !lds_stages && nx <= 10) || (integ == PCG_INT_RODAS4 && structured && nx <= 10)) ? 2 : 1;
+  return (((integ == PCG_INT_DOPRI5 || integ == PCG_INT_TSIT5) && !lds_stages && nx <= 10) ||
+          (integ == PCG_INT_RODAS4 && structured && nx <= 10)) ? 2 : 1;
 }
 constexpr int KNU = PCG_MAX_NA + PCG_MAX_NDM;                      // kernel-side u width
 constexpr int CON_W = PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + KNU; // padded constraint row
@@ -463,6 +464,14 @@ PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const do
     int nacc = 0, nrej = 0;
     const RosLds<NX> Lm(stage_l);
     status = rodas3<NX>(f, Lm, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    if (A.nsteps) {
+      A.nsteps[e] = nacc;
+      A.nsteps[A.B + e] = nrej;
+    }
+    poison_if_failed<NX>(status, x);
+  } else if (INTEG == PCG_INT_TSIT5) {
+    int nacc = 0, nrej = 0;
+    status = tsit5<NX>(f, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
     if (A.nsteps) {
       A.nsteps[e] = nacc;
       A.nsteps[A.B + e] = nrej;
@@ -1502,6 +1511,14 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX, ros_structured<M>::val
       nsteps[e] = nacc;
       nsteps[B + e] = nrej;
     }
+  } else if (INTEG == PCG_INT_TSIT5) {
+    int nacc = 0, nrej = 0;
+    const int status = tsit5<NX>(f, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+    poison_if_failed<NX>(status, x);
+    if (nsteps) {
+      nsteps[e] = nacc;
+      nsteps[B + e] = nrej;
+    }
   } else if (INTEG == PCG_INT_RODAS4) {
     int nacc = 0, nrej = 0, status;
     const EpWeights<M, typename M::CKP> ep{kp, u, c.ep_c, c.ep_kmax};
@@ -1618,6 +1635,10 @@ Kernels make_kernels() {
   k.step[PCG_INT_RODAS4][1][0][0] = k.step[PCG_INT_RODAS4][1][0][1] = step_kernel<M, PCG_INT_RODAS4, true, false, true>;
   k.integ[PCG_INT_RODAS4][0] = integrate_kernel<M, PCG_INT_RODAS4, false>;
   k.ros_structured = ros_structured<M>::value;
+  // Tsit5 (the reference's jax method): general kernel, both counter modes, and the integration hook
+  k.step[PCG_INT_TSIT5][0][0][0] = k.step[PCG_INT_TSIT5][0][0][1] = step_kernel<M, PCG_INT_TSIT5, false, false, true>;
+  k.step[PCG_INT_TSIT5][1][0][0] = k.step[PCG_INT_TSIT5][1][0][1] = step_kernel<M, PCG_INT_TSIT5, true, false, true>;
+  k.integ[PCG_INT_TSIT5][0] = k.integ[PCG_INT_TSIT5][1] = integrate_kernel<M, PCG_INT_TSIT5, false>;
   if constexpr (ros_structured<M>::value && !M::DYNAMIC) {
     k.queue_r4[0] = step_kernel_queue<M, false, true, PCG_INT_RODAS4>;
     k.queue_r4[1] = step_kernel_queue<M, true, true, PCG_INT_RODAS4>;
@@ -1668,6 +1689,7 @@ Kernels make_kernels() {
       k.step[PCG_INT_RK4][pe][1][ex] = k.step[PCG_INT_RK4][pe][0][ex];
       k.step[PCG_INT_RODAS3][pe][1][ex] = k.step[PCG_INT_RODAS3][pe][0][ex];
       k.step[PCG_INT_RODAS4][pe][1][ex] = k.step[PCG_INT_RODAS4][pe][0][ex];
+      k.step[PCG_INT_TSIT5][pe][1][ex] = k.step[PCG_INT_TSIT5][pe][0][ex];
       if (!k.step[PCG_INT_DOPRI5][pe][1][ex]) k.step[PCG_INT_DOPRI5][pe][1][ex] = k.step[PCG_INT_DOPRI5][pe][0][ex];
     }
   k.rollout[PCG_INT_RK4][1] = k.rollout[PCG_INT_RK4][0];

@@ -80,7 +80,7 @@ def collect_rollouts(env, policy=None, actions=None):
     obs, _ = env.reset()
     # the fused rollout records observations and rewards, not the constraint rows; per-env parameters need the
     # per-step kernel; the 20-state DOPRI5 rollout kernel is slower than stepping (tools/rollout_probe.py)
-    fused_ok = (not s.ncon and not s.nunc and (s.integrator not in ("rodas3", "rodas4") or (s.integrator == "rodas4" and s.model.name == "multistage_extraction"))
+    fused_ok = (not s.ncon and not s.nunc and (s.integrator not in ("rodas3", "rodas4", "tsit5") or (s.integrator == "rodas4" and s.model.name == "multistage_extraction"))
                 and s.user_rhs_src is None
                 and (s.integrator == "rk4" or s.nx <= 10))
     if actions is not None:

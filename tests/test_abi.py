@@ -31,7 +31,7 @@ def test_enums_match_header():
     assert int(ids["PCG_MODEL_CRYST"]) == M.CRYST and int(ids["PCG_MODEL_AFFINE"]) == M.AFFINE
     ints = dict(re.findall(r"(PCG_INT_[A-Z0-9]+) = (\d+)", HDR))
     assert int(ints["PCG_INT_RK4"]) == abi.PCG_INT_RK4 and int(ints["PCG_INT_DOPRI5"]) == abi.PCG_INT_DOPRI5
-    assert int(ints["PCG_INT_RODAS3"]) == abi.PCG_INT_RODAS3 and int(ints["PCG_INT_COUNT"]) == 4 and int(ints["PCG_INT_RODAS4"]) == abi.PCG_INT_RODAS4
+    assert int(ints["PCG_INT_RODAS3"]) == abi.PCG_INT_RODAS3 and int(ints["PCG_INT_COUNT"]) == 5 and int(ints["PCG_INT_RODAS4"]) == abi.PCG_INT_RODAS4 and int(ints["PCG_INT_TSIT5"]) == abi.PCG_INT_TSIT5
 
 
 def _struct_fields(name):

@@ -208,14 +208,14 @@ def test_integrator_selection():
     assert sm.integrator == "rodas4" and sm.rtol == 3e-8 and sm.atol == 3e-8 and (sm.ep_frac, sm.ep_kmax) == (0.5, 10)
     pj = P("me_canonical")
     pj["integration_method"] = "jax"                           # the reference's explicit 5(4) path keeps its semantic
-    assert EnvSpec(pj).integrator == "dopri5" and EnvSpec(pj).rtol == 1e-8 and EnvSpec(pj).ep_kmax == 0
+    assert EnvSpec(pj).integrator == "tsit5" and EnvSpec(pj).rtol == 1e-8 and EnvSpec(pj).ep_kmax == 0
     pu = P("me_canonical")
     pu.update(uncertainty_percentages={"Kla": 0.1}, uncertainty_bounds={"low": [4.0], "high": [6.0]})
     assert EnvSpec(pu).integrator == "dopri5"                  # per-env parameters: general explicit kernel
     p = P("cstr_canonical")
     p["integration_method"] = "jax"                            # reference's adaptive 5(4) path
     s = EnvSpec(p)
-    assert s.integrator == "dopri5" and s.rtol == 1e-8 and s.atol == 1e-8  # integrator.py:61
+    assert s.integrator == "tsit5" and s.rtol == 1e-8 and s.atol == 1e-8  # integrator.py:56-61: Tsit5, PID(1e-8, 1e-8)
     p["integration_method"] = "scipy"
     with pytest.raises(ValueError):
         EnvSpec(p)
@@ -229,6 +229,8 @@ def test_integrator_selection():
     p["integrator"] = "bdf"
     with pytest.raises(ValueError, match="rodas3"):
         EnvSpec(p)
+    p["integrator"] = "tsit5"
+    assert EnvSpec(p).to_cfg()[0].integrator_id == abi.PCG_INT_TSIT5
 
 
 def test_shape_errors():

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Condense the PMC passes of tools/prof_all.sh into one JSON (committed as profiles/r3/pmc.json, read by bench.py):
+per workload the dominant step kernel's mean counters per launch, HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE: the gfx950
+FETCH_SIZE correction of /opt/skills/guides/MI355X_MICROARCH.md "HBM"), and the VALU issue fraction
+4 SQ_INSTS_VALU / (1024 SIMDs x SQ_BUSY_CYCLES / 32).   usage: pmc_json.py <gpurun_out> <workload ...>"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root, wls = sys.argv[1], sys.argv[2:]
+SEG = {"Model<0>": "cstr", "Model<1>": "four_tank", "Model<2>": "multistage_extraction", "Model<18>": "multistage_extraction",
+       "Model<3>": "multistage_extraction_reactive", "Model<19>": "multistage_extraction_reactive", "Model<4>": "crystallization"}
+
+
+def counters(d):
+    agg = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = row["Kernel_Name"]
+                if "step_kernel" in k:
+                    agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"_n": len(next(iter(cs.values())))} for k, cs in agg.items()}
+
+
+def durations(d):
+    out = {}
+    for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                out[row["Name"]] = (int(row["Calls"]), float(row["AverageNs"]))
+    return out
+
+
+def entry(kname, c, dur, wl):
+    e = {"kernel": kname[:120], "launches_in_pmc_pass": c["_n"]}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        rd, wr = c["FETCH_SIZE"] * 1024 * 2.0, c["WRITE_SIZE"] * 1024
+        e.update(FETCH_SIZE_KiB=c["FETCH_SIZE"], WRITE_SIZE_KiB=c["WRITE_SIZE"], gfx950_fetch_correction=2.0,
+                 read_bytes=rd, write_bytes=wr, traffic_bytes_per_launch=rd + wr)
+    if "SQ_INSTS_VALU" in c:
+        e["SQ_INSTS_VALU_per_launch"] = c["SQ_INSTS_VALU"]
+        for k in ("SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
+            if k in c:
+                e[k + "_per_launch"] = c[k]
+    if "GRBM_GUI_ACTIVE" in c:
+        e["GRBM_GUI_ACTIVE_per_launch"] = c["GRBM_GUI_ACTIVE"]  # (includes dispatch overhead: not used as the cycle count)
+    if kname in dur:
+        e["rocprof_avg_us"] = dur[kname][1] / 1e3
+        e["rocprof_calls"] = dur[kname][0]
+    if "SQ_BUSY_CYCLES" in c and "SQ_INSTS_VALU" in c and c["SQ_BUSY_CYCLES"] > 0:
+        # SQ_BUSY_CYCLES is summed over the 32 shader engines (8 XCDs x 4): /32 = busy cycles of the launch -- calibrated
+        # against the kernel duration it gives 2.05-2.15 GHz on every workload.  A wave64 VALU instruction occupies its
+        # 16-lane SIMD for 4 cycles; 1024 SIMDs.
+        cyc = c["SQ_BUSY_CYCLES"] / 32.0
+        e["busy_cycles_per_launch"] = cyc
+        e["valu_issue_frac"] = 4.0 * c["SQ_INSTS_VALU"] / (1024.0 * cyc)
+        if kname in dur:
+            e["sq_clock_GHz"] = cyc / dur[kname][1]
+    e["source"] = (f"profiles/r3/{wl}/rocprofv3_summary.txt (tools/prof_all.sh: FETCH_SIZE, WRITE_SIZE, SQ and GRBM counters in "
+                   "separate --pmc passes with --kernel-trace only; FETCH_SIZE x 2 per MI355X_MICROARCH.md HBM section); NOT "
+                   "measured in the bench run itself")
+    return e
+
+
+res = {}
+for wl in wls:
+    d = os.path.join(root, "prof_" + wl)
+    cs, dur = counters(d), durations(d)
+    if not cs:
+        continue
+    if wl == "mixed":
+        segs = {}
+        for k, c in cs.items():
+            name = next((v for q, v in SEG.items() if q in k), None)
+            if name and (name not in segs or c["_n"] > segs[name]["launches_in_pmc_pass"]):
+                segs[name] = entry(k, c, dur, wl)
+        res[wl] = {"segments": segs}
+    else:
+        k = max(cs, key=lambda q: cs[q]["_n"])  # the kernel of (almost) every launch of the workload
+        res[wl] = entry(k, cs[k], dur, wl)
+print(json.dumps(res, indent=1))
