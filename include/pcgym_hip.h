@@ -190,8 +190,8 @@ enum pcg_integrator {
  *      [ x(0..nx) | SP slot (nsp_obs) | configured disturbances (nd) | uncertain parameters (nunc) ]
  *                                                                   Nobs = nx+nsp_obs+nd+nunc
  *      (reset order of the reference, pcgym.py:291-316; with disturbances AND parameter uncertainty the
- *      reference's step() writes the disturbance slots at a different offset -- quirk Q11 -- that
- *      combination is rejected)
+ *      reference's step() writes the disturbance slots at a different offset -- quirk Q11: this layout is
+ *      kept in step() too, see d_param_index)
  * and of the model input vector (pcgym.py:371,386-404):
  *      uk = [ action (na) | model disturbance inputs (ndm) ]            Nu = na+ndm
  */
@@ -282,6 +282,12 @@ typedef struct pcg_env_cfg {
   double ep_frac;         /* fraction of the model's contraction rate credited to the damping (0.5 by default: the cascade
                              is non-normal -- a perturbation travels down the stages before it decays)                 */
   int32_t ep_kmax;        /* largest exponent: tolerances are relaxed by at most 2^ep_kmax (10 by default, 0 = off)    */
+  /* Disturbances TOGETHER with per-env uncertain parameters (pcgym.py:291-316, 386-412; quirk Q11).  The state /
+   * observation layout is the reference's reset() order [x | SP | d | unc] in reset AND step (its step() writes the
+   * disturbance slots at another offset -- the one place where this engine deliberately does not follow it); a model
+   * disturbance input that is NOT configured takes the env's own (possibly uncertain) parameter value, as the
+   * reference's `self.model.info()["parameters"][k]` does (pcgym.py:400-404).  d_param_index names that parameter. */
+  const int32_t* d_param_index; /* [ndm] or NULL: index in `params` of each model disturbance input                  */
 } pcg_env_cfg;
 
 /*

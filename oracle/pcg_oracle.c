@@ -1222,7 +1222,8 @@ static void env_step(const pcg_env_cfg* c, orc_env* e, const double* action_in, 
   /* disturbances :386-412 */
   for (int i = 0; i < na; ++i) uk[i] = action[i];
   if (ndm > 0) {
-    for (int j = 0; j < ndm; ++j) uk[na + j] = c->d_default[j]; /* :400-404 */
+    for (int j = 0; j < ndm; ++j) /* :400-404 -- the env's own parameter value when parameters are uncertain (Q11) */
+      uk[na + j] = (c->nunc > 0 && c->d_param_index) ? params[c->d_param_index[j]] : c->d_default[j];
     for (int k = 0; k < nd; ++k) {
       double v;
       if (d_env) v = d_env[k];

@@ -128,6 +128,7 @@ class pcg_env_cfg(C.Structure):
         ("user_rhs_src", C.c_char_p),
         ("ep_frac", C.c_double),
         ("ep_kmax", C.c_int32),
+        ("d_param_index", _pi),
     ]
 
 

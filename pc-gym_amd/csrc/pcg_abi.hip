@@ -199,7 +199,7 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   const int nunc = c->nunc;
   if (nunc < 0 || nunc > PCG_MAX_NUNC) return PCG_E_DIM;
   if (nunc > 0 && (k.dynamic || !c->unc_index || !c->unc_pct)) return nunc > 0 && k.dynamic ? PCG_E_UNSUPPORTED : PCG_E_NULL;
-  if (nunc > 0 && nd > 0) return PCG_E_UNSUPPORTED;  // quirk Q11: the reference's slot layout is inconsistent there
+  if (nunc > 0 && ndm > 0 && !c->d_param_index) return PCG_E_NULL;  // Q11: which parameter an unconfigured input reads
   if (nso != 0 && nso != nsp) return PCG_E_DIM;
   if (nd > 0 && nso != nsp) return PCG_E_UNSUPPORTED;
   if (nrew < 0 || nrew > PCG_MAX_NX) return PCG_E_DIM;

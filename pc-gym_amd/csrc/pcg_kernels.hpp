@@ -786,9 +786,14 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
     typename M::KP kpl;
     double dd[PCG_MAX_NDM] = {0.0, 0.0, 0.0, 0.0};
     M::prep(raw, NX, NA, reinterpret_cast<double*>(&kpl), dd);
-    if (c.ndm == 0) {  // unconfigured disturbance inputs take the (possibly uncertain) model parameters
+    // unconfigured disturbance inputs take the env's own (possibly uncertain) model parameters (pcgym.py:400-404);
+    // configured ones keep their schedule value (quirk Q11: layout [x | SP | d | unc] in reset and step)
 #pragma unroll
-      for (int j = 0; j < NDM; ++j) pre.u[NA + j] = dd[j];
+    for (int j = 0; j < NDM; ++j) {
+      bool configured = false;
+#pragma unroll
+      for (int k = 0; k < NDM; ++k) configured = configured || (k < c.nd && c.ndm != 0 && c.d_slot[k] == j);
+      if (!configured) pre.u[NA + j] = dd[j];
     }
     status = integrate_env<M, INTEG, LDS_STAGES>(A, c, kpl, pre.u, x, stage_l, e, nx);
   } else {

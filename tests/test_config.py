@@ -299,8 +299,12 @@ def test_parameter_uncertainty_parsing():
     assert s2.nunc == 1 and s2.x0_unc is not None and not s2.x0_normal or True
     p3 = P("cstr_dist_Ti")
     p3.update(uncertainty_percentages={"UA": 0.1}, uncertainty_bounds={"low": np.array([4e4]), "high": np.array([6e4])})
-    with pytest.raises(ValueError, match="disturbances together with parameter uncertainty"):
-        EnvSpec(p3)
+    s3 = EnvSpec(p3)  # quirk Q11: supported since round 3 with the reset layout [x | SP | d | unc] in reset and step
+    cfg3, _k3 = s3.to_cfg()
+    assert s3.nunc == 1 and s3.nd == 1 and s3.nobs == 2 + 1 + 1 + 1 and list(s3.d_param_index) == [8, 9]
+    assert _lib.load().pcg_cfg_validate(C.byref(cfg3)) == 0
+    cfg3.d_param_index = None
+    assert _lib.load().pcg_cfg_validate(C.byref(cfg3)) == abi.PCG_E_NULL
 
 
 def test_empirical_distribution_parsing_and_oracle_sampling():
