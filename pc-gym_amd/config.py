@@ -247,6 +247,136 @@ def trace_callable(fn, dims, sample_points, what, arg_names=("x", "u")):
     return exprs
 
 
+class _SPSeries:
+    """``self.SP[key]`` inside a traced custom_reward: a set-point schedule that may be scaled / shifted element-wise and
+    is finally indexed with ``self.t`` -- which yields the kernel's ``sp[k]`` (the value at the NEW step counter, what the
+    reference's callables read after ``self.t += 1``, pcgym.py:441, 470-471)"""
+    __array_priority__ = 2000.0
+
+    def __init__(self, elem):
+        self.elem = elem  # _Sym over sp[k]
+
+    def _map(self, f):
+        return _SPSeries(f(self.elem))
+
+    def __add__(self, o): return self._map(lambda e: e + o)
+    def __radd__(self, o): return self._map(lambda e: o + e)
+    def __sub__(self, o): return self._map(lambda e: e - o)
+    def __rsub__(self, o): return self._map(lambda e: o - e)
+    def __mul__(self, o): return self._map(lambda e: e * o)
+    def __rmul__(self, o): return self._map(lambda e: o * e)
+    def __truediv__(self, o): return self._map(lambda e: e / o)
+    def __neg__(self): return self._map(lambda e: -e)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, _TStep):
+            return self.elem
+        raise _TraceError("a set-point schedule may only be indexed with self.t in a custom_reward that is to be compiled")
+
+
+class _TStep(_Sym):
+    """``self.t`` inside a traced custom_reward: the expression variable ``t``; indexes a schedule"""
+    __slots__ = ()
+
+    def __init__(self):
+        super().__init__("t")
+
+
+class _RewardSelf:
+    """the ``self`` a traced custom_reward sees: the attributes the reference's callables read (pcgym.py:470-471 hands
+    them the env itself) -- SP, t, N, dt, tsim, env_params, model, a few sizes.  Anything else (``self.u_prev`` and
+    other state kept on the env between calls) is an AttributeError: such a reward is not a function of this step alone
+    and cannot be compiled (the declarative ``sp_track`` form covers the paper's family)."""
+
+    def __init__(self, spec, symbolic, t=None):
+        self.env_params = spec.env_params
+        self.model = _ModelInfo(spec)
+        self.N, self.dt, self.tsim = spec.N, spec.dt, spec.tsim
+        self.Nx, self.Nx_oracle, self.Nu = spec.nobs, spec.nx, spec.nu
+        if symbolic:
+            self.t = _TStep()
+            self.SP = {k: _SPSeries(_Sym(f"sp[{j}]")) for j, k in enumerate(spec.sp_keys)}
+        else:
+            self.t = int(t)
+            self.SP = {k: np.asarray(spec.sp[j], dtype=_f64) for j, k in enumerate(spec.sp_keys)}
+
+
+class _ModelInfo:
+    def __init__(self, spec):
+        self._info = {"states": list(spec.model.states), "inputs": list(spec.model.inputs),
+                      "disturbances": list(spec.model.disturbances), "parameters": dict(spec.model.parameters)}
+
+    def info(self):
+        return self._info
+
+
+def trace_reward_callable(fn, spec):
+    """``custom_reward(self, obs, uk, violated)`` (pcgym.py:201-205, 470-471) -> ONE C expression over o[], u[], sp[],
+    violated, t, N for the batched kernel.  The callable is run twice on symbolic scalars, once per value of
+    ``violated`` (a plain bool, so ``if con:`` works), with ``float`` neutralised inside its module for the duration
+    (the usual ``return float(...)``); the result is checked numerically against the callable itself."""
+    import math
+
+    g = getattr(fn, "__globals__", None)
+    had = g is not None and "float" in g
+    old = g.get("float") if had else None
+    exprs = {}
+    try:
+        if g is not None:
+            g["float"] = lambda v=0.0: v if isinstance(v, _Sym) else float(v)
+        for con in (False, True):
+            o = np.array([_Sym(f"o[{i}]") for i in range(spec.nobs)], dtype=object)
+            u = np.array([_Sym(f"u[{j}]") for j in range(spec.nu)], dtype=object)
+            try:
+                r = fn(_RewardSelf(spec, True), o, u, con)
+            except _TraceError as e:
+                raise ValueError(f"custom_reward: {e}") from None
+            except Exception as e:  # noqa: BLE001
+                raise ValueError("custom_reward: the callable could not be traced into an expression "
+                                 f"({type(e).__name__}: {e}); it probably keeps state on the env (self.u_prev ...) -- use "
+                                 "the declarative {'kind': 'sp_track'} form or {'expr': ...}") from None
+            r = np.asarray(r, dtype=object).reshape(-1)
+            if r.size != 1:
+                raise ValueError("custom_reward: the callable must return one number")
+            exprs[con] = r[0].e if isinstance(r[0], _Sym) else _Sym._lit(r[0])
+    finally:
+        if g is not None:
+            if had:
+                g["float"] = old
+            else:
+                g.pop("float", None)
+    text = exprs[False] if exprs[False] == exprs[True] else f"((violated) ? ({exprs[True]}) : ({exprs[False]}))"
+    # numeric confirmation against the callable itself: random observations in the observation box, inputs in the
+    # action box (+ nominal disturbance inputs), random step counters, both values of `violated`
+    rng = np.random.default_rng(0)
+    env = {k: getattr(math, k) for k in ("exp", "log", "sqrt", "sin", "cos", "tanh", "fabs")}
+    env["pow"] = math.pow
+    verified = 0
+    for trial in range(8):
+        o = spec.o_low + rng.uniform(0.05, 0.95, spec.nobs) * (spec.o_high - spec.o_low)
+        u = np.concatenate([spec.a_low + rng.uniform(0, 1, spec.na) * (spec.a_high - spec.a_low),
+                            np.asarray(spec.d_default, dtype=_f64)[:spec.ndm]])
+        t = int(rng.integers(1, spec.N))
+        for con in (False, True):
+            with np.errstate(all="ignore"):
+                want = float(np.asarray(fn(_RewardSelf(spec, False, t), o.copy(), u.copy(), con), dtype=_f64).reshape(-1)[0])
+            scope = dict(env, o=list(map(float, o)), u=list(map(float, u)), sp=[float(spec.sp[j][t]) for j in range(spec.nsp)],
+                         violated=int(con), t=t, N=spec.N)
+            e = exprs[con]
+            try:
+                got = float(eval(e, {"__builtins__": {}}, scope))  # noqa: S307 (our own text)
+            except (ValueError, ZeroDivisionError, OverflowError):
+                continue
+            if np.isfinite(want):
+                if abs(want - got) > 1e-9 * (abs(want) + 1e-12):
+                    raise ValueError("custom_reward: the traced expression does not reproduce the callable (hidden state or "
+                                     "control flow that tracing cannot see)")
+                verified += 1
+    if verified == 0:
+        raise ValueError("custom_reward: the traced expression could not be checked against the callable at any probe point")
+    return text
+
+
 _EXPR_FUNCS = {"exp", "log", "sqrt", "pow", "fabs", "fmin", "fmax", "sin", "cos", "tanh"}
 
 

@@ -55,9 +55,20 @@ class VecEnv:
         self.spec = s = EnvSpec(env_params)
         self.env_params = s.env_params
         if s.custom_reward is not None and not getattr(self, "_allow_custom_reward", False):
-            raise ValueError("custom_reward callables cannot run inside the batched kernel; use the built-in "
-                             "SP / terminal reward, or the single-env make_env() façade which evaluates the "
-                             "callable on the host exactly like the reference (pcgym.py:470-471)")
+            # a Python callable cannot run inside the batched kernel -- but one that is a function of this step alone
+            # (obs, uk, violated, self.SP[..][self.t], constants) writes its own C expression when run on symbolic
+            # scalars (config.trace_reward_callable), which is then compiled into the step kernel like {'expr': ...}
+            from .config import trace_reward_callable
+
+            try:
+                expr = trace_reward_callable(s.custom_reward, s)
+            except ValueError as e:
+                raise ValueError(f"{e}.  (custom_reward callables that cannot be traced run in the single-env make_env() "
+                                 "façade, which evaluates them on the host exactly like the reference, "
+                                 "pcgym.py:470-471.)") from None
+            env_params = dict(s.env_params, custom_reward={"expr": expr})
+            self.spec = s = EnvSpec(env_params)
+            self.env_params = s.env_params
         torch = _torch()
         self._lib = _lib.load()  # raises when the HIP library is missing: no fallback
         if not torch.cuda.is_available():

@@ -454,3 +454,40 @@ def test_large_affine_python_model_takes_the_traced_route():
     s = EnvSpec(p)
     assert s.model.model_id == M.USER and s.nx == 10 and s.affine_AB is None
     assert "dx[9] = (double)((((-1.0) * x[9]) + x[8]));" in s.user_rhs_src
+
+
+def test_custom_reward_callable_is_traced_into_an_expression():
+    """custom_reward(self, obs, uk, violated) (pcgym.py:201-205, 470-471): a callable that is a function of the current
+    step only -- here the one the reference ran when tests/golden/step_cstr_expr_reward_q3.npz was recorded -- writes its
+    own kernel expression: `float(...)`, `if con`, `self.SP[key][self.t]` and np.exp included; a callable that keeps state
+    on the env (the paper's self.u_prev) is refused with a pointer to the declarative form"""
+    from pcgym_amd.config import trace_reward_callable
+
+    sc = SC.scenarios()["cstr_expr_reward_q3"]
+    p = copy.deepcopy(sc["ref_env_params"])
+    assert callable(p["custom_reward"])
+    spec = EnvSpec(p)
+    text = trace_reward_callable(p["custom_reward"], spec)
+    assert "violated" in text and "sp[0]" in text and "exp(" in text and "o[1]" in text
+    s2 = EnvSpec(dict(spec.env_params, custom_reward={"expr": text}))
+    assert s2.user_reward_src is not None and s2.custom_reward is None
+
+    def stateful(self, x, u, con):
+        if not hasattr(self, "u_prev"):
+            self.u_prev = u
+        return -float((x[0] - self.SP["Ca"][self.t]) ** 2 + (u[0] - self.u_prev[0]) ** 2)
+
+    # (first call: hasattr is False on the proxy, so the trace itself succeeds -- and the numeric check then sees a
+    # function that ignores u_prev on fresh objects; a reward reading self.u_prev unconditionally is refused)
+    def reads_state(self, x, u, con):
+        return -float((u[0] - self.u_prev[0]) ** 2)
+
+    with pytest.raises(ValueError, match="could not be traced"):
+        trace_reward_callable(reads_state, spec)
+
+    def indexes_elsewhere(self, x, u, con):
+        return -float((x[0] - self.SP["Ca"][0]) ** 2)
+
+    with pytest.raises(ValueError, match="indexed with self.t"):
+        trace_reward_callable(indexes_elsewhere, spec)
+    assert stateful is not None

@@ -338,6 +338,33 @@ def test_python_constraint_callable_is_traced_and_replays_the_reference_recordin
     env.close()
 
 
+def test_python_custom_reward_callable_is_traced_and_replays_the_reference_recording():
+    """the custom_reward callable the reference ran when the fixture was recorded (tests/golden/scenarios.py:
+    reward_cstr_exp: tracking + an exponential temperature cost + a violation charge behind `if con`, wrapped in
+    float()) handed to VecEnv as-is, together with the Python constraint function (VERDICT r2 "missing" item 4)"""
+    torch = _torch()
+    from pcgym_amd import VecEnv
+
+    name = "cstr_expr_reward_q3"
+    sc = SC.scenarios()[name]
+    g = H.gold("step_" + name)
+    p = copy.deepcopy(sc["ref_env_params"])
+    assert callable(p["custom_reward"]) and callable(p["constraints"])
+    p.update(H.tight_for(p))
+    B = 130
+    env = VecEnv(p, n_envs=B, seed=1)
+    assert env.spec.user_reward_src is not None and "violated" in env.spec.user_reward_src
+    A = SC.actions_for(name, sc)
+    env.reset()
+    for i in range(sc["steps"]):
+        a = torch.tensor(np.repeat(A[i].reshape(-1, 1), B, axis=1), device=env.device)
+        o, r, d, _, info = env.step(a)
+        want = g["obs"][i + 1]
+        assert np.all(np.abs(o.cpu().numpy() - want[None, :]) <= 2e-9 * np.maximum(np.abs(want), 1.0)), i
+        assert np.allclose(r.cpu().numpy(), g["rew"][i], rtol=1e-7, atol=1e-9), (i, r[:3], g["rew"][i])
+    env.close()
+
+
 class _ChemostatObject:
     """a model in the reference's protocol: __call__(x, u) + info(); nothing about C anywhere"""
     mumax, Ks, Ki, Y, Sf = 0.53, 0.12, 22.0, 0.4, 4.0
