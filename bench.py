@@ -11,6 +11,8 @@ N-1 steps long and the reset that ends each episode is inside the timed region (
 launch, pcg_step_autoreset).  value = total env-steps / wall time (max over ranks), whole job.
 
 --workload selects the other BASELINE configurations (parity-test cases made measurable; not the headline):
+  cstr_safe  the headline's envs / dt / actions under the model's DEFAULT plan (guarded RK4 with adaptive fallback) on the
+             full x0 box U(0.7,1.0) x U(310,350) K of SURVEY.md section 8(d) -- reported beside the headline, not as it
   four_tank  four_tank B = 2^20, RK4 x5 per dt = 1000/60 (the model's default: the smallest count inside 1e-6 on this box)
   me10       configs[2]: multistage_extraction (10 states) B = 262,144, adaptive DOPRI5 rtol = atol = 1e-8, dt = 1,
              (L, G) per env over the FULL action box [5,10]..[500,1000], x0 = doc ICs x (1 + 0.05 U(-1,1))
@@ -127,6 +129,14 @@ def single_workload(name):
     S = SC.scenarios()
     if name == "cstr":
         return "cstr_b2^20_rk4_fp64", workload_params(), 1 << 20, (5900, 590), 64
+    if name == "cstr_safe":
+        # the headline's envs, dt and actions under the model's DEFAULT plan (guarded RK4, adaptive fallback for the envs
+        # the guard refuses) on SURVEY.md section 8(d)'s full x0 box U(0.7,1.0) x U(310,350) K -- a third of which ignites,
+        # which is why the headline itself (plain RK4 x 1, BASELINE configs[1]) draws T0 below 334 K
+        p = workload_params()
+        del p["integrator"], p["substeps"]
+        p.update(x0=np.array([0.85, 330.0, 0.85]), uncertainty_percentages={"x0": [0.15 / 0.85, 20.0 / 330.0]})
+        return "cstr_b2^20_default-plan(rk4g)_full-x0-box_fp64", p, 1 << 20, (1180, 118), 64
     if name == "four_tank":
         return "four_tank_b2^20_rk4x5_fp64", copy.deepcopy(S["four_tank_canonical"]["env_params"]), 1 << 20, (1180, 118), 16
     if name == "me10_ros4":
@@ -330,7 +340,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cstr", choices=["cstr", "four_tank", "me10", "me10_ros4", "me20", "cryst", "mixed"])
+    ap.add_argument("--workload", default="cstr", choices=["cstr", "cstr_safe", "four_tank", "me10", "me10_ros4", "me20", "cryst", "mixed"])
     ap.add_argument("--batch", type=int, default=None, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=None, help="fixed OpenMP team of the cpu_baseline leg (default min(16, avail))")

@@ -144,7 +144,15 @@ enum pcg_integrator {
                           PIDController(rtol = atol = 1e-8)); controller, norm, initial step and failure semantics of
                           PCG_INT_DOPRI5.  General kernel (both counter modes), pcg_step_autoreset, pcg_graph_*,
                           pcg_integrate; pcg_rollout and per-env uncertain parameters: PCG_E_UNSUPPORTED */
-  PCG_INT_COUNT = 5
+  PCG_INT_RK4G = 5,    /* GUARDED RK4: `substeps` equal RK4 sub-steps, accepted per env only while the model's guard says the
+                          fixed step is accurate -- no growing mode (largest growth rate g <= 0) and a resolved fastest
+                          rate (rho h <= 1) at every sub-step start and at the end state, finite result; an env that
+                          fails the guard is re-integrated from its start state by PCG_INT_DOPRI5 at rtol / atol inside
+                          the same launch (nsteps reports (0,0) for accepted envs, the pair's counts otherwise).  Models
+                          with a guard hook only (cstr: the ignition branch; the default plan of that model).  General
+                          kernel, pcg_step_autoreset, pcg_graph_*, pcg_integrate, pcg_rollout; not with per-env uncertain
+                          parameters */
+  PCG_INT_COUNT = 6
 };
 
 /* cfg.flags */

@@ -434,6 +434,53 @@ static void rk4(const orc_model* m, double* x, const double* u, double dt, int n
   }
 }
 
+/* Guard of the fixed-step plan of the cstr (PCG_INT_RK4G; twin of Model<PCG_MODEL_CSTR>::guard): growth rate of the thermal
+ * feedback g = d(dT/dt)/dT and a bound rho of the fastest rate, from model_classes.py:45-62's terms. */
+static int guard_ok(const orc_model* m, const double* x, double h, int* calm, int* slow) {
+  if (m->model_id != PCG_MODEL_CSTR) { *calm = 0; return 0; }
+  const double* p = m->p;
+  double q = p[0], V = p[1], rho_ = p[2], C = p[3], deltaHr = p[4], EA_over_R = p[5], k0 = p[6], UA = p[7];
+  double ca = x[0], T = x[1];
+  double kk = k0 * exp(-EA_over_R / T);
+  double fb = ((-deltaHr) * (1 / (rho_ * C))) * (kk * ca) * (EA_over_R / (T * T));
+  double base = q / V + UA * (1 / (rho_ * C * V));
+  double g = fb - base, rr = kk + fb + base;
+  if (!(g <= 0.0)) *calm = 0;                      /* growth, or NaN */
+  if (!(rr * h <= 1.0 || !(rr == rr))) *slow = 0;  /* unresolved fastest rate */
+  return 1;
+}
+static int dopri5(const orc_model* m, double* x, const double* u, double dt, double rtol, double atol, int max_steps,
+                  int32_t* nacc, int32_t* nrej);
+/* guarded RK4: rk4() while the guard holds at every sub-step start and at the end state; otherwise the adaptive pair from
+ * the start state -- at the plan's tolerance when a growing mode was seen, at 1e-7 when only the fastest rate is unresolved
+ * (contracting stiff state: local errors do not grow).  Twin of the PCG_INT_RK4G branch of integrate_env in pcg_kernels.hpp */
+static int rk4g(const orc_model* m, double* x, const double* u, double dt, int nsub, double rtol, double atol, int max_steps,
+                int32_t* nacc, int32_t* nrej) {
+  int nx = m->nx;
+  double h = dt / nsub;
+  double x0[PCG_MAX_NX], k1[PCG_MAX_NX], k2[PCG_MAX_NX], k3[PCG_MAX_NX], k4[PCG_MAX_NX], y[PCG_MAX_NX];
+  int calm = 1, slow = 1;
+  for (int i = 0; i < nx; ++i) x0[i] = x[i];
+  for (int s = 0; s <= nsub; ++s) {
+    guard_ok(m, x, h, &calm, &slow);
+    if (s == nsub) break;
+    rhs_int(m, x, u, k1);
+    for (int i = 0; i < nx; ++i) y[i] = x[i] + 0.5 * h * k1[i];
+    rhs_int(m, y, u, k2);
+    for (int i = 0; i < nx; ++i) y[i] = x[i] + 0.5 * h * k2[i];
+    rhs_int(m, y, u, k3);
+    for (int i = 0; i < nx; ++i) y[i] = x[i] + h * k3[i];
+    rhs_int(m, y, u, k4);
+    for (int i = 0; i < nx; ++i) x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+  }
+  if (nacc) *nacc = 0;
+  if (nrej) *nrej = 0;
+  if (calm && slow) return 0;
+  for (int i = 0; i < nx; ++i) x[i] = x0[i];
+  if (calm) { rtol = fmax(rtol, 1e-7); atol = fmax(atol, 1e-7); }
+  return dopri5(m, x, u, dt, rtol, atol, max_steps, nacc, nrej);
+}
+
 /* Dormand & Prince (1980) 5(4) pair, FSAL.  Controller = the spec in DESIGN.md
  * "adaptive stepping": RMS error norm over scale = atol + rtol*max(|y|,|ynew|),
  * accept iff E < 1, factor = clip(0.9*E^-1/5, 0.2, 10) (<=1 right after a
@@ -1252,6 +1299,8 @@ static void env_step(const pcg_env_cfg* c, orc_env* e, const double* action_in, 
   if (c->integrator_id == PCG_INT_RK4) rk4(&m, e->state, uk, c->dt, c->substeps);
   else if (c->integrator_id == PCG_INT_RODAS3)
     ist = rodas3(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
+  else if (c->integrator_id == PCG_INT_RK4G)
+    ist = rk4g(&m, e->state, uk, c->dt, c->substeps, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
   else if (c->integrator_id == PCG_INT_TSIT5)
     ist = tsit5(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
   else if (c->integrator_id == PCG_INT_RODAS4)
@@ -1409,6 +1458,7 @@ ORC_EXPORT int orc_integrate(const pcg_env_cfg* c, int64_t B, double* x, const d
     for (int i = 0; i < nu; ++i) ui[i] = u[(size_t)i * B + b];
     if (c->integrator_id == PCG_INT_RK4) rk4(&m, xi, ui, c->dt, c->substeps);
     else if (c->integrator_id == PCG_INT_RODAS3) rodas3(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, &na_, &nr_);
+    else if (c->integrator_id == PCG_INT_RK4G) rk4g(&m, xi, ui, c->dt, c->substeps, c->rtol, c->atol, c->max_steps, &na_, &nr_);
     else if (c->integrator_id == PCG_INT_TSIT5) tsit5(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, &na_, &nr_);
     else if (c->integrator_id == PCG_INT_RODAS4)
       rodas4(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, &na_, &nr_);

@@ -44,6 +44,7 @@ PCG_INT_DOPRI5 = 1
 PCG_INT_RODAS3 = 2
 PCG_INT_RODAS4 = 3
 PCG_INT_TSIT5 = 4
+PCG_INT_RK4G = 5
 
 PCG_F_NORMALISE_A = 0x0001
 PCG_F_NORMALISE_O = 0x0002

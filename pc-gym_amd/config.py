@@ -7,7 +7,7 @@ Mirrors the parsing done by the reference ``make_env.__init__`` and its
 C ABI.  Nothing numeric about the hot path happens here.
 
 New optional keys (do not exist in the reference):
-  integrator   'rk4' | 'dopri5' | 'tsit5' | 'rodas3' | 'rodas4' (stiff-capable Rosenbrock pairs)   (default per model,
+  integrator   'rk4' | 'rk4g' (guarded RK4 with adaptive fallback, cstr) | 'dopri5' | 'tsit5' | 'rodas3' | 'rodas4' (stiff-capable Rosenbrock pairs)   (default per model,
                see DEFAULT_INTEGRATOR; integration_method='jax' -> 'tsit5', the reference's own method, integrator.py:56-61)
   endpoint_control  rodas4 only: {'frac': 0.5, 'kmax': 10} | False -- end-point error control (pcgym_hip.h,
                PCG_INT_RODAS4); on by default, acts only on models with a contraction-rate hook (extraction cascades)
@@ -40,7 +40,10 @@ DEFAULT_INTEGRATOR = {
     # (o_space T up to 350 K, cstr_train.py:12-47); on that branch |lambda| dt >> 2.78 and fixed-step RK4 returns
     # finite garbage, while the reference's CVODES integrates it.  integrator='rk4' stays available as an explicit
     # opt-in for the canonical closed loop (T < 330 K), where 4 sub-steps reach 6e-8.
-    M.CSTR: "dopri5",
+    # Round 3: 'rk4g' -- RK4 x 5 under the model's guard (no growing mode, resolved fastest rate, at every sub-step start
+    # and at the end state); an env that trips it is re-integrated by the adaptive pair at 1e-10 inside the same launch.
+    # The canonical closed loop never trips it (128 -> ~37 us per 2^20-env step); the ignition and hot branches always do.
+    M.CSTR: "rk4g",
     M.FOUR_TANK: "rk4",
     # stiff at high L,G (|lambda| dt up to ~240).  Round 3: the fourth-order Rosenbrock pair with the cascade's
     # structured linear algebra and end-point error control -- what the reference does with CVODES BDF
@@ -824,11 +827,13 @@ class EnvSpec:
             # diffrax.Tsit5 + PIDController(rtol = atol = 1e-8): the same tableau, tolerances and step-size controller
             # family here; plans it has no kernel for (per-env parameters) use the Dormand-Prince pair of the same class
             d_int = "tsit5" if self.nunc == 0 else "dopri5"
-        elif d_int == "rodas4" and self.nunc > 0:
+        elif d_int in ("rodas4", "rk4g") and self.nunc > 0:
             d_int = "dopri5"
         self.integrator = p.get("integrator", d_int)
-        if self.integrator not in ("rk4", "dopri5", "tsit5", "rodas3", "rodas4"):
-            raise ValueError("integrator must be 'rk4', 'dopri5', 'tsit5', 'rodas3' or 'rodas4'")
+        if self.integrator not in ("rk4", "rk4g", "dopri5", "tsit5", "rodas3", "rodas4"):
+            raise ValueError("integrator must be 'rk4', 'rk4g', 'dopri5', 'tsit5', 'rodas3' or 'rodas4'")
+        if self.integrator == "rk4g" and self.model.model_id != M.CSTR:
+            raise ValueError("integrator 'rk4g' (guarded RK4) needs a model with a guard hook: cstr")
         epc = p.get("endpoint_control", True)
         self.ep_frac, self.ep_kmax = 0.0, 0
         if self.integrator == "rodas4" and epc is not False and epc is not None:
@@ -837,6 +842,8 @@ class EnvSpec:
             if not (0.0 <= self.ep_frac <= 1.0) or not (0 <= self.ep_kmax <= 40):
                 raise ValueError("endpoint_control: frac must lie in [0, 1] and kmax in [0, 40]")
         d_sub = default_substeps(self.model.model_id, self.dt)
+        if self.integrator == "rk4g":  # the guard's calibration: 5 sub-steps per canonical dt = 26/60 (h <= 0.0867)
+            d_sub = max(1, int(np.ceil(self.dt / (26.0 / 60.0 / 5) - 1e-9)))
         if self.affine_AB is not None:
             # affine models: keep |A|_inf * h <= 0.05 (RK4 local error ~ (|A| h)^5 / 120)
             d_sub = max(8, int(np.ceil(self.dt * np.abs(self.affine_AB[0]).sum(axis=1).max() / 0.05)))
@@ -1004,7 +1011,7 @@ class EnvSpec:
         cfg = abi.pcg_env_cfg()
         cfg.model_id = self.model.model_id
         cfg.integrator_id = {"rk4": abi.PCG_INT_RK4, "dopri5": abi.PCG_INT_DOPRI5, "rodas3": abi.PCG_INT_RODAS3,
-                             "rodas4": abi.PCG_INT_RODAS4, "tsit5": abi.PCG_INT_TSIT5}[self.integrator]
+                             "rodas4": abi.PCG_INT_RODAS4, "tsit5": abi.PCG_INT_TSIT5, "rk4g": abi.PCG_INT_RK4G}[self.integrator]
         cfg.ep_frac, cfg.ep_kmax = self.ep_frac, self.ep_kmax
         cfg.nx, cfg.na, cfg.ndm, cfg.nd = self.nx, self.na, self.ndm, self.nd
         cfg.nsp, cfg.ncon, cfg.nrew, cfg.N = self.nsp, self.ncon, self.nrew, self.N

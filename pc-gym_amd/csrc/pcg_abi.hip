@@ -206,6 +206,8 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   if (c->N < 2 || c->N > PCG_MAX_N) return PCG_E_DIM;
   if (!(c->dt > 0.0) || !std::isfinite(c->dt)) return PCG_E_VALUE;
   if (c->integrator_id == PCG_INT_RK4 && c->substeps < 0) return PCG_E_VALUE;  // 0 = no integration (I/O probe)
+  if (c->integrator_id == PCG_INT_RK4G && (c->substeps < 1 || !k.step[PCG_INT_RK4G][0][0][0] || c->nunc > 0))
+    return c->substeps < 1 ? PCG_E_VALUE : PCG_E_UNSUPPORTED;  // models with a guard hook only
   if (c->integrator_id != PCG_INT_RK4 && (!(c->rtol > 0) || !(c->atol >= 0) || c->max_steps < 1))
     return PCG_E_VALUE;
   const int nobs = nx + nso + nd + nunc, cnu = na + ndm;

@@ -49,6 +49,54 @@ PCG_DEV void rk4(const F& f, R (&x)[NX], double h, int nsub) {
   }
 }
 
+template <class M, class = void>
+struct has_guard : tt::false_type {};
+template <class M>
+struct has_guard<M, tt::void_t<decltype(M::GUARD)>> : tt::true_type {};
+
+// RK4 with the model's guard (PCG_INT_RK4G): the same arithmetic as rk4(); returns 0 when the guard holds at every
+// sub-step start and at the end state, 2 when a growing mode was seen (g > 0, or a non-finite value: errors amplify, the
+// fallback needs the plan's tight tolerance), 1 when only the fastest rate is unresolved (rho h > 1 with g <= 0 throughout:
+// a contracting, stiff state -- the hot branch of the cstr -- where local errors do not grow and the fallback runs at
+// GUARD_LOOSE_TOL).
+constexpr double GUARD_LOOSE_TOL = 1e-7;
+template <class M, class K, class F>
+PCG_DEV int rk4_guarded(const F& f, const K& kp, const typename M::Hold& hold, double (&x)[M::NX], double h, int nsub) {
+  constexpr int NX = M::NX;
+  double k[NX], acc[NX], y[NX];
+  const double h2 = 0.5 * h, h6 = h / 6.0;
+  bool calm = true, slow = true;
+  for (int s = 0; s <= nsub; ++s) {
+    double g, rho;
+    if (s == nsub) M::guard(kp, hold, x, g, rho);
+    else M::rhs_guard(kp, hold, x, k, g, rho);  // k1 and the guard share the Arrhenius factor
+    calm = calm && (g <= 0.0);  // (NaN compares false: counts as growth)
+    slow = slow && (rho * h <= 1.0 || !(rho == rho));
+    if (s == nsub) break;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      acc[i] = k[i];
+      y[i] = x[i] + h2 * k[i];
+    }
+    f(y, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      acc[i] = acc[i] + 2.0 * k[i];
+      y[i] = x[i] + h2 * k[i];
+    }
+    f(y, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      acc[i] = acc[i] + 2.0 * k[i];
+      y[i] = x[i] + h * k[i];
+    }
+    f(y, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = x[i] + h6 * (acc[i] + k[i]);
+  }
+  return !calm ? 2 : (slow ? 0 : 1);
+}
+
 // ---- stage storage policies -------------------------------------------------
 template <int NX>
 struct RegStages {

@@ -469,6 +469,28 @@ PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const do
       A.nsteps[A.B + e] = nrej;
     }
     poison_if_failed<NX>(status, x);
+  } else if (INTEG == PCG_INT_RK4G) {
+    int nacc = 0, nrej = 0;
+    if constexpr (has_guard<M>::value) {
+      double x0[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x0[i] = x[i];
+      const int gc = rk4_guarded<M>(f, kp, hold, x, c.h, c.substeps);
+      if (gc != 0) {  // the fixed step is not trusted for this env: the adaptive pair, from the start state
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = x0[i];
+        RegStages<NX> Kst;
+        const double rt = gc == 2 ? c.rtol : fmax(c.rtol, GUARD_LOOSE_TOL), at = gc == 2 ? c.atol : fmax(c.atol, GUARD_LOOSE_TOL);
+        status = dopri5<NX>(f, Kst, x, nx, c.dt, rt, at, c.max_steps, nacc, nrej);
+        poison_if_failed<NX>(status, x);
+      }
+    } else {
+      status = PCG_ST_NONFINITE;  // (not reachable: plans of models without a guard are refused at creation)
+    }
+    if (A.nsteps) {
+      A.nsteps[e] = nacc;
+      A.nsteps[A.B + e] = nrej;
+    }
   } else if (INTEG == PCG_INT_TSIT5) {
     int nacc = 0, nrej = 0;
     status = tsit5<NX>(f, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
@@ -1516,6 +1538,26 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX, ros_structured<M>::val
       nsteps[e] = nacc;
       nsteps[B + e] = nrej;
     }
+  } else if (INTEG == PCG_INT_RK4G) {
+    int nacc = 0, nrej = 0;
+    if constexpr (has_guard<M>::value) {
+      double x0[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x0[i] = x[i];
+      const int gc = rk4_guarded<M>(f, kp, hold, x, c.h, c.substeps);
+      if (gc != 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = x0[i];
+        RegStages<NX> K;
+        const double rt = gc == 2 ? c.rtol : fmax(c.rtol, GUARD_LOOSE_TOL), at = gc == 2 ? c.atol : fmax(c.atol, GUARD_LOOSE_TOL);
+        const int status = dopri5<NX>(f, K, x, nx, c.dt, rt, at, c.max_steps, nacc, nrej);
+        poison_if_failed<NX>(status, x);
+      }
+    }
+    if (nsteps) {
+      nsteps[e] = nacc;
+      nsteps[B + e] = nrej;
+    }
   } else if (INTEG == PCG_INT_TSIT5) {
     int nacc = 0, nrej = 0;
     const int status = tsit5<NX>(f, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
@@ -1640,6 +1682,13 @@ Kernels make_kernels() {
   k.step[PCG_INT_RODAS4][1][0][0] = k.step[PCG_INT_RODAS4][1][0][1] = step_kernel<M, PCG_INT_RODAS4, true, false, true>;
   k.integ[PCG_INT_RODAS4][0] = integrate_kernel<M, PCG_INT_RODAS4, false>;
   k.ros_structured = ros_structured<M>::value;
+  // guarded RK4 (models with a guard hook): general kernel, integration hook, fused rollout
+  if constexpr (has_guard<M>::value) {
+    k.step[PCG_INT_RK4G][0][0][0] = k.step[PCG_INT_RK4G][0][0][1] = step_kernel<M, PCG_INT_RK4G, false, false, true>;
+    k.step[PCG_INT_RK4G][1][0][0] = k.step[PCG_INT_RK4G][1][0][1] = step_kernel<M, PCG_INT_RK4G, true, false, true>;
+    k.integ[PCG_INT_RK4G][0] = k.integ[PCG_INT_RK4G][1] = integrate_kernel<M, PCG_INT_RK4G, false>;
+    k.rollout[PCG_INT_RK4G][0] = k.rollout[PCG_INT_RK4G][1] = rollout_kernel<M, PCG_INT_RK4G, false>;
+  }
   // Tsit5 (the reference's jax method): general kernel, both counter modes, and the integration hook
   k.step[PCG_INT_TSIT5][0][0][0] = k.step[PCG_INT_TSIT5][0][0][1] = step_kernel<M, PCG_INT_TSIT5, false, false, true>;
   k.step[PCG_INT_TSIT5][1][0][0] = k.step[PCG_INT_TSIT5][1][0][1] = step_kernel<M, PCG_INT_TSIT5, true, false, true>;
@@ -1695,6 +1744,7 @@ Kernels make_kernels() {
       k.step[PCG_INT_RODAS3][pe][1][ex] = k.step[PCG_INT_RODAS3][pe][0][ex];
       k.step[PCG_INT_RODAS4][pe][1][ex] = k.step[PCG_INT_RODAS4][pe][0][ex];
       k.step[PCG_INT_TSIT5][pe][1][ex] = k.step[PCG_INT_TSIT5][pe][0][ex];
+      k.step[PCG_INT_RK4G][pe][1][ex] = k.step[PCG_INT_RK4G][pe][0][ex];
       if (!k.step[PCG_INT_DOPRI5][pe][1][ex]) k.step[PCG_INT_DOPRI5][pe][1][ex] = k.step[PCG_INT_DOPRI5][pe][0][ex];
     }
   k.rollout[PCG_INT_RK4][1] = k.rollout[PCG_INT_RK4][0];

@@ -197,9 +197,10 @@ def test_registry_shaped_custom_model_reuses_kernel_with_its_parameters():
 
 
 def test_integrator_selection():
-    # cstr: adaptive by default (the ignition branch inside the canonical o_space is beyond fixed-step RK4);
-    # rk4 is an explicit opt-in and then gets the tuned sub-step count
-    assert EnvSpec(P("cstr_canonical")).integrator == "dopri5"
+    # cstr: the guarded fixed step by default (the ignition branch inside the canonical o_space is beyond fixed-step RK4:
+    # those envs fall back to the adaptive pair); plain rk4 is an explicit opt-in and then gets the tuned sub-step count
+    sc_ = EnvSpec(P("cstr_canonical"))  # guarded RK4 x 5; the adaptive pair at 1e-10 for the envs the guard refuses
+    assert sc_.integrator == "rk4g" and sc_.substeps == 5 and sc_.rtol == 1e-10
     p4 = P("cstr_canonical")
     p4["integrator"] = "rk4"
     assert EnvSpec(p4).integrator == "rk4" and EnvSpec(p4).substeps == 4   # dt = 26/60

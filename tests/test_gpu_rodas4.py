@@ -249,3 +249,42 @@ def test_fused_rollout_equals_stepping_and_dense_path_is_refused():
     with pytest.raises(Exception):
         env.rollout(torch.zeros((3, 2, 64), device="cuda", dtype=torch.float64))  # PCG_E_UNSUPPORTED
     env.close()
+
+
+def test_guarded_rk4_vs_oracle_on_the_ignition_box():
+    """PCG_INT_RK4G (the cstr default): the same envs are accepted / escalated on both sides (nsteps == (0,0) marks an
+    accepted env), accepted envs agree like fixed-step RK4, escalated ones like the adaptive pair"""
+    torch = _torch()
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+    p.pop("noise", None), p.pop("noise_percentage", None)
+    p.update(x0=np.array([0.85, 330.0, 0.85]), uncertainty_percentages={"x0": [0.15 / 0.85, 20.0 / 330.0]})
+    for per_env_t in (False, True):
+        B = 6000
+        env = VecEnv(p, n_envs=B, seed=9, per_env_t=per_env_t)
+        assert env.spec.integrator == "rk4g"
+        orc = O.OracleEnv(env.spec, B, seed=9, per_env_t=per_env_t)
+        env.reset(), orc.reset()
+        rng = np.random.default_rng(1)
+        seen_esc = 0
+        for i in range(6):
+            a = rng.uniform(-1, 1, (1, B))
+            o, r, d, _, _ = env.step(torch.tensor(a, device=env.device))
+            orc.step(a)
+            ng, no = env.nsteps.cpu().numpy(), orc.nsteps
+            esc_g, esc_o = ng.sum(axis=0) > 0, no.sum(axis=0) > 0
+            assert (esc_g != esc_o).sum() <= 2, (i, (esc_g != esc_o).sum())  # a guard value within round-off of 0 may flip
+            same = esc_g == esc_o
+            seen_esc += int(esc_g.sum())
+            xs = np.maximum(np.abs(orc.x), 1e-9)
+            ex = np.max(np.abs(env.x.cpu().numpy() - orc.x) / xs, axis=0)
+            assert ex[same & ~esc_g].max() <= 1e-11, (i, ex[same & ~esc_g].max())
+            if (same & esc_g).any():
+                assert ex[same & esc_g].max() <= 1e-8, (i, ex[same & esc_g].max())  # the ignition front amplifies round-off
+                assert np.mean(np.all(ng[:, same & esc_g] == no[:, same & esc_g], axis=0)) >= 0.99
+            assert ex.max() <= 1e-6 and not env.status.any()
+            env.x.copy_(torch.tensor(orc.x, device=env.device))  # one-step comparisons
+        assert seen_esc > B // 10
+        env.close()

@@ -1,0 +1,58 @@
+"""CPU: the guarded fixed-step plan of the cstr (PCG_INT_RK4G, the model's default) in the oracle -- the guard's calibration
+stated as a test: over episodes from the WHOLE observation box (a third of the starts ignite) every env the guard accepts
+is within 1e-6 of a 1e-13 solve, every other env takes the adaptive pair and is too; the canonical closed loop is never
+escalated."""
+import copy
+
+import numpy as np
+
+import scenarios as SC
+from oracle import oracle as O
+from pcgym_amd.config import EnvSpec
+
+
+def _spec(**kw):
+    p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+    p.pop("noise", None), p.pop("noise_percentage", None)
+    p.update(kw)
+    return EnvSpec(p)
+
+
+def test_default_plan_is_the_guarded_one():
+    s = _spec()
+    assert s.integrator == "rk4g" and s.substeps == 5 and s.rtol == 1e-10 and s.atol == 1e-10
+    assert _spec(tsim=13.0).substeps == 3 and _spec(tsim=52.0).substeps == 10  # h <= 26/60/5 whatever dt is
+
+
+import pytest
+
+
+@pytest.mark.parametrize("tsim", [26.0, 1.0])  # canonical dt = 26/60 min; the bench's dt = 1 s
+def test_guard_accepts_only_accurate_steps_and_escalates_the_rest(tsim):
+    rng = np.random.default_rng(0)
+    B = 5000
+    ref, plan = _spec(integrator="dopri5", rtol=1e-13, atol=1e-13, tsim=tsim), _spec(tsim=tsim)
+    x = np.stack([rng.uniform(0.7, 1.0, B), rng.uniform(310, 350, B)])
+    worst_acc = worst_esc = 0.0
+    frac, hot = [], 0.0
+    for t in range(8 if tsim > 2 else 200):
+        u = rng.uniform(295, 302, (1, B))
+        want, _ = O.integrate(ref, x, u)
+        got, ns = O.integrate(plan, x, u)
+        err = np.max(np.abs(got - want) / np.abs(want), axis=0)
+        esc = ns.sum(axis=0) > 0
+        frac.append(esc.mean())
+        worst_acc = max(worst_acc, err[~esc].max())
+        worst_esc = max(worst_esc, err[esc].max())
+        hot = max(hot, float((want[1] > 400).mean()))
+        x = want
+    assert worst_acc <= 1e-6 and worst_esc <= 1e-6, (worst_acc, worst_esc)
+    assert 0.25 < frac[0] < 0.6 and hot > 0.02  # the ignition branch really is in the sample
+    if tsim < 2:
+        return
+    # the canonical closed loop (x0 = (0.8, 330 K), random jacket temperatures): never escalated
+    x = np.stack([np.full(B, 0.8), np.full(B, 330.0)])
+    for t in range(30):
+        u = rng.uniform(295, 302, (1, B))
+        x, ns = O.integrate(plan, x, u)
+        assert ns.sum() == 0, t
