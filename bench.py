@@ -428,9 +428,12 @@ def main():
         assert all(e.N == N for e in envs)
 
         def run(n, timed):
+            # actions are resident and nothing consumes the outputs between steps (as for the single-model workloads,
+            # whose launches queue back to back on one stream): no cross-stream hand-shake per step, one join at the end
             menv.timing = timed
             for i in range(n):
-                menv.step([a[i % n_act] for a in acts])
+                menv.step([a[i % n_act] for a in acts], join=False)
+            menv.join()
 
         spec = envs[2].spec
     else:

@@ -512,6 +512,8 @@ class EnvSpec:
             if self.na == 0:
                 self.a_low = self.a_high = np.zeros(1)
                 self.na = 1
+            if self.affine_AB is not None and self.affine_AB[1].shape[1] == 0:  # affine model without inputs: B = 0 for the dummy
+                self.affine_AB = (self.affine_AB[0], np.zeros((self.affine_AB[0].shape[0], 1)), self.affine_AB[2])
         elif self.nu_inputs != self.na:
             raise ValueError(f"a_space has {self.na} entries but the model has {self.nu_inputs} inputs")
 
@@ -933,8 +935,10 @@ class EnvSpec:
             not_affine = e
         if not_affine is not None:
             # (b) any other Python model: record its arithmetic as C expressions and compile those (PCG_MODEL_USER)
+            # (a model without inputs -- the reference's coupled_oscillators(N=...) for any ring size, invariant_batch --
+            # is carried with one dummy action its right-hand side never reads, as the registry's own no-input models)
             na = len(info["inputs"])
-            if not (1 <= nx <= abi.PCG_MAX_NX) or not (1 <= na <= abi.PCG_MAX_NA) or len(dist) > abi.PCG_MAX_NDM:
+            if not (1 <= nx <= abi.PCG_MAX_NX) or not (0 <= na <= abi.PCG_MAX_NA) or len(dist) > abi.PCG_MAX_NDM:
                 raise not_affine
             for d in dist:
                 if d not in info.get("parameters", {}):

@@ -46,14 +46,19 @@ class MixedVecEnv:
     def __len__(self):
         return len(self.envs)
 
-    def _each(self, fn, timed=False):
-        """Run fn(i, env) for every segment on that segment's stream; the caller's stream waits for all of them
-        (so results can be consumed on it without a host synchronisation)."""
+    def _each(self, fn, timed=False, join=True):
+        """Run fn(i, env) for every segment on that segment's stream; with `join` the caller's stream waits for all of
+        them (so results can be consumed on it without a host synchronisation) and every segment's stream has waited for
+        the caller's (so inputs produced on it are visible).  join=False skips both hand-shakes: each segment simply
+        continues on its own stream -- for callers whose inputs are already resident and who consume the outputs later
+        (call join() then): consecutive steps of a segment then run back to back instead of meeting the slowest
+        segment of the previous step at a cross-stream barrier."""
         torch = _torch()
         cur = torch.cuda.current_stream(self.device)
         out = []
         for i, (e, s) in enumerate(zip(self.envs, self.streams)):
-            s.wait_stream(cur)
+            if join:
+                s.wait_stream(cur)
             with torch.cuda.stream(s):
                 if timed:
                     eb, ee = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -62,19 +67,26 @@ class MixedVecEnv:
                 if timed:
                     ee.record(s)
                     self._events[i].append((eb, ee))
+        if join:
+            for s in self.streams:
+                cur.wait_stream(s)
+        return out
+
+    def join(self):
+        """make the caller's stream wait for everything the segments have been given so far (after step(join=False))"""
+        cur = _torch().cuda.current_stream(self.device)
         for s in self.streams:
             cur.wait_stream(s)
-        return out
 
     def reset(self, seed=None):
         return self._each(lambda i, e: e.reset(seed=seed))
 
-    def step(self, actions, disturbances=None):
+    def step(self, actions, disturbances=None, join=True):
         """actions: one (na_i, B_i) SoA tensor (or (B_i, na_i)) per segment -> list of step() tuples."""
         if len(actions) != len(self.envs):
             raise ValueError(f"one action tensor per segment ({len(self.envs)}) is required")
         d = disturbances or [None] * len(self.envs)
-        return self._each(lambda i, e: e.step(actions[i], d[i]), timed=self.timing)
+        return self._each(lambda i, e: e.step(actions[i], d[i]), timed=self.timing, join=join)
 
     def segment_times(self):
         """[(total ms, launches)] per segment of the step launches recorded while `timing` was on (synchronises)."""

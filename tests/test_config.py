@@ -492,3 +492,30 @@ def test_custom_reward_callable_is_traced_into_an_expression():
     with pytest.raises(ValueError, match="indexed with self.t"):
         trace_reward_callable(indexes_elsewhere, spec)
     assert stateful is not None
+
+
+def test_custom_model_without_inputs_takes_the_traced_route():
+    """coupled_oscillators(N=...) for ring sizes other than the compiled N = 10 (model_classes.py:186-216)"""
+    class Osc:
+        def __init__(self, N):
+            self.N, self.k, self.m, self.int_method = N, 1.0, 1.0, "casadi"
+
+        def __call__(self, x, u=None):
+            N = self.N
+            return np.concatenate([x[N:] / self.m, np.array([-self.k * (2 * x[i] - x[(i - 1) % N] - x[(i + 1) % N]) for i in range(N)])])
+
+        def info(self):
+            return {"parameters": {"N": self.N, "k": self.k, "m": self.m}, "inputs": [], "disturbances": [],
+                    "states": [f"x{i + 1}" for i in range(self.N)] + [f"p{i + 1}" for i in range(self.N)]}
+
+    for N, mid in ((3, M.AFFINE), (6, M.USER), (12, M.USER)):
+        nx = 2 * N
+        s = EnvSpec({"custom_model": Osc(N), "N": 20, "tsim": 10.0, "x0": np.linspace(0.1, 1.0, nx),
+                     "a_space": {"low": np.zeros(0), "high": np.zeros(0)}, "o_space": {"low": -5 * np.ones(nx), "high": 5 * np.ones(nx)},
+                     "reward_states": ["x1"], "maximise_reward": True, "r_scale": {"x1": 1.0}})
+        assert s.model.model_id == mid and s.nx == nx and s.na == 1 and s.na_user == 0
+        if mid == M.USER:
+            assert s.user_rhs_src.count("dx[") == nx
+    with pytest.raises(ValueError):
+        EnvSpec({"custom_model": Osc(13), "N": 20, "tsim": 10.0, "x0": np.zeros(26), "a_space": {"low": np.zeros(0), "high": np.zeros(0)},
+                 "o_space": {"low": -np.ones(26), "high": np.ones(26)}, "reward_states": ["x1"], "maximise_reward": True})

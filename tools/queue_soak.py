@@ -30,7 +30,12 @@ def main():
         pe = bool(rng.integers(0, 2))
         ar = bool(rng.integers(0, 2))
         p = copy.deepcopy(S[name]["env_params"])
-        p["integrator"] = "dopri5"
+        # the extraction scenarios alternate between the explicit pair and the Rosenbrock pair (structured W: its own
+        # queue instantiation, tiles up to 2048 slots, one workgroup per CU when the batch fits one tile per CU)
+        ros = name.startswith("me_") and name != "me_reactive" and (it // len(names)) % 2 == 1
+        p["integrator"] = "rodas4" if ros else "dopri5"
+        if ros:
+            p.pop("rtol", None), p.pop("atol", None)
         p.pop("noise", None), p.pop("noise_percentage", None)
         q = VecEnv(copy.deepcopy(p), n_envs=B, seed=it, per_env_t=pe, auto_reset=ar)
         c = VecEnv(copy.deepcopy(p), n_envs=B, seed=it, per_env_t=pe, auto_reset=ar, variant=1)
@@ -58,7 +63,7 @@ def main():
             if pe:
                 assert torch.equal(q.t_env, c.t_env)
         q.close(), c.close()
-        print(it, name, "B", B, "per_env_t", pe, "auto_reset", ar, "ok", flush=True)
+        print(it, name, p["integrator"], "B", B, "per_env_t", pe, "auto_reset", ar, "ok", flush=True)
     print("queue soak: %d configurations ok" % iters)
 
 
