@@ -1056,7 +1056,7 @@ static int rodas4(const orc_model* m, double* x, const double* u, double dt, dou
       double q = U6[i] / (atol + rtol * (a0 > a1 ? a0 : a1));
       E2 += (q * q) * sg[ep_group(m, i)];
     }
-    E2 = E2 / n;
+    E2 = E2 * (1.0 / n);
     if (!lu_ok) E2 = NAN;
     if (E2 < 1.0) {
       double f = (E2 == 0.0) ? 6.0 : fmin(6.0, fmax(0.2, qtrunc6(0.9 * pow(E2, -0.125))));

@@ -876,9 +876,8 @@ static int queue_geometry(pcg_plan* p, const Kernels& k, int pe, size_t sched_by
   p->q_bpc[pe] = best_b;
   p->q_tile1[pe] = t1;
   if (best_t > 0) {
-    const int tmax = t1 > best_t ? t1 : best_t;
-    e = hipFuncSetAttribute((const void*)qfn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(k.queue_lds(tmax) + sched_bytes));
+    // (the whole CU's LDS: a launch may also park its tile's state there when that fits, see step_impl)
+    e = hipFuncSetAttribute((const void*)qfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
     if (e != hipSuccess) return (int)e;
   }
   return PCG_OK;
@@ -1006,8 +1005,13 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       const int64_t nsub = (per + Tq - 1) / Tq;
       const bool filled = (per + nsub - 1) / nsub >= (7 * QBLOCK) / 4 || std::getenv("PCG_Q_FORCE") != nullptr;
       if (filled) {
-      hipLaunchKernelGGL(qtab[pe], dim3((unsigned)nwg), dim3(QBLOCK), k.queue_lds(a.q_tile & 0xFFFF) + sb,
-                         (hipStream_t)stream, a);
+      // the tile's state in LDS too when that still leaves room for the other workgroups of the CU
+      size_t qsh = k.queue_lds(Tq) + sb;
+      if (k.queue_lds_x(Tq) + sb <= (size_t)(160 * 1024 - 2048) / q_bpc && !std::getenv("PCG_Q_NOXLDS")) {
+        a.q_tile |= 0x20000;
+        qsh = k.queue_lds_x(Tq) + sb;
+      }
+      hipLaunchKernelGGL(qtab[pe], dim3((unsigned)nwg), dim3(QBLOCK), qsh, (hipStream_t)stream, a);
       return (int)hipGetLastError();
       }
     }

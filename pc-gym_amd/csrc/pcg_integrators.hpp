@@ -770,7 +770,7 @@ PCG_DEV double ms_scaled_ep(const EP& ep, double tau, const double (&v)[NX], con
     const double w = EP::group(i) ? sg[1] : sg[0];
     s += (i < n) ? (r * r) * w : 0.0;
   }
-  return s / n;
+  return s * (1.0 / n);  // (the oracle multiplies by the same reciprocal: a division less per attempt)
 }
 
 // One attempted step of size h from x (f0 = f(x)): the candidate solution in xn, the error estimate in err; returns
@@ -779,7 +779,9 @@ template <int NX, class F, class LS>
 PCG_DEV bool rodas4_try(const F& f, const LS& ls, const double (&x)[NX], const double (&f0)[NX], double h,
                         double (&xn)[NX], double (&err)[NX]) {
 #pragma clang fp contract(off)
-  const double igh = 1.0 / (r4::GAM * h), ih = 1.0 / h;
+  // gamma = 1/4: 1 / (gamma h) == 4 (1 / h) bit for bit (scaling by a power of two commutes with rounding): one division
+  const double ih = 1.0 / h, igh = 4.0 * ih;
+  static_assert(r4::GAM == 0.25, "igh = 4 / h");
   const bool lu_ok = ls.factor(x, f0, igh);
   double U1[NX], U2[NX], U3[NX], U4[NX], U5[NX], y[NX], fy[NX];
 #pragma unroll

@@ -309,6 +309,10 @@ struct QLayout {
   PCG_HD static size_t bytes(int T) {
     return sizeof(double) * (size_t)(NU + 1) * T + sizeof(uint32_t) * QSORT + sizeof(int32_t) * 3 * (size_t)T + 16;
   }
+  // with the tile's STATE parked in LDS too (xs[NX][T], round 3): every access of the batch stays coalesced -- phase 1
+  // reads x once, phase 3 writes it once -- instead of NX scattered 8-byte loads / stores per env whenever a lane picks
+  // up / finishes one (PMC, round 2: 2.3-4.3x the algorithmic bytes).  Used when it fits beside the other workgroups.
+  PCG_HD static size_t bytes_x(int T) { return bytes(T) + sizeof(double) * (size_t)M::NX * T; }
 };
 
 template <class M, bool PER_ENV_T, bool EXTRAS, int INTEG = PCG_INT_DOPRI5>
@@ -329,7 +333,9 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
   int32_t* rejs = accs + T;
   int32_t* flag = rejs + T;   // bits 0-1: PCG_ST_* of the integration, bit 2: pre-step "done"
   int32_t* next = flag + T;   // queue head (the first min(n, 256) sorted slots are handed out directly)
-  double* sched_l = reinterpret_cast<double*>(next + 4 + (T & 1));  // per-env-t schedule tables behind the tile (8-byte aligned)
+  const bool xlds = (A.q_tile & 0x20000) != 0;  // the tile's state lives in LDS (host: it fits)
+  double* xs = reinterpret_cast<double*>(next + 4 + (T & 1));  // [NX][T] when xlds (8-byte aligned)
+  double* sched_l = xs + (xlds ? (size_t)NX * T : 0);  // per-env-t schedule tables behind the tile
   if (PER_ENV_T) stage_schedules(A, c, sched_l);
   typename M::CKP& kp = *(typename M::CKP*)c.kp;
   const int64_t B = A.B;
@@ -370,6 +376,10 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
         }
 #pragma unroll
         for (int i = 0; i < NU; ++i) us[(size_t)i * T + s] = pre.u[i];
+        if (xlds) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xs[(size_t)i * T + s] = x[i];
+        }
         hs[s] = h;
         flag[s] = pre.done_pre ? 4 : 0;
         float key;
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
     // only idles it (me10: 0.678 ms at 8, 0.656 at 2); with more envs per lane the refill code -- executed by the whole
     // wave -- is worth batching (configs[4] shard: 0.916 ms at 8, 0.929 at 2; profiles/r2/queue_refill_sweep.txt)
     const int refill = refill_hi ? refill_hi : (n <= 2 * QBLOCK ? 2 : QREFILL);
-    queue_integrate<M, INTEG>(&kp, A.x + base, B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax);
+    queue_integrate<M, INTEG>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax);
     __syncthreads();
     // ---------------- phase 3: post-integration half, coalesced stores ----------------
     for (int s = tid; s < n; s += QBLOCK) {
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
       double x[NX];
       EnvPre<M> pre;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) x[i] = A.x[(size_t)i * B + e];  // written by phase 2 (same workgroup, behind a barrier)
+      for (int i = 0; i < NX; ++i) x[i] = xlds ? xs[(size_t)i * T + s] : A.x[(size_t)i * B + e];  // written by phase 2 (same workgroup, behind a barrier)
 #pragma unroll
       for (int i = 0; i < NU; ++i) pre.u[i] = us[(size_t)i * T + s];
 #pragma unroll
@@ -448,7 +458,10 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
         reset_env(A, c, e, A.reset_seed);
         continue;
       }
-      // (the new state is already in place)
+      if (xlds) {  // the new state goes back to the batch, coalesced (otherwise phase 2 has put it in place)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) A.x[(size_t)i * B + e] = x[i];
+      }
       store_out<M>(A, c, e, out, A.obs + e);
       if (PER_ENV_T) A.t[e] = t + 1;
     }
