@@ -985,15 +985,14 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       if (const char* ev = std::getenv("PCG_Q_REFILL")) a.q_tile |= (std::atoi(ev) & 0x7F) << 20;  // measurement switch
       a.q_w = r4q ? 3.56f : 20.0f;  // (Rodas4: the fit of MEImpl::cost_key_ros) tools/queue_w_sweep.sh: 0 / 10 / 20 / 33 -> me10 0.689 / 0.684 / 0.683 / 0.719 ms, configs[4] shard 0.964 / 0.938 / 0.920 / 0.924 ms
       if (const char* ev = std::getenv("PCG_Q_W")) a.q_w = (float)std::atof(ev);  // measurement switch: key weight
-      int q_bpc = p->q_bpc[pe];
-      // Rodas4: a launch is as long as its heaviest env (~100 attempts against a mean of 22), and a wave that has its
-      // SIMD to itself runs an attempt in 2.9 us against 4.7 us when two share it: when the batch fits ONE tile per CU,
-      // one workgroup per CU with the whole pool in one tile beats two half pools (me10: 0.444 -> 0.375 ms)
-      if (r4q && p->q_tile1[pe] > 0 && !std::getenv("PCG_Q_BPC") &&
-          (io->B + p->num_cus - 1) / p->num_cus <= p->q_tile1[pe] && !std::getenv("PCG_Q_TILE")) {
-        q_bpc = 1;
-        a.q_tile = (a.q_tile & ~0xFFFF) | p->q_tile1[pe];
-      }
+      // Rodas4 with two workgroups per CU: a wave that carries one of the 128 heaviest envs of its tile raises its issue
+      // priority (s_setprio) -- it then runs at the speed of a wave that has its SIMD to itself (2.9 instead of 4.7 us per
+      // attempt) while its SIMD-mate fills the gaps; the two workgroups of a CU start their heaviest envs on different
+      // SIMDs.  configs[4]'s ME segment (349,524 envs: too many for one tile per CU): 484 -> 430 us; no effect on the
+      // explicit pair (profiles/r3/queue_prio_sweep.txt).
+      a.q_prio = r4q ? 128 : 0;
+      if (const char* ev = std::getenv("PCG_Q_PRIO")) a.q_prio = std::atoi(ev);  // measurement switch: issue priority
+      const int q_bpc = p->q_bpc[pe];
       int64_t nwg = (int64_t)p->num_cus * q_bpc;
       const int64_t cap = (io->B + QBLOCK - 1) / QBLOCK;  // no workgroup with less than one env per lane
       if (nwg > cap) nwg = cap;
@@ -1001,11 +1000,19 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       // re-balancing gain (measured 1.11x at 2.0 on BASELINE configs[2]) no longer covers the bookkeeping (0.99x at
       // 1.33: the ME segment of configs[4]) -- such launches stay on the classic kernel.
       const int64_t per = (io->B + nwg - 1) / nwg;
-      const int Tq = a.q_tile & 0xFFFF;
+      int Tq = a.q_tile & 0xFFFF;
       const int64_t nsub = (per + Tq - 1) / Tq;
-      const bool filled = (per + nsub - 1) / nsub >= (7 * QBLOCK) / 4 || std::getenv("PCG_Q_FORCE") != nullptr;
+      const int64_t sub = (per + nsub - 1) / nsub;
+      const bool filled = sub >= (7 * QBLOCK) / 4 || std::getenv("PCG_Q_FORCE") != nullptr;
       if (filled) {
-      // the tile's state in LDS too when that still leaves room for the other workgroups of the CU
+      // LDS for the sub-tile this launch actually walks, not for the largest one the plan could (the kernel derives the
+      // same number of sub-tiles from the smaller stride); the tile's state goes to LDS too when that still leaves room
+      // for the other workgroups of the CU
+      const int Tfit = (int)((sub + 63) / 64 * 64) < QBLOCK ? QBLOCK : (int)((sub + 63) / 64 * 64);
+      if (Tfit < Tq && !std::getenv("PCG_Q_TILE")) {
+        Tq = Tfit;
+        a.q_tile = (a.q_tile & ~0xFFFF) | Tq;
+      }
       size_t qsh = k.queue_lds(Tq) + sb;
       if (k.queue_lds_x(Tq) + sb <= (size_t)(160 * 1024 - 2048) / q_bpc && !std::getenv("PCG_Q_NOXLDS")) {
         a.q_tile |= 0x20000;

@@ -161,6 +161,8 @@ struct StepArgs {
   int64_t a_ss, a_cs, o_ss, o_cs, r_ss;
   int32_t T;
   float q_w;             // work-queue kernel: weight of ln(scaled |f(x0)|) in the sort key (the transient's share)
+  int32_t q_prio;        // work-queue kernel: waves holding one of the q_prio heaviest envs of their tile raise their issue
+                         // priority (0 = off); workgroups of the upper half of the grid start their heaviest envs two waves on
 };
 
 // ---------------------------------------------------------------------------

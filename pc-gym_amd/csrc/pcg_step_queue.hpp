@@ -210,13 +210,17 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
                                                           const uint32_t* sortbuf, int32_t* accs, int32_t* rejs,
                                                           int32_t* flag, int32_t* next, int T, int n, int refill, double dt, double dt_edge,
                                                           double h_floor, double rtol, double atol, int max_steps,
-                                                          double ep_c = 0.0, int ep_kmax = 0) {
+                                                          double ep_c = 0.0, int ep_kmax = 0, int prio_h = 0, int rot = 0) {
   constexpr int NX = M::NX, NU = M::NA + M::NDM;
   typename M::CKP& kp = *kpp;
   const int tid = threadIdx.x;
   typename QLaneSel<NX, INTEG>::type L;
-  int slot = tid < n ? (int)(sortbuf[tid] & (QSORT - 1)) : -1;  // QSORT - 1 == the QSLOT_BITS mask
+  // sorted position of the lane's current env (the sort is by decreasing cost: small = heavy).  `rot` shifts which wave
+  // starts with the heaviest 64: two workgroups that share a CU put them on different SIMDs (see q_prio)
+  int pos = (tid + rot) & (QBLOCK - 1);
+  int slot = pos < n ? (int)(sortbuf[pos] & (QSORT - 1)) : -1;  // QSORT - 1 == the QSLOT_BITS mask
   bool fresh = slot >= 0;
+  bool wave_hi = false;
   bool drained = n <= QBLOCK;  // wave-uniform: the queue has nothing (left) for this wave
   // every spin is bounded: a lane integrates at most two envs' worth of its tile share plus the refill rounds; the
   // bound is never reached by a correct run (max_steps bounds each env) and turns a logic error into a flagged
@@ -268,12 +272,21 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
         const int j = got + rank;
         if (j < n) {
           slot = (int)(sortbuf[j] & (QSORT - 1));
+          pos = j;
           fresh = true;
         }
       }
       if (got < n) continue;
     }
     if (bm == 0ull) break;  // nothing in flight in this wave and the queue is empty
+    if (prio_h > 0) {  // a launch is as long as its heaviest env: the wave that carries one goes first on its SIMD
+      const bool hi = __ballot(busy && pos < prio_h) != 0ull;
+      if (hi != wave_hi) {
+        if (hi) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+        wave_hi = hi;
+      }
+    }
     if (busy) {
       // the held input stays in LDS between attempts (a few ds_read per ~1000-instruction attempt) instead of in
       // registers: the resumable loop sits right at the 256-register budget
@@ -419,7 +432,9 @@ __global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void ste
     // only idles it (me10: 0.678 ms at 8, 0.656 at 2); with more envs per lane the refill code -- executed by the whole
     // wave -- is worth batching (configs[4] shard: 0.916 ms at 8, 0.929 at 2; profiles/r2/queue_refill_sweep.txt)
     const int refill = refill_hi ? refill_hi : (n <= 2 * QBLOCK ? 2 : QREFILL);
-    queue_integrate<M, INTEG>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax);
+    queue_integrate<M, INTEG>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, A.q_prio,
+                              (A.q_prio > 0 && blockIdx.x >= gridDim.x / 2) ? 2 * 64 : 0);
+    if (A.q_prio > 0) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     // ---------------- phase 3: post-integration half, coalesced stores ----------------
     for (int s = tid; s < n; s += QBLOCK) {
