@@ -14,11 +14,11 @@ from pcgym_amd import MixedVecEnv, VecEnv  # noqa: E402
 gen = torch.Generator(device="cuda").manual_seed(1)
 _, p, B, _, _ = BN.single_workload("me10")
 p["integrator"] = "rodas4"
-p.pop("rtol"), p.pop("atol")
+p.pop("rtol", None), p.pop("atol", None)
 env = VecEnv(p, n_envs=B, seed=1234)
 segs = BN.mixed_segments(1 << 20)
 segs[2][0]["integrator"] = "rodas4"
-segs[2][0].pop("rtol"), segs[2][0].pop("atol")
+segs[2][0].pop("rtol", None), segs[2][0].pop("atol", None)
 mix = MixedVecEnv(segs, seed=1234)
 for name, e, stepper in (("me10", env, None), ("mixed ME segment", mix.envs[2], mix)):
     (stepper or e).reset()
