@@ -13,7 +13,8 @@ launch, pcg_step_autoreset).  value = total env-steps / wall time (max over rank
 --workload selects the other BASELINE configurations (parity-test cases made measurable; not the headline):
   cstr_safe  the headline's envs / dt / actions under the model's DEFAULT plan (guarded RK4 with adaptive fallback) on the
              full x0 box U(0.7,1.0) x U(310,350) K of SURVEY.md section 8(d) -- reported beside the headline, not as it
-  four_tank  four_tank B = 2^20, RK4 x5 per dt = 1000/60 (the model's default: the smallest count inside 1e-6 on this box)
+  four_tank  four_tank B = 2^20, one Cooper-Verner order-8 step per dt = 1000/60 (the model's default: 11 right-hand sides;
+             --integrator rk4 gives the RK4 x5 plan it replaced)
   me10       configs[2]: multistage_extraction (10 states) B = 262,144, adaptive DOPRI5 rtol = atol = 1e-8, dt = 1,
              (L, G) per env over the FULL action box [5,10]..[500,1000], x0 = doc ICs x (1 + 0.05 U(-1,1))
   me10_ros4  the same envs, actions and starts through the stiff pair the engine now defaults to for this model (Rodas4 with
@@ -136,9 +137,9 @@ def single_workload(name):
         p = workload_params()
         del p["integrator"], p["substeps"]
         p.update(x0=np.array([0.85, 330.0, 0.85]), uncertainty_percentages={"x0": [0.15 / 0.85, 20.0 / 330.0]})
-        return "cstr_b2^20_default-plan(rk4g)_full-x0-box_fp64", p, 1 << 20, (1180, 118), 64
+        return "cstr_b2^20_default-plan(tsit5g)_full-x0-box_fp64", p, 1 << 20, (1180, 118), 64
     if name == "four_tank":
-        return "four_tank_b2^20_rk4x5_fp64", copy.deepcopy(S["four_tank_canonical"]["env_params"]), 1 << 20, (1180, 118), 16
+        return "four_tank_b2^20_cv8x1_fp64", copy.deepcopy(S["four_tank_canonical"]["env_params"]), 1 << 20, (1180, 118), 16
     if name == "me10_ros4":
         wl, p, B, kw, na = single_workload("me10")
         p.update(integrator="rodas4")
@@ -353,8 +354,9 @@ def main():
     ap.add_argument("--substeps", type=int, default=None,
                     help="cstr workload: RK4 sub-steps per env step (1 = the headline; other values are probes)")
     ap.add_argument("--status", type=int, default=1, help="write the per-env status byte (0 = off, A/B)")
-    ap.add_argument("--integrator", default=None, choices=["dopri5", "rodas4", "rodas3"],
-                    help="me10 / me20 / mixed: integrator of the extraction envs (default: the workload's named one)")
+    ap.add_argument("--integrator", default=None, choices=["dopri5", "rodas4", "rodas3", "rk4", "cv8", "rk4g", "tsit5g"],
+                    help="me10 / me20 / mixed: integrator of the extraction envs; four_tank / cstr_safe: the plan "
+                         "(default: the workload's named one)")
     args = ap.parse_args()
 
     import numpy as np
@@ -443,6 +445,9 @@ def main():
             for k in ("rtol", "atol"):  # the integrator's own default tolerance for this model (config.ROS4_TOL)
                 params.pop(k, None)
             wl_name = wl_name.replace("dopri5_1e-8", args.integrator)
+        if args.integrator and args.workload in ("four_tank", "cstr_safe"):
+            params["integrator"] = args.integrator
+            wl_name = wl_name.replace("cv8x1", args.integrator).replace("(tsit5g)", "(" + args.integrator + ")")
         B = args.batch or Bd
         K = args.steps if args.steps is not None else Kd
         W = args.warmup if args.warmup is not None else Wd
@@ -615,7 +620,7 @@ def main():
             bpe = env.bytes_per_env_step  # SURVEY.md section 8d formula for this plan and buffer set
             alg_bytes = float(bpe) * B
             achieved = alg_bytes / kern_avg_s / 1e9
-            adaptive = spec.integrator != "rk4"
+            adaptive = spec.integrator not in ("rk4", "cv8")
             fp64 = spec.model.name in FLOP_PER_RHS
             rl = {
                 "bound": "hbm",

@@ -49,7 +49,7 @@ typedef unsigned long uintptr_t;
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 9
+#define PCG_ABI_VERSION 10
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -152,7 +152,20 @@ enum pcg_integrator {
                           with a guard hook only (cstr: the ignition branch; the default plan of that model).  General
                           kernel, pcg_step_autoreset, pcg_graph_*, pcg_integrate, pcg_rollout; not with per-env uncertain
                           parameters */
-  PCG_INT_COUNT = 6
+  PCG_INT_T5G = 6,     /* GUARDED FIXED-STEP TSIT5: `substeps` equal steps of Tsit5's fifth-order solution weights (six
+                          right-hand sides per step, no error estimate), accepted per env while the model's guard holds at
+                          EVERY stage state and at the end state (g <= 0, rho h <= 2); otherwise PCG_INT_DOPRI5 from the
+                          start state inside the same launch, as PCG_INT_RK4G (same nsteps convention).  12 evaluations per
+                          canonical cstr step for the accuracy RK4G reaches with 20 (37 against 45 us per 2^20-env step):
+                          the default plan of the cstr.  Models with a guard hook only; general kernel,
+                          pcg_step_autoreset, pcg_graph_*, pcg_integrate, pcg_rollout; not with per-env uncertain
+                          parameters */
+  PCG_INT_CV8 = 7,     /* Cooper & Verner's explicit Runge-Kutta method of order 8 (11 stages), `substeps` equal steps per
+                          env step: for smooth right-hand sides one step replaces several RK4 steps (four_tank's default
+                          plan: 11 evaluations instead of 20 at a smaller error).  Kernels of PCG_INT_RK4: lean pipelined
+                          kernel (small models), general kernel, pcg_step_autoreset, pcg_graph_*, pcg_integrate,
+                          pcg_rollout; not with per-env uncertain parameters */
+  PCG_INT_COUNT = 8
 };
 
 /* cfg.flags */

@@ -436,17 +436,18 @@ static void rk4(const orc_model* m, double* x, const double* u, double dt, int n
 
 /* Guard of the fixed-step plan of the cstr (PCG_INT_RK4G; twin of Model<PCG_MODEL_CSTR>::guard): growth rate of the thermal
  * feedback g = d(dT/dt)/dT and a bound rho of the fastest rate, from model_classes.py:45-62's terms. */
-static int guard_ok(const orc_model* m, const double* x, double h, int* calm, int* slow) {
+static int guard_ok(const orc_model* m, const double* x, double h, double lim, int* calm, int* slow) {
   if (m->model_id != PCG_MODEL_CSTR) { *calm = 0; return 0; }
   const double* p = m->p;
   double q = p[0], V = p[1], rho_ = p[2], C = p[3], deltaHr = p[4], EA_over_R = p[5], k0 = p[6], UA = p[7];
   double ca = x[0], T = x[1];
-  double kk = k0 * exp(-EA_over_R / T);
-  double fb = ((-deltaHr) * (1 / (rho_ * C))) * (kk * ca) * (EA_over_R / (T * T));
+  double z = (-EA_over_R) / T; /* EA/T^2 = z^2 / EA: no second division (the device computes z for the Arrhenius factor) */
+  double kk = k0 * exp(z);
+  double fb = ((((-deltaHr) * (1 / (rho_ * C))) * (kk * ca)) * (z * z)) * (1.0 / EA_over_R);
   double base = q / V + UA * (1 / (rho_ * C * V));
   double g = fb - base, rr = kk + fb + base;
   if (!(g <= 0.0)) *calm = 0;                      /* growth, or NaN */
-  if (!(rr * h <= 1.0 || !(rr == rr))) *slow = 0;  /* unresolved fastest rate */
+  if (!(rr * h <= lim || !(rr == rr))) *slow = 0;  /* unresolved fastest rate */
   return 1;
 }
 static int dopri5(const orc_model* m, double* x, const double* u, double dt, double rtol, double atol, int max_steps,
@@ -462,7 +463,7 @@ static int rk4g(const orc_model* m, double* x, const double* u, double dt, int n
   int calm = 1, slow = 1;
   for (int i = 0; i < nx; ++i) x0[i] = x[i];
   for (int s = 0; s <= nsub; ++s) {
-    guard_ok(m, x, h, &calm, &slow);
+    guard_ok(m, x, h, 1.0, &calm, &slow);
     if (s == nsub) break;
     rhs_int(m, x, u, k1);
     for (int i = 0; i < nx; ++i) y[i] = x[i] + 0.5 * h * k1[i];
@@ -705,6 +706,104 @@ static int tsit5(const orc_model* m, double* x, const double* u, double dt, doub
   if (status != 0)
     for (int i = 0; i < nx; ++i) x[i] = NAN;
   return status;
+}
+
+/* Guarded fixed-step Tsit5 (PCG_INT_T5G, the cstr's default since round 3): nsub steps of the Tsit5 solution weights (six
+ * right-hand sides per step, no error estimate) while the model's guard holds at EVERY stage state and at the end state
+ * (the guard shares the Arrhenius factor with the right-hand side: a few multiplications per stage); otherwise the
+ * adaptive explicit pair from the start state, as rk4g().  Two steps per canonical dt reach the accuracy of five RK4 steps
+ * (7.5e-7 against 6.9e-7 of a 1e-13 solve on the accepted envs of full-box episodes, tools/prototypes/cstr_guard_t5.py)
+ * with 12 evaluations instead of 20.  Twin of t5_guarded() in pc-gym_amd/csrc/pcg_integrators.hpp. */
+#define T5G_SLOW_LIMIT 2.0
+static int t5g(const orc_model* m, double* x, const double* u, double dt, int nsub, double rtol, double atol, int max_steps,
+               int32_t* nacc, int32_t* nrej) {
+  int nx = m->nx;
+  const double(*a)[6] = T5_A;
+  double h = dt / nsub;
+  double x0[MAXNX], k1[MAXNX], k2[MAXNX], k3[MAXNX], k4[MAXNX], k5[MAXNX], k6[MAXNX], y[MAXNX];
+  int calm = 1, slow = 1;
+  for (int i = 0; i < nx; ++i) x0[i] = x[i];
+  for (int s = 0; s < nsub; ++s) {
+    guard_ok(m, x, h, T5G_SLOW_LIMIT, &calm, &slow);
+    rhs_int(m, x, u, k1);
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc1(a[1][0], k1[i]), x[i]);
+    guard_ok(m, y, h, T5G_SLOW_LIMIT, &calm, &slow);
+    rhs_int(m, y, u, k2);
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc2(a[2][0], k1[i], a[2][1], k2[i]), x[i]);
+    guard_ok(m, y, h, T5G_SLOW_LIMIT, &calm, &slow);
+    rhs_int(m, y, u, k3);
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc3(a[3][0], k1[i], a[3][1], k2[i], a[3][2], k3[i]), x[i]);
+    guard_ok(m, y, h, T5G_SLOW_LIMIT, &calm, &slow);
+    rhs_int(m, y, u, k4);
+    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc4(a[4][0], k1[i], a[4][1], k2[i], a[4][2], k3[i], a[4][3], k4[i]), x[i]);
+    guard_ok(m, y, h, T5G_SLOW_LIMIT, &calm, &slow);
+    rhs_int(m, y, u, k5);
+    for (int i = 0; i < nx; ++i)
+      y[i] = axpy(h, lc5(a[5][0], k1[i], a[5][1], k2[i], a[5][2], k3[i], a[5][3], k4[i], a[5][4], k5[i]), x[i]);
+    guard_ok(m, y, h, T5G_SLOW_LIMIT, &calm, &slow);
+    rhs_int(m, y, u, k6);
+    for (int i = 0; i < nx; ++i)
+      x[i] = axpy(h, lc6(a[6][0], k1[i], a[6][1], k2[i], a[6][2], k3[i], a[6][3], k4[i], a[6][4], k5[i], a[6][5], k6[i]), x[i]);
+  }
+  guard_ok(m, x, h, T5G_SLOW_LIMIT, &calm, &slow);
+  if (nacc) *nacc = 0;
+  if (nrej) *nrej = 0;
+  if (calm && slow) return 0;
+  for (int i = 0; i < nx; ++i) x[i] = x0[i];
+  if (calm) { rtol = fmax(rtol, 1e-7); atol = fmax(atol, 1e-7); }
+  return dopri5(m, x, u, dt, rtol, atol, max_steps, nacc, nrej);
+}
+
+/* Cooper & Verner (1972) explicit Runge-Kutta method of order 8 in 11 stages, fixed step (PCG_INT_CV8): for smooth
+ * right-hand sides ONE step per env step replaces five RK4 steps -- four_tank at the canonical dt: 7.2e-7 of a 1e-13
+ * solve with 11 evaluations against 1.8e-6 with 20 (tools/prototypes/erk_fixed.py).  Coefficients in sqrt(21), written
+ * as correctly rounded doubles; pinned by the order conditions in tests/test_erk.py.  Twin of cv8() in
+ * pc-gym_amd/csrc/pcg_integrators.hpp: every stage sum is a chain of fused multiply-adds over the non-zero
+ * coefficients in increasing stage order, then one fma with h. */
+static const double CV8_A[11][10] = {
+    {0},
+    {0.5},
+    {0.25, 0.25},
+    {0.14285714285714285, -0.2117115008659951, 0.8961811933628409},
+    {0.18550685351137905, 0, 0.5766714726956089, 0.06514850914700064},
+    {0.19963699364491333, 0, 0.3772937693043289, -0.46345538964060623, 0.386524626691364},
+    {0.1289862929772419, 0, -0.03302551131448482, -0.3497052863177422, 0.32851721314173715, 0.09790045615925942},
+    {0.07142857142857142, 0, 0, 0, 0.0020021659931149204, -0.011868683886786031, 0.1111111111111111},
+    {0.03125, 0, 0, 0, -0.009086961100820556, 0.1527777777777778, -0.6325461606959097, 0.9576053440189525},
+    {0.07142857142857142, 0, 0, 0, 0.1111111111111111, -0.6379313501852646, 2.031083139166862, -1.8108630829377543,
+     1.0624984467704635},
+    {0, 0, 0, 0, -0.5512205630727289, 2.451380432416967, -7.164951553231382, 7.553840442120271, -2.2291582101947447,
+     0.9401094519616178}};
+static const double CV8_B[11] = {0.05, 0, 0, 0, 0, 0, 0, 0.2722222222222222, 0.35555555555555557, 0.2722222222222222, 0.05};
+ORC_EXPORT void orc_cv8_tableau(double* a110, double* b11) {
+  memcpy(a110, CV8_A, sizeof CV8_A);
+  memcpy(b11, CV8_B, sizeof CV8_B);
+}
+static void cv8(const orc_model* m, double* x, const double* u, double dt, int nsub) {
+  int nx = m->nx;
+  double h = dt / nsub;
+  double k[11][MAXNX], y[MAXNX];
+  for (int s = 0; s < nsub; ++s) {
+    rhs_int(m, x, u, k[0]);
+    for (int st = 1; st < 11; ++st) {
+      for (int i = 0; i < nx; ++i) {
+        double acc = 0.0;
+        int first = 1;
+        for (int j = 0; j < st; ++j) {
+          if (CV8_A[st][j] == 0.0) continue;
+          acc = first ? CV8_A[st][j] * k[j][i] : fma(CV8_A[st][j], k[j][i], acc);
+          first = 0;
+        }
+        y[i] = fma(h, acc, x[i]);
+      }
+      rhs_int(m, y, u, k[st]);
+    }
+    for (int i = 0; i < nx; ++i) {
+      double acc = CV8_B[0] * k[0][i];
+      for (int j = 7; j < 11; ++j) acc = fma(CV8_B[j], k[j][i], acc);
+      x[i] = fma(h, acc, x[i]);
+    }
+  }
 }
 
 /* Rodas3 (Sandu et al. 1997): 4-stage linearly implicit Rosenbrock 3(2) pair, gamma = 1/2, L-stable, stiffly accurate
@@ -1301,6 +1400,9 @@ static void env_step(const pcg_env_cfg* c, orc_env* e, const double* action_in, 
     ist = rodas3(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
   else if (c->integrator_id == PCG_INT_RK4G)
     ist = rk4g(&m, e->state, uk, c->dt, c->substeps, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
+  else if (c->integrator_id == PCG_INT_T5G)
+    ist = t5g(&m, e->state, uk, c->dt, c->substeps, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
+  else if (c->integrator_id == PCG_INT_CV8) cv8(&m, e->state, uk, c->dt, c->substeps);
   else if (c->integrator_id == PCG_INT_TSIT5)
     ist = tsit5(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
   else if (c->integrator_id == PCG_INT_RODAS4)
@@ -1459,6 +1561,8 @@ ORC_EXPORT int orc_integrate(const pcg_env_cfg* c, int64_t B, double* x, const d
     if (c->integrator_id == PCG_INT_RK4) rk4(&m, xi, ui, c->dt, c->substeps);
     else if (c->integrator_id == PCG_INT_RODAS3) rodas3(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, &na_, &nr_);
     else if (c->integrator_id == PCG_INT_RK4G) rk4g(&m, xi, ui, c->dt, c->substeps, c->rtol, c->atol, c->max_steps, &na_, &nr_);
+    else if (c->integrator_id == PCG_INT_T5G) t5g(&m, xi, ui, c->dt, c->substeps, c->rtol, c->atol, c->max_steps, &na_, &nr_);
+    else if (c->integrator_id == PCG_INT_CV8) cv8(&m, xi, ui, c->dt, c->substeps);
     else if (c->integrator_id == PCG_INT_TSIT5) tsit5(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, &na_, &nr_);
     else if (c->integrator_id == PCG_INT_RODAS4)
       rodas4(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, &na_, &nr_);

@@ -206,8 +206,10 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   if (c->N < 2 || c->N > PCG_MAX_N) return PCG_E_DIM;
   if (!(c->dt > 0.0) || !std::isfinite(c->dt)) return PCG_E_VALUE;
   if (c->integrator_id == PCG_INT_RK4 && c->substeps < 0) return PCG_E_VALUE;  // 0 = no integration (I/O probe)
-  if (c->integrator_id == PCG_INT_RK4G && (c->substeps < 1 || !k.step[PCG_INT_RK4G][0][0][0] || c->nunc > 0))
+  if ((c->integrator_id == PCG_INT_RK4G || c->integrator_id == PCG_INT_T5G) &&
+      (c->substeps < 1 || !k.step[c->integrator_id][0][0][0] || c->nunc > 0))
     return c->substeps < 1 ? PCG_E_VALUE : PCG_E_UNSUPPORTED;  // models with a guard hook only
+  if (c->integrator_id == PCG_INT_CV8 && (c->substeps < 1 || c->nunc > 0)) return c->substeps < 1 ? PCG_E_VALUE : PCG_E_UNSUPPORTED;
   if (c->integrator_id != PCG_INT_RK4 && (!(c->rtol > 0) || !(c->atol >= 0) || c->max_steps < 1))
     return PCG_E_VALUE;
   const int nobs = nx + nso + nd + nunc, cnu = na + ndm;
@@ -888,8 +890,9 @@ static int queue_geometry(pcg_plan* p, const Kernels& k, int pe, size_t sched_by
 static int warm_occupancy(pcg_plan* p) {
   const Kernels& k = kernels(p->kid);
   for (int e = 0; e < 2; ++e) {
-    if (p->integrator_id == PCG_INT_RK4 && k.pipe[e] && p->pipe_occ[0][e] == 0) {
-      const int q = resident_blocks(k.pipe[e]);
+    const int ls = lean_scheme(p->integrator_id);
+    if (ls >= 0 && k.pipe[ls][e] && p->pipe_occ[0][e] == 0) {
+      const int q = resident_blocks(k.pipe[ls][e]);
       if (q < 0) return -q;
       p->pipe_occ[0][e] = q;
     }
@@ -1031,22 +1034,27 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   // Adaptive stepping is left to the one-wave-per-workgroup classic kernel unless a streaming variant is forced:
   // lanes take different numbers of steps, and a persistent grid fixes each wave's share of the batch up front,
   // whereas the dispatcher hands single-wave workgroups to whichever SIMD slot frees first.
-  const bool stream_ok = p->integrator_id == PCG_INT_RK4 || p->variant == 2 || p->variant == 3;
-  const bool lean_ar_ok = !auto_reset || ((p->variant == 4 || p->variant == 0) && p->integrator_id == PCG_INT_RK4 && k.pipe[0]);
+  const int ls = lean_scheme(p->integrator_id);  // fixed-step schemes with a lean pipelined kernel (RK4, CV8)
+  const StepFn* const pipe = ls >= 0 ? k.pipe[ls] : nullptr;
+  const bool stream_ok = ls >= 0 || p->variant == 2 || p->variant == 3;
+  const bool lean_ar_ok = !auto_reset || ((p->variant == 4 || p->variant == 0) && pipe && pipe[0]);
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto al2 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 1u) == 0; };
-  const bool pipe_ok = (p->variant == 4 || p->variant == 0) && p->integrator_id == PCG_INT_RK4 && k.pipe[0];
+  const bool pipe_ok = (p->variant == 4 || p->variant == 0) && pipe && pipe[0];
   if (!per_env_t && !extras && !lds_st && !io->viol && (!io->status || pipe_ok) && p->variant != 1 && stream_ok && lean_ar_ok &&
-      k.stream[p->integrator_id][0]) {
-    const bool epl2_ok = k.stream[p->integrator_id][1] && (io->B % 2 == 0) && al16(io->x) && al16(io->a) &&
-                         al16(io->obs) && al16(io->rew) && al2(io->done);
+      (k.stream[p->integrator_id][0] || pipe_ok)) {
+    const bool epl2_ok = (k.stream[p->integrator_id][1] || (pipe_ok && pipe[1])) && (io->B % 2 == 0) && al16(io->x) &&
+                         al16(io->a) && al16(io->obs) && al16(io->rew) && al2(io->done);
     int epl = (p->variant == 2) ? 1 : (epl2_ok ? 2 : 1);
     if (p->variant == 3 && !epl2_ok) return PCG_E_UNSUPPORTED;
+    if (const char* ev = std::getenv("PCG_LEAN_EPL"))  // measurement switch: one env per lane
+      if (std::atoi(ev) == 1) epl = 1;
     StepFn sfn = k.stream[p->integrator_id][epl - 1];
     // auto (0): the software-pipelined kernel where it exists (measured best on the cstr workload:
     // 14.9 us vs 15.0 two-sub-tile streaming vs 16.9 plain streaming vs 21 classic, profiles/r1)
-    const bool piped = (p->variant == 4 || p->variant == 0) && p->integrator_id == PCG_INT_RK4 && k.pipe[epl - 1];
-    if (piped) sfn = auto_reset ? k.pipe_ar[epl - 1] : k.pipe[epl - 1];
+    const bool piped = pipe_ok && pipe[epl - 1];
+    if (piped) sfn = auto_reset ? k.pipe_ar[ls][epl - 1] : pipe[epl - 1];
+    if (!sfn) return PCG_E_UNSUPPORTED;  // (a forced streaming variant of a scheme that only has the pipelined kernel)
     int& occ = piped ? p->pipe_occ[auto_reset ? 1 : 0][epl - 1] : p->stream_occ[epl - 1];
     if (occ == 0) {
       const int q = resident_blocks(sfn);

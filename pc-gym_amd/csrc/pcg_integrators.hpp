@@ -327,6 +327,153 @@ constexpr double e1 = -0.00178001105222577714, e2 = -0.0008164344596567469, e3 =
                  e4 = -0.1447110071732629, e5 = 0.5823571654525552, e6 = -0.45808210592918697, e7 = 0.015151515151515152;
 }  // namespace t5
 
+// ---- value-type helpers: the fixed-step schemes below run on one env (double) or W envs (Pack<W>) per lane ----------
+template <class R>
+struct pack_w {
+  static constexpr int W = 1;
+};
+template <int W_>
+struct pack_w<Pack<W_>> {
+  static constexpr int W = W_;
+};
+PCG_DEV double pk_at(double v, int) { return v; }
+template <int W>
+PCG_DEV double pk_at(const Pack<W>& v, int j) {
+  return v.v[j];
+}
+// stage sums as chains of fused multiply-adds in increasing stage order (the oracle's cv8() / t5g() do the same)
+template <class R>
+PCG_DEV R ch0(const R& k, double a) {
+  return k * a;
+}
+template <class R>
+PCG_DEV R ch(const R& acc, const R& k, double a) {
+  return pk_fma(k, a, acc);
+}
+
+// Guarded fixed-step Tsit5 (PCG_INT_T5G): nsub steps of the Tsit5 solution weights with the model's guard evaluated at
+// every stage state (it shares the right-hand side's Arrhenius factor) and at the end state.  gc[j] per env of the lane:
+// 0 accepted, 2 growing mode seen (g > 0 or non-finite), 1 only the fastest rate unresolved (rho h > T5G_SLOW_LIMIT) --
+// as rk4_guarded().  12 right-hand sides per canonical cstr step for the accuracy of RK4 x 5 (20).
+constexpr double T5G_SLOW_LIMIT = 2.0;
+template <class R, int W>
+PCG_DEV void guard_acc(const R& g, const R& rho, double h, double lim, bool (&calm)[W], bool (&slow)[W]) {
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const double gj = pk_at(g, j), rj = pk_at(rho, j);
+    calm[j] = calm[j] && (gj <= 0.0);  // (NaN compares false: counts as growth)
+    slow[j] = slow[j] && (rj * h <= lim || !(rj == rj));
+  }
+}
+template <class M, class K, class R>
+PCG_DEV void t5_guarded(const K& kp, const typename M::template HoldT<R>& hold, R (&x)[M::NX], double h, int nsub,
+                        int (&gc)[pack_w<R>::W]) {
+#pragma clang fp contract(off)
+  using namespace t5;
+  constexpr int NX = M::NX, W = pack_w<R>::W;
+  R k1[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX], y[NX], g, rho;
+  bool calm[W], slow[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) calm[j] = slow[j] = true;
+  for (int s = 0; s < nsub; ++s) {
+    M::rhs_guard(kp, hold, x, k1, g, rho);
+    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch0(k1[i], a21), h, x[i]);
+    M::rhs_guard(kp, hold, y, k2, g, rho);
+    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch(ch0(k1[i], a31), k2[i], a32), h, x[i]);
+    M::rhs_guard(kp, hold, y, k3, g, rho);
+    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch(ch(ch0(k1[i], a41), k2[i], a42), k3[i], a43), h, x[i]);
+    M::rhs_guard(kp, hold, y, k4, g, rho);
+    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch(ch(ch(ch0(k1[i], a51), k2[i], a52), k3[i], a53), k4[i], a54), h, x[i]);
+    M::rhs_guard(kp, hold, y, k5, g, rho);
+    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      y[i] = pk_fma(ch(ch(ch(ch(ch0(k1[i], a61), k2[i], a62), k3[i], a63), k4[i], a64), k5[i], a65), h, x[i]);
+    M::rhs_guard(kp, hold, y, k6, g, rho);
+    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      x[i] = pk_fma(ch(ch(ch(ch(ch(ch0(k1[i], b1), k2[i], b2), k3[i], b3), k4[i], b4), k5[i], b5), k6[i], b6), h, x[i]);
+  }
+  M::guard(kp, hold, x, g, rho);
+  guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+#pragma unroll
+  for (int j = 0; j < W; ++j) gc[j] = !calm[j] ? 2 : (slow[j] ? 0 : 1);
+}
+
+// Cooper & Verner (1972), order 8 in 11 stages, fixed step (PCG_INT_CV8; coefficients in sqrt(21) as correctly rounded
+// doubles, pinned by the 200 order conditions in tests/test_erk.py).  Twin of cv8() in oracle/pcg_oracle.c.
+namespace c8 {
+constexpr double a21 = 0.5;
+constexpr double a31 = 0.25, a32 = 0.25;
+constexpr double a41 = 0.14285714285714285, a42 = -0.2117115008659951, a43 = 0.8961811933628409;
+constexpr double a51 = 0.18550685351137905, a53 = 0.5766714726956089, a54 = 0.06514850914700064;
+constexpr double a61 = 0.19963699364491333, a63 = 0.3772937693043289, a64 = -0.46345538964060623, a65 = 0.386524626691364;
+constexpr double a71 = 0.1289862929772419, a73 = -0.03302551131448482, a74 = -0.3497052863177422, a75 = 0.32851721314173715,
+                 a76 = 0.09790045615925942;
+constexpr double a81 = 0.07142857142857142, a85 = 0.0020021659931149204, a86 = -0.011868683886786031, a87 = 0.1111111111111111;
+constexpr double a91 = 0.03125, a95 = -0.009086961100820556, a96 = 0.1527777777777778, a97 = -0.6325461606959097,
+                 a98 = 0.9576053440189525;
+constexpr double aA1 = 0.07142857142857142, aA5 = 0.1111111111111111, aA6 = -0.6379313501852646, aA7 = 2.031083139166862,
+                 aA8 = -1.8108630829377543, aA9 = 1.0624984467704635;
+constexpr double aB5 = -0.5512205630727289, aB6 = 2.451380432416967, aB7 = -7.164951553231382, aB8 = 7.553840442120271,
+                 aB9 = -2.2291582101947447, aBA = 0.9401094519616178;
+constexpr double b1 = 0.05, b8 = 0.2722222222222222, b9 = 0.35555555555555557, bA = 0.2722222222222222, bB = 0.05;
+}  // namespace c8
+template <int NX, class F, class R>
+PCG_DEV void cv8(const F& f, R (&x)[NX], double h, int nsub) {
+#pragma clang fp contract(off)
+  using namespace c8;
+  R k1[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX], k7[NX], k8[NX], k9[NX], kA[NX], y[NX];
+  for (int s = 0; s < nsub; ++s) {
+    f(x, k1);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch0(k1[i], a21), h, x[i]);
+    f(y, k2);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch(ch0(k1[i], a31), k2[i], a32), h, x[i]);
+    f(y, k3);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch(ch(ch0(k1[i], a41), k2[i], a42), k3[i], a43), h, x[i]);
+    f(y, k4);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch(ch(ch0(k1[i], a51), k3[i], a53), k4[i], a54), h, x[i]);
+    f(y, k5);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch(ch(ch(ch0(k1[i], a61), k3[i], a63), k4[i], a64), k5[i], a65), h, x[i]);
+    f(y, k6);
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      y[i] = pk_fma(ch(ch(ch(ch(ch0(k1[i], a71), k3[i], a73), k4[i], a74), k5[i], a75), k6[i], a76), h, x[i]);
+    f(y, k7);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch(ch(ch(ch0(k1[i], a81), k5[i], a85), k6[i], a86), k7[i], a87), h, x[i]);
+    f(y, k8);
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      y[i] = pk_fma(ch(ch(ch(ch(ch0(k1[i], a91), k5[i], a95), k6[i], a96), k7[i], a97), k8[i], a98), h, x[i]);
+    f(y, k9);
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      y[i] = pk_fma(ch(ch(ch(ch(ch(ch0(k1[i], aA1), k5[i], aA5), k6[i], aA6), k7[i], aA7), k8[i], aA8), k9[i], aA9), h, x[i]);
+    f(y, kA);
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      y[i] = pk_fma(ch(ch(ch(ch(ch(ch0(k5[i], aB5), k6[i], aB6), k7[i], aB7), k8[i], aB8), k9[i], aB9), kA[i], aBA), h, x[i]);
+    f(y, k2);  // stage 11 (k2 is dead since stage 4)
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = pk_fma(ch(ch(ch(ch(ch0(k1[i], b1), k8[i], b8), k9[i], b9), kA[i], bA), k2[i], bB), h, x[i]);
+  }
+}
+
 // returns 0 ok, 1 step budget exhausted, 2 step-size underflow
 template <int NX, class F>
 PCG_DEV int tsit5(const F& f, double (&x)[NX], int n, double dt, double rtol, double atol, int max_steps, int& nacc,

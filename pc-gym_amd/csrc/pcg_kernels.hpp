@@ -56,6 +56,8 @@ constexpr int BLOCK_LDS = 64;   // LDS-staged DOPRI5: 6*NX*8 B of stage storage 
 constexpr bool ros_dense(int integ, bool structured) {
   return integ == PCG_INT_RODAS3 || (integ == PCG_INT_RODAS4 && !structured);
 }
+// the fixed-step schemes the lean pipelined kernel is instantiated for: index into Kernels::pipe (-1: none)
+constexpr int lean_scheme(int integ) { return integ == PCG_INT_RK4 ? 0 : integ == PCG_INT_CV8 ? 1 : -1; }
 constexpr int tb(bool lds_stages, int integ, int nx = 0, bool structured = false) {
   return ros_dense(integ, structured) ? ros_threads(nx)
          : (lds_stages || integ == PCG_INT_DOPRI5 || integ == PCG_INT_RODAS4 || integ == PCG_INT_TSIT5) ? BLOCK_LDS : BLOCK;
@@ -453,6 +455,40 @@ PCG_DEV int finite_status(int status, const double (&x)[NX], int nx) {
   return (status == PCG_ST_OK && !ok) ? PCG_ST_NONFINITE : status;
 }
 
+// Guarded fixed-step plans on one env (PCG_INT_RK4G, PCG_INT_T5G): the fixed-step scheme under the model's guard; an env
+// that trips it is re-integrated from its start state by the adaptive pair -- at the plan's tolerance when a growing mode
+// was seen, at GUARD_LOOSE_TOL on contracting stiff states.  Returns the pair's status (PCG_ST_OK for accepted envs).
+template <class M, int INTEG, class K, class F>
+PCG_DEV int guarded_env(const F& f, const K& kp, const typename M::Hold& hold, double (&x)[M::NX], CDevConst& c, int nx,
+                        int& nacc, int& nrej) {
+  constexpr int NX = M::NX;
+  int status = PCG_ST_OK;
+  if constexpr (has_guard<M>::value) {
+    double x0[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x0[i] = x[i];
+    int gc;
+    if constexpr (INTEG == PCG_INT_T5G) {
+      int g1[1];
+      t5_guarded<M, K, double>(kp, hold, x, c.h, c.substeps, g1);
+      gc = g1[0];
+    } else {
+      gc = rk4_guarded<M>(f, kp, hold, x, c.h, c.substeps);
+    }
+    if (gc != 0) {  // the fixed step is not trusted for this env: the adaptive pair, from the start state
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = x0[i];
+      RegStages<NX> Kst;
+      const double rt = gc == 2 ? c.rtol : fmax(c.rtol, GUARD_LOOSE_TOL), at = gc == 2 ? c.atol : fmax(c.atol, GUARD_LOOSE_TOL);
+      status = dopri5<NX>(f, Kst, x, nx, c.dt, rt, at, c.max_steps, nacc, nrej);
+      poison_if_failed<NX>(status, x);
+    }
+  } else {
+    status = PCG_ST_NONFINITE;  // (not reachable: plans of models without a guard are refused at creation)
+  }
+  return status;
+}
+
 template <class M, int INTEG, bool LDS_STAGES, class K>
 PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const double (&u)[M::NA + M::NDM],
                           double (&x)[M::NX], double* stage_l, int64_t e, int nx) {
@@ -471,24 +507,11 @@ PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const do
       A.nsteps[A.B + e] = nrej;
     }
     poison_if_failed<NX>(status, x);
-  } else if (INTEG == PCG_INT_RK4G) {
+  } else if (INTEG == PCG_INT_CV8) {
+    cv8<NX>(f, x, c.h, c.substeps);
+  } else if (INTEG == PCG_INT_RK4G || INTEG == PCG_INT_T5G) {
     int nacc = 0, nrej = 0;
-    if constexpr (has_guard<M>::value) {
-      double x0[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) x0[i] = x[i];
-      const int gc = rk4_guarded<M>(f, kp, hold, x, c.h, c.substeps);
-      if (gc != 0) {  // the fixed step is not trusted for this env: the adaptive pair, from the start state
-#pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = x0[i];
-        RegStages<NX> Kst;
-        const double rt = gc == 2 ? c.rtol : fmax(c.rtol, GUARD_LOOSE_TOL), at = gc == 2 ? c.atol : fmax(c.atol, GUARD_LOOSE_TOL);
-        status = dopri5<NX>(f, Kst, x, nx, c.dt, rt, at, c.max_steps, nacc, nrej);
-        poison_if_failed<NX>(status, x);
-      }
-    } else {
-      status = PCG_ST_NONFINITE;  // (not reachable: plans of models without a guard are refused at creation)
-    }
+    status = guarded_env<M, INTEG>(f, kp, hold, x, c, nx, nacc, nrej);
     if (A.nsteps) {
       A.nsteps[e] = nacc;
       A.nsteps[A.B + e] = nrej;
@@ -958,7 +981,11 @@ struct LeanOut {
   bool done;                // wave-uniform
 };
 
-template <class M, int W>
+// INTEG: PCG_INT_RK4 (the lean kernels' scheme) or PCG_INT_CV8.  (A guarded scheme with the adaptive fallback inside this
+// kernel was built and measured: 41.3 us against 37 us in the general kernel on the canonical cstr loop -- the fallback's
+// registers leave one env per lane at four waves per SIMD -- and 26 % slower when half the batch escalates, because a
+// 256-thread workgroup then waits for its slowest env.)
+template <class M, int W, int INTEG = PCG_INT_RK4>
 PCG_DEV void env_step_lean(const StepArgs& A, CDevConst& c, int t, const Pack<W> (&a_in)[M::NA],
                            Pack<W> (&x)[M::NX], LeanOut<M, W>& out) {
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
@@ -990,7 +1017,11 @@ PCG_DEV void env_step_lean(const StepArgs& A, CDevConst& c, int t, const Pack<W>
   // integrate over [0,dt] with the input held (integrator.py:163-182)
   const typename M::template HoldT<R> hold = M::template hold<R>(kp, u);
   const RhsFn<M, R> f{kp, hold};
-  rk4<NX>(f, x, c.h, c.substeps);
+  if constexpr (INTEG == PCG_INT_CV8) {
+    cv8<NX>(f, x, c.h, c.substeps);
+  } else {
+    rk4<NX>(f, x, c.h, c.substeps);
+  }
   // SP slot = SP[t_old] (Q5), reward against SP[t_new] (pcgym.py:432-441, 535-558)
   R r(0.0);
 #pragma unroll
@@ -1267,8 +1298,8 @@ void step_kernel_stream(const StepArgs A) {
 // (pcg_step_autoreset).  It is a separate instantiation because the inlined reset path (Philox draws for the x0 /
 // parameter uncertainty) raises the register count of the whole kernel from 75 to 118 (6 -> 4 waves per SIMD);
 // the other N-2 steps of the episode run the lean one.
-template <class M, int EPL, bool AR = false>
-__global__ __launch_bounds__(BLOCK, PCG_LEAN_WPE) void step_kernel_pipe(const StepArgs A) {
+template <class M, int EPL, bool AR = false, int INTEG = PCG_INT_RK4>
+__global__ __launch_bounds__(BLOCK, INTEG == PCG_INT_RK4 ? PCG_LEAN_WPE : 4) void step_kernel_pipe(const StepArgs A) {
   CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA;
   using V = typename Vec<EPL>::T;
@@ -1317,8 +1348,8 @@ __global__ __launch_bounds__(BLOCK, PCG_LEAN_WPE) void step_kernel_pipe(const St
 #pragma unroll
         for (int j = 0; j < EPL; ++j) as[i].v[j] = (i < na) ? Vec<EPL>::get(av[i], j) : 0.0;
       LeanOut<M, EPL> out;
-      env_step_lean<M, EPL>(A, c, t, as, xs, out);
-      if (A.status) {  // per-env health: fixed-step RK4 can only leave a non-finite state; only failures are written
+      env_step_lean<M, EPL, INTEG>(A, c, t, as, xs, out);
+      if (A.status) {  // per-env health: a fixed step can only leave a non-finite state; only failures are written
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
           bool ok = true;
@@ -1540,22 +1571,11 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX, ros_structured<M>::val
       nsteps[e] = nacc;
       nsteps[B + e] = nrej;
     }
-  } else if (INTEG == PCG_INT_RK4G) {
+  } else if (INTEG == PCG_INT_CV8) {
+    cv8<NX>(f, x, c.h, c.substeps);
+  } else if (INTEG == PCG_INT_RK4G || INTEG == PCG_INT_T5G) {
     int nacc = 0, nrej = 0;
-    if constexpr (has_guard<M>::value) {
-      double x0[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) x0[i] = x[i];
-      const int gc = rk4_guarded<M>(f, kp, hold, x, c.h, c.substeps);
-      if (gc != 0) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = x0[i];
-        RegStages<NX> K;
-        const double rt = gc == 2 ? c.rtol : fmax(c.rtol, GUARD_LOOSE_TOL), at = gc == 2 ? c.atol : fmax(c.atol, GUARD_LOOSE_TOL);
-        const int status = dopri5<NX>(f, K, x, nx, c.dt, rt, at, c.max_steps, nacc, nrej);
-        poison_if_failed<NX>(status, x);
-      }
-    }
+    guarded_env<M, INTEG>(f, kp, hold, x, c, nx, nacc, nrej);
     if (nsteps) {
       nsteps[e] = nacc;
       nsteps[B + e] = nrej;
@@ -1646,8 +1666,8 @@ struct Kernels {
   bool queue_default;                // route adaptive plans to it unless told otherwise (models with a cost key)
   size_t (*queue_lds)(int);          // LDS bytes of a tile of T slots
   size_t (*queue_lds_x)(int);        // ... with the tile's state parked in LDS as well
-  StepFn pipe[2];                    // RK4 software-pipelined lean kernel [EPL-1] (may be null)
-  StepFn pipe_ar[2];                 // the same with the same-launch auto-reset path compiled in [EPL-1]
+  StepFn pipe[2][2];                 // software-pipelined lean kernel [lean_scheme(integrator)][EPL-1] (may be null)
+  StepFn pipe_ar[2][2];              // the same with the same-launch auto-reset path compiled in
   StepFn roll_lean[2];               // RK4 lean fused rollout [EPL-1] (may be null)
   StepFn rollout[PCG_INT_COUNT][2];  // [integrator][lds_stages]
   RhsKFn rhs;
@@ -1692,6 +1712,17 @@ Kernels make_kernels() {
     k.integ[PCG_INT_RK4G][0] = k.integ[PCG_INT_RK4G][1] = integrate_kernel<M, PCG_INT_RK4G, false>;
     k.rollout[PCG_INT_RK4G][0] = k.rollout[PCG_INT_RK4G][1] = rollout_kernel<M, PCG_INT_RK4G, false>;
   }
+  if constexpr (has_guard<M>::value) {  // guarded fixed-step Tsit5: the same set
+    k.step[PCG_INT_T5G][0][0][0] = k.step[PCG_INT_T5G][0][0][1] = step_kernel<M, PCG_INT_T5G, false, false, true>;
+    k.step[PCG_INT_T5G][1][0][0] = k.step[PCG_INT_T5G][1][0][1] = step_kernel<M, PCG_INT_T5G, true, false, true>;
+    k.integ[PCG_INT_T5G][0] = k.integ[PCG_INT_T5G][1] = integrate_kernel<M, PCG_INT_T5G, false>;
+    k.rollout[PCG_INT_T5G][0] = k.rollout[PCG_INT_T5G][1] = rollout_kernel<M, PCG_INT_T5G, false>;
+  }
+  // fixed-step order-8 method: general kernel, integration hook, fused rollout (launch shape of RK4)
+  k.step[PCG_INT_CV8][0][0][0] = k.step[PCG_INT_CV8][0][0][1] = step_kernel<M, PCG_INT_CV8, false, false, true>;
+  k.step[PCG_INT_CV8][1][0][0] = k.step[PCG_INT_CV8][1][0][1] = step_kernel<M, PCG_INT_CV8, true, false, true>;
+  k.integ[PCG_INT_CV8][0] = k.integ[PCG_INT_CV8][1] = integrate_kernel<M, PCG_INT_CV8, false>;
+  k.rollout[PCG_INT_CV8][0] = k.rollout[PCG_INT_CV8][1] = rollout_kernel<M, PCG_INT_CV8, false>;
   // Tsit5 (the reference's jax method): general kernel, both counter modes, and the integration hook
   k.step[PCG_INT_TSIT5][0][0][0] = k.step[PCG_INT_TSIT5][0][0][1] = step_kernel<M, PCG_INT_TSIT5, false, false, true>;
   k.step[PCG_INT_TSIT5][1][0][0] = k.step[PCG_INT_TSIT5][1][0][1] = step_kernel<M, PCG_INT_TSIT5, true, false, true>;
@@ -1734,10 +1765,20 @@ Kernels make_kernels() {
     // small (the HBM-bound models)
     if constexpr (M::NX <= 4) {
       k.roll_lean[1] = rollout_kernel_lean<M, 2>;
-      k.pipe[0] = step_kernel_pipe<M, 1>;
-      k.pipe[1] = step_kernel_pipe<M, 2>;
-      k.pipe_ar[0] = step_kernel_pipe<M, 1, true>;
-      k.pipe_ar[1] = step_kernel_pipe<M, 2, true>;
+      k.pipe[0][0] = step_kernel_pipe<M, 1>;
+      k.pipe[0][1] = step_kernel_pipe<M, 2>;
+      k.pipe_ar[0][0] = step_kernel_pipe<M, 1, true>;
+      k.pipe_ar[0][1] = step_kernel_pipe<M, 2, true>;
+      // the order-8 scheme keeps more stage vectors alive: two envs per lane only where that fits 128 registers (four
+      // waves per SIMD, and room beside the work-queue kernels of a mixed batch) without spilling
+      k.pipe[1][0] = step_kernel_pipe<M, 1, false, PCG_INT_CV8>;
+      k.pipe_ar[1][0] = step_kernel_pipe<M, 1, true, PCG_INT_CV8>;
+      // (measured on four_tank, 4 states: two envs per lane at once spill at 128 registers, one after the other is no
+      // faster than one env per lane -- 45.1 against 43.3 us per 2^20-env step -- and writes its spills to HBM)
+      if constexpr (M::NX <= 2) {
+        k.pipe[1][1] = step_kernel_pipe<M, 2, false, PCG_INT_CV8>;
+        k.pipe_ar[1][1] = step_kernel_pipe<M, 2, true, PCG_INT_CV8>;
+      }
       k.stream[PCG_INT_RK4][1] = step_kernel_stream<M, PCG_INT_RK4, 2, 1>;
     }
   }
@@ -1749,6 +1790,8 @@ Kernels make_kernels() {
       k.step[PCG_INT_RODAS4][pe][1][ex] = k.step[PCG_INT_RODAS4][pe][0][ex];
       k.step[PCG_INT_TSIT5][pe][1][ex] = k.step[PCG_INT_TSIT5][pe][0][ex];
       k.step[PCG_INT_RK4G][pe][1][ex] = k.step[PCG_INT_RK4G][pe][0][ex];
+      k.step[PCG_INT_T5G][pe][1][ex] = k.step[PCG_INT_T5G][pe][0][ex];
+      k.step[PCG_INT_CV8][pe][1][ex] = k.step[PCG_INT_CV8][pe][0][ex];
       if (!k.step[PCG_INT_DOPRI5][pe][1][ex]) k.step[PCG_INT_DOPRI5][pe][1][ex] = k.step[PCG_INT_DOPRI5][pe][0][ex];
     }
   k.rollout[PCG_INT_RK4][1] = k.rollout[PCG_INT_RK4][0];

@@ -54,7 +54,7 @@ struct Model<PCG_MODEL_CSTR> {
   static constexpr bool DYNAMIC = false;
   static constexpr bool FULL = true;  // all kernel specialisations
   struct KP {
-    double qV, c1, c2, k0, nEAR;
+    double qV, c1, c2, k0, nEAR, iEA;
   };
   using CKP = const PCG_CONSTANT KP;
   template <class R>
@@ -69,6 +69,7 @@ struct Model<PCG_MODEL_CSTR> {
     k.c2 = r[7] * (1.0 / (r[2] * r[3] * r[1]));
     k.k0 = r[6];
     k.nEAR = -r[5];
+    k.iEA = 1.0 / r[5];
     __builtin_memcpy(kp_out, &k, sizeof(k));
     ddef[0] = r[8];
     ddef[1] = r[9];
@@ -87,32 +88,34 @@ struct Model<PCG_MODEL_CSTR> {
     dx[0] = k.qV * (h.Caf - ca) - rA;
     dx[1] = k.qV * (h.Ti - T) + k.c1 * rA + k.c2 * (h.Tc - T);
   }
-  // Guard of the fixed-step plan (PCG_INT_RK4G): g = d(dT/dt)/dT = c1 rA EA/T^2 - (q/V + c2), the growth rate of the
-  // thermal feedback (> 0: the reaction heats itself faster than flow and jacket cool it -- ignition, errors amplify),
-  // and rho = k + c1 rA EA/T^2 + q/V + c2, a bound of the fastest rate.  Calibrated on 72,000 (state, input) pairs of
-  // episodes over the whole observation box (tools/cstr_guard_calibration.py): with 5 sub-steps per canonical dt, every
-  // env with g <= 0 and rho h <= 1 at the sub-step starts and at the end state is within 6.6e-7 of a 1e-13 solve; the
+  // Guard of the fixed-step plans (PCG_INT_RK4G, PCG_INT_T5G): g = d(dT/dt)/dT = c1 rA EA/T^2 - (q/V + c2), the growth
+  // rate of the thermal feedback (> 0: the reaction heats itself faster than flow and jacket cool it -- ignition, errors
+  // amplify), and rho = k + c1 rA EA/T^2 + q/V + c2, a bound of the fastest rate.  EA/T^2 = z^2/EA with z = -EA/T, the
+  // Arrhenius exponent the right-hand side computes anyway: no second division.  Calibrated on (state, input) pairs of
+  // episodes over the whole observation box (tests/test_rk4g.py, tests/test_erk.py, tools/prototypes/cstr_guard_t5.py):
+  // every env with g <= 0 and rho h below the scheme's limit at the checked states is within 7.5e-7 of a 1e-13 solve; the
   // canonical closed loop (T <= 330 K) never trips it, the ignition branch and the hot branch always do.
   static constexpr bool GUARD = true;
-  template <class K>
-  PCG_DEV static void guard(const K& k, const HoldT<double>&, const double (&x)[NX], double& g, double& rho) {
-    const double ca = x[0], T = x[1];
-    const double kk = k.k0 * exp_bounded(div_fast(k.nEAR, T));
-    const double fb = k.c1 * (kk * ca) * div_fast(-k.nEAR, T * T);
+  template <class R, class K>
+  PCG_DEV static void guard(const K& k, const HoldT<R>&, const R (&x)[NX], R& g, R& rho) {
+    const R ca = x[0], T = x[1];
+    const R z = div_fast(k.nEAR, T);
+    const R kk = k.k0 * exp_bounded(z);
+    const R fb = ((k.c1 * (kk * ca)) * (z * z)) * k.iEA;
     const double base = k.qV + k.c2;
     g = fb - base;
     rho = kk + fb + base;
   }
   // rhs() and guard() at the same point in one pass (one Arrhenius factor for both): the same bits as the two calls
-  template <class K>
-  PCG_DEV static void rhs_guard(const K& k, const HoldT<double>& h, const double (&x)[NX], double (&dx)[NX], double& g,
-                                double& rho) {
-    const double ca = x[0], T = x[1];
-    const double kk = k.k0 * exp_bounded(div_fast(k.nEAR, T));
-    const double rA = kk * ca;
+  template <class R, class K>
+  PCG_DEV static void rhs_guard(const K& k, const HoldT<R>& h, const R (&x)[NX], R (&dx)[NX], R& g, R& rho) {
+    const R ca = x[0], T = x[1];
+    const R z = div_fast(k.nEAR, T);
+    const R kk = k.k0 * exp_bounded(z);
+    const R rA = kk * ca;
     dx[0] = k.qV * (h.Caf - ca) - rA;
     dx[1] = k.qV * (h.Ti - T) + k.c1 * rA + k.c2 * (h.Tc - T);
-    const double fb = k.c1 * rA * div_fast(-k.nEAR, T * T);
+    const R fb = ((k.c1 * rA) * (z * z)) * k.iEA;
     const double base = k.qV + k.c2;
     g = fb - base;
     rho = kk + fb + base;

@@ -135,7 +135,7 @@ class VecEnv:
         self.g_pre = torch.zeros((s.ncon, B), dtype=f64, device=dev) if s.ncon else None
         self.t_env = torch.zeros(B, dtype=torch.int32, device=dev) if self.per_env_t else None
         self.nsteps = (torch.zeros((2, B), dtype=torch.int32, device=dev)
-                       if s.integrator != "rk4" else None)
+                       if s.integrator not in ("rk4", "cv8") else None)
         self.p_unc = torch.zeros((s.nunc, B), dtype=f64, device=dev) if s.nunc else None  # per-env parameters
         # previous physical action of the declarative tracking reward; NaN = none yet (custom_reward.py:7-8)
         self.u_prev = (torch.full((s.na, B), float("nan"), dtype=f64, device=dev)

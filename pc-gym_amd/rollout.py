@@ -82,7 +82,7 @@ def collect_rollouts(env, policy=None, actions=None):
     # per-step kernel; the 20-state DOPRI5 rollout kernel is slower than stepping (tools/rollout_probe.py)
     fused_ok = (not s.ncon and not s.nunc and (s.integrator not in ("rodas3", "rodas4", "tsit5") or (s.integrator == "rodas4" and s.model.name == "multistage_extraction"))
                 and s.user_rhs_src is None
-                and (s.integrator == "rk4" or s.nx <= 10))
+                and (s.integrator in ("rk4", "cv8") or s.nx <= 10))
     if actions is not None:
         actions = actions.to(device=dev, dtype=f64)
         if actions.shape != (N, s.na, B):

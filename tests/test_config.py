@@ -199,12 +199,16 @@ def test_registry_shaped_custom_model_reuses_kernel_with_its_parameters():
 def test_integrator_selection():
     # cstr: the guarded fixed step by default (the ignition branch inside the canonical o_space is beyond fixed-step RK4:
     # those envs fall back to the adaptive pair); plain rk4 is an explicit opt-in and then gets the tuned sub-step count
-    sc_ = EnvSpec(P("cstr_canonical"))  # guarded RK4 x 5; the adaptive pair at 1e-10 for the envs the guard refuses
-    assert sc_.integrator == "rk4g" and sc_.substeps == 5 and sc_.rtol == 1e-10
+    sc_ = EnvSpec(P("cstr_canonical"))  # guarded Tsit5 x 2; the adaptive pair at 1e-10 for the envs the guard refuses
+    assert sc_.integrator == "tsit5g" and sc_.substeps == 2 and sc_.rtol == 1e-10 and sc_.to_cfg()[0].integrator_id == abi.PCG_INT_T5G
+    pg = P("cstr_canonical")
+    pg["integrator"] = "rk4g"            # the first guarded plan of round 3 stays available
+    assert EnvSpec(pg).substeps == 5 and EnvSpec(pg).to_cfg()[0].integrator_id == abi.PCG_INT_RK4G
     p4 = P("cstr_canonical")
     p4["integrator"] = "rk4"
     assert EnvSpec(p4).integrator == "rk4" and EnvSpec(p4).substeps == 4   # dt = 26/60
-    assert EnvSpec(P("four_tank_canonical")).integrator == "rk4"
+    sf = EnvSpec(P("four_tank_canonical"))  # one order-8 step per canonical dt
+    assert sf.integrator == "cv8" and sf.substeps == 1 and sf.to_cfg()[0].integrator_id == abi.PCG_INT_CV8
     sm = EnvSpec(P("me_canonical"))                            # stiff: the Rosenbrock pair with end-point control
     assert sm.integrator == "rodas4" and sm.rtol == 3e-8 and sm.atol == 3e-8 and (sm.ep_frac, sm.ep_kmax) == (0.5, 10)
     pj = P("me_canonical")

@@ -369,7 +369,7 @@ def test_batched_step_vs_oracle(name, kw, tol, per_env_t, B):
     spec = env.spec
     orc = O.OracleEnv(spec, B, seed=5, per_env_t=per_env_t)
     acts = _rand_actions(spec, T, B, 3)  # the FULL action box (ME: L up to 500, G up to 1000, |lambda| dt ~ 240)
-    adaptive = spec.integrator != "rk4"
+    adaptive = spec.integrator not in ("rk4", "cv8")
     o_g, _ = env.reset()
     o_c = orc.reset()
     rng = np.random.default_rng(9)

@@ -264,7 +264,7 @@ def test_guarded_rk4_vs_oracle_on_the_ignition_box():
     for per_env_t in (False, True):
         B = 6000
         env = VecEnv(p, n_envs=B, seed=9, per_env_t=per_env_t)
-        assert env.spec.integrator == "rk4g"
+        assert env.spec.integrator == "tsit5g"
         orc = O.OracleEnv(env.spec, B, seed=9, per_env_t=per_env_t)
         env.reset(), orc.reset()
         rng = np.random.default_rng(1)

@@ -221,7 +221,7 @@ def test_default_cstr_integrator_survives_the_ignition_branch():
     p.update(tsim=26.0, x0=np.array([0.85, 330.0, 0.85]), uncertainty_percentages={"x0": [0.15 / 0.85, 20.0 / 330.0]})
     B, W = 1 << 20, 4096
     env = VecEnv(p, n_envs=B, seed=77)
-    assert env.spec.integrator == "rk4g"  # the guarded plan: igniting envs fall back to the adaptive pair at 1e-10
+    assert env.spec.integrator == "tsit5g"  # the guarded plan: igniting envs fall back to the adaptive pair at 1e-10
     env.reset()
     x0 = env.x.clone()
     assert float(x0[1].max()) > 349.0 and float(x0[1].min()) < 311.0

@@ -105,7 +105,7 @@ def test_integrators_reach_true_solution(fix, model, tol_default, tight, tol_tig
     s = _spec_for_integration(model, dt, nu)
     xf, _ = O.integrate(s, g["x"].T, g["u"].T)
     if model == "cstr":
-        assert s.integrator == "rk4g" and (g["xf"][:, 1] > 360.0).sum() >= 3  # the fixture holds igniting samples (escalated)
+        assert s.integrator == "tsit5g" and (g["xf"][:, 1] > 360.0).sum() >= 3  # the fixture holds igniting samples (escalated)
     # mixed tolerance, as CVODES' own (reltol 1e-6, abstol 1e-8): small components are held absolutely
     tol = 1e-5 if model == "cstr" else tol_default  # ignition transients: the 1e-8 local tolerance gives ~3e-6 global
     assert np.all(np.abs(xf.T - g["xf"]) <= tol * scale + 3e-8)

@@ -1,4 +1,4 @@
-"""CPU: the guarded fixed-step plan of the cstr (PCG_INT_RK4G, the model's default) in the oracle -- the guard's calibration
+"""CPU: the guarded RK4 plan of the cstr (PCG_INT_RK4G; the model's default is its Tsit5 sibling: tests/test_erk.py) in the oracle -- the guard's calibration
 stated as a test: over episodes from the WHOLE observation box (a third of the starts ignite) every env the guard accepts
 is within 1e-6 of a 1e-13 solve, every other env takes the adaptive pair and is too; the canonical closed loop is never
 escalated."""
@@ -14,11 +14,12 @@ from pcgym_amd.config import EnvSpec
 def _spec(**kw):
     p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
     p.pop("noise", None), p.pop("noise_percentage", None)
+    p.setdefault("integrator", "rk4g")
     p.update(kw)
     return EnvSpec(p)
 
 
-def test_default_plan_is_the_guarded_one():
+def test_guarded_rk4_plan():
     s = _spec()
     assert s.integrator == "rk4g" and s.substeps == 5 and s.rtol == 1e-10 and s.atol == 1e-10
     assert _spec(tsim=13.0).substeps == 3 and _spec(tsim=52.0).substeps == 10  # h <= 26/60/5 whatever dt is
