@@ -59,6 +59,8 @@ def flops_per_env_step(model, nx, integrator, attempts, substeps=1):
     f = FLOP_PER_RHS[model]
     if integrator == "rk4":
         return 4 * substeps * (f + 2 * 6 * nx)
+    if integrator == "cv8":  # 11 RHS per step; 44 + 5 stage-sum multiply-adds and 11 axpys per state
+        return substeps * (11 * f + 2 * (49 + 11) * nx)
     if integrator == "rodas4":
         return attempts * (6 * f + 25 * 2 * nx + 60 + 6 * 66 + 4 * nx)
     return (2 + 6 * attempts) * (f + 2 * 6 * nx)
@@ -159,6 +161,9 @@ def single_workload(name):
         p = copy.deepcopy(S["cryst_adelta"]["env_params"])
         p.update(integrator="rk4", substeps=32)
         return "crystallization_b2^18_rk4x32_adelta_fp64", p, 1 << 18, (116, 12), 8
+    if name == "cryst_cv8":  # the same envs under the model's default plan: four order-8 steps per env step (44 RHS)
+        p = copy.deepcopy(S["cryst_adelta"]["env_params"])
+        return "crystallization_b2^18_cv8x4_adelta_fp64", p, 1 << 18, (116, 12), 8
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -341,7 +346,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cstr", choices=["cstr", "cstr_safe", "four_tank", "me10", "me10_ros4", "me20", "cryst", "mixed"])
+    ap.add_argument("--workload", default="cstr", choices=["cstr", "cstr_safe", "four_tank", "me10", "me10_ros4", "me20", "cryst", "cryst_cv8", "mixed"])
     ap.add_argument("--batch", type=int, default=None, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=None, help="fixed OpenMP team of the cpu_baseline leg (default min(16, avail))")
@@ -461,7 +466,7 @@ def main():
         acts = act_box(spec) * (2 * torch.rand((n_act, spec.na, B), generator=gen, device=dev, dtype=torch.float64) - 1) \
             + act_shift(spec)
         env.reset()
-        if args.workload == "cryst":  # initial moments x (1 + 0.01 U), CV and Ln recomputed (cryst_train.py:80-81)
+        if args.workload in ("cryst", "cryst_cv8"):  # initial moments x (1 + 0.01 U), CV and Ln recomputed (cryst_train.py:80-81)
             x = env.x.clone()
             x[:5] *= 1 + 0.01 * (2 * torch.rand((5, B), generator=gen, device=dev, dtype=torch.float64) - 1)
             x[5] = torch.sqrt(x[2] * x[0] / x[1] ** 2 - 1)
@@ -643,7 +648,7 @@ def main():
                     rl["attempted_steps_mean"] = att
                     rl["accepted_steps_mean"] = stepsum[0] / max(stepsum[2], 1)
                 else:
-                    rhs = 4 * spec.substeps
+                    rhs = (11 if spec.integrator == "cv8" else 4) * spec.substeps
                 fl = flops_per_env_step(spec.model.name, spec.nx, spec.integrator, att, spec.substeps) * B
                 tf = fl / kern_avg_s / 1e12
                 rl.update(bound="fp64_valu", achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
@@ -668,7 +673,9 @@ def main():
                                         "at 10 (instruction-level cost of the transcendentals); SURVEY.md section 8(a) counts "
                                         f"every operation once: {f_survey} flop -> frac_at_survey_flop_count")
                 if f_survey is not None:
-                    rl["frac_at_survey_flop_count"] = rl["frac"] * (4 * spec.substeps * (f_survey + 12 * spec.nx) * B) / fl
+                    fs = (spec.substeps * (11 * f_survey + 120 * spec.nx) if spec.integrator == "cv8" else
+                          4 * spec.substeps * (f_survey + 12 * spec.nx))
+                    rl["frac_at_survey_flop_count"] = rl["frac"] * (fs * B) / fl
             out["roofline"] = rl
             out["config"]["launch"] = ("eager pcg_step launches" if graph is None else
                                        f"HIP graph of one {last_t}-step episode (pcg_graph_*)")

@@ -69,6 +69,31 @@ def test_default_plans():
     assert _spec("four_tank_canonical", integrator="rk4").substeps == 5  # the round-2/3 plan stays an opt-in
     with pytest.raises(ValueError):
         _spec("four_tank_canonical", integrator="tsit5g")
+    c = _spec("cryst_adelta")
+    assert c.integrator == "cv8" and c.substeps == 4 and _spec("cryst_adelta", integrator="rk4").substeps == 32
+
+
+def test_cv8_four_steps_per_cryst_step_match_rk4x32():
+    """crystallization over its action box: CV8 x 4 (44 right-hand sides) is in the accuracy class of RK4 x 32 (128)"""
+    rng = np.random.default_rng(0)
+    B = 3000
+    ref = _spec("cryst_adelta", integrator="dopri5", rtol=1e-13, atol=1e-13)
+    cv, rk = _spec("cryst_adelta"), _spec("cryst_adelta", integrator="rk4")
+    lo, hi = np.array(ref.a_act_low), np.array(ref.a_act_high)
+    orc = O.OracleEnv(ref, B, seed=1)
+    orc.reset()
+    worst = [0.0, 0.0]
+    for t in range(ref.N - 1):
+        x = orc.x.copy()
+        orc.step(rng.uniform(-1, 1, (ref.na, B)))
+        if t % 4:
+            continue
+        u = rng.uniform(lo[:, None], hi[:, None], (len(lo), B))
+        want, _ = O.integrate(ref, x, u)
+        for i, s in enumerate((cv, rk)):
+            got, _ = O.integrate(s, x, u)
+            worst[i] = max(worst[i], float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-9 * np.abs(want).max(axis=1, keepdims=True)))))
+    assert worst[0] <= 5e-8 and worst[1] <= 2e-7, worst
 
 
 def test_cv8_one_step_per_four_tank_step_beats_rk4x5():
