@@ -288,16 +288,18 @@ typedef struct pcg_env_cfg {
    *   user_reward_src  ONE expression of type double over  o[] = the (noisy) physical observation vector the reference
    *                    hands to custom_reward, x[] = the noise-free state vector, u[] = uk, sp[] = SP_k[t] at the new t,
    *                    violated (0/1), t (new step counter), N.  Replaces the built-in reward.
-   * Available in the one-env-per-lane general kernel only (any integrator, lock-stepped or per-env counters); not with
-   * per-env uncertain parameters, pcg_rollout or pcg_graph.  Math: exp log sqrt pow fabs fmin fmax sin cos tanh. */
+   * Available in the one-env-per-lane general kernel only (any integrator, lock-stepped or per-env counters) and in
+   * pcg_rollout (the run-time compiled module carries its own fused rollout kernel; not for the Rosenbrock integrators,
+   * whose matrices live in LDS); not with per-env uncertain parameters or pcg_graph.  Math: exp log sqrt pow fabs fmin
+   * fmax sin cos tanh. */
   const char* user_cons_src;
   const char* user_reward_src;
   const char* jit_include_dir;  /* directory holding pcg_kernels.hpp and its siblings (the library's own csrc/)      */
   /* PCG_MODEL_USER: the model's right-hand side (the reference's custom_model.__call__(x, u), pcgym.py:150-153) as C
    * statements that fill dx[0 .. nx-1] (double) from x[] (nx states), u[] (na inputs, then ndm disturbance inputs) and
    * p[] (n_params parameters = cfg.params).  Compiled with hipRTC into this plan's general step kernel (both time
-   * modes), pcg_integrate and pcg_rhs; any integrator; composes with user_cons_src / user_reward_src.  Not available:
-   * pcg_rollout, per-env uncertain parameters. */
+   * modes), pcg_integrate, pcg_rhs and pcg_rollout (the last not for PCG_INT_RODAS3 / PCG_INT_RODAS4); any integrator;
+   * composes with user_cons_src / user_reward_src.  Not available: per-env uncertain parameters. */
   const char* user_rhs_src;
   /* PCG_INT_RODAS4, end-point error control (see enum pcg_integrator): 0 / 0 = classical local error control */
   double ep_frac;         /* fraction of the model's contraction rate credited to the damping (0.5 by default: the cascade

@@ -107,6 +107,7 @@ struct pcg_plan {
   int cfg_nu;        // na + ndm as the caller counts them
   hipFunction_t jit_fn[2];  // run-time compiled general step kernel with user expressions [per_env_t] (or null)
   hipFunction_t jit_integ, jit_rhs;  // PCG_MODEL_USER: the run-time compiled test hooks (pcg_integrate / pcg_rhs)
+  hipFunction_t jit_roll;            // run-time compiled fused rollout of a plan with user expressions (or null)
   int nx;                   // states (the kernel table's for built-in models, the cfg's for PCG_MODEL_USER)
 };
 static constexpr uint32_t PLAN_MAGIC = 0x50434731u;  // 'PCG1'
@@ -419,6 +420,7 @@ static int kernel_id_for(const pcg_env_cfg* c) {
 struct JitModule {
   hipFunction_t fn[2];      // step_kernel [per_env_t]
   hipFunction_t integ, rhs; // PCG_MODEL_USER only
+  hipFunction_t roll;       // fused rollout kernel (null for the Rosenbrock integrators: their matrices live in LDS)
 };
 static std::mutex g_jit_mu;
 static std::map<uint64_t, JitModule> g_jit_cache;
@@ -570,8 +572,10 @@ static int jit_kernels(const pcg_env_cfg* cfg, int kid, int device, JitModule* o
     src << "__device__ double pcg_user_reward(const double* o, const double* x, const double* u, const double* sp, "
            "int violated, int t, int N) {\n  return (double)(" << cfg->user_reward_src << ");\n}\n";
   src << "}\n";
-  const int nfn = user ? 4 : 2;
-  std::string names[4];
+  const bool roll = cfg->integrator_id != PCG_INT_RODAS3 && cfg->integrator_id != PCG_INT_RODAS4;
+  const int iroll = user ? 4 : 2;
+  const int nfn = iroll + (roll ? 1 : 0);
+  std::string names[5];
   for (int pe = 0; pe < 2; ++pe) {
     std::ostringstream nm;
     nm << "pcg::step_kernel<pcg::Model<" << kid << ">, " << cfg->integrator_id << ", " << (pe ? "true" : "false")
@@ -587,6 +591,12 @@ static int jit_kernels(const pcg_env_cfg* cfg, int kid, int device, JitModule* o
     names[3] = nr.str();
     src << "template __global__ void " << names[2] << "(pcg::CDevConst*, int64_t, int, double*, const double*, int32_t*);\n";
     src << "template __global__ void " << names[3] << "(pcg::CDevConst*, int64_t, int, const double*, const double*, double*);\n";
+  }
+  if (roll) {  // pcg_rollout for plans with user expressions: T steps with the state in registers
+    std::ostringstream nm;
+    nm << "pcg::rollout_kernel<pcg::Model<" << kid << ">, " << cfg->integrator_id << ", false>";
+    names[iroll] = nm.str();
+    src << "template __global__ void " << names[iroll] << "(const pcg::StepArgs);\n";
   }
   const std::string text = src.str();
   // The translation unit only says `#include "pcg_kernels.hpp"`: the CONTENT of the kernel headers it will be compiled
@@ -606,7 +616,7 @@ static int jit_kernels(const pcg_env_cfg* cfg, int kid, int device, JitModule* o
   char hex[40];
   std::snprintf(hex, sizeof(hex), "%016llx%016llx", (unsigned long long)fnv1a(ident), (unsigned long long)fnv1a_seed(ident, 0x9E3779B97F4A7C15ull));
   const std::string path = dir.empty() ? std::string() : dir + "/" + hex + ".pco";
-  std::string code, low[4];
+  std::string code, low[5];
   bool from_disk = !path.empty() && jit_cache_read(path, nfn, &code, low);
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (code.empty()) {
@@ -652,7 +662,8 @@ static int jit_kernels(const pcg_env_cfg* cfg, int kid, int device, JitModule* o
       return (int)le;
     }
     JitModule jm;
-    jm.integ = jm.rhs = nullptr;
+    jm.integ = jm.rhs = jm.roll = nullptr;
+    if (roll) HIP_TRY(hipModuleGetFunction(&jm.roll, mod, low[iroll].c_str()));
     for (int pe = 0; pe < 2; ++pe) HIP_TRY(hipModuleGetFunction(&jm.fn[pe], mod, low[pe].c_str()));
     if (user) {
       HIP_TRY(hipModuleGetFunction(&jm.integ, mod, low[2].c_str()));
@@ -692,7 +703,7 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   p->dC = nullptr;
   p->dsched = nullptr;
   p->jit_fn[0] = p->jit_fn[1] = nullptr;
-  p->jit_integ = p->jit_rhs = nullptr;
+  p->jit_integ = p->jit_rhs = p->jit_roll = nullptr;
   p->nx = cfg->nx;
   hipError_t e = hipGetDevice(&p->device);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&p->num_cus, hipDeviceAttributeMultiprocessorCount, p->device);
@@ -731,6 +742,7 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
     p->jit_fn[1] = jm.fn[1];
     p->jit_integ = jm.integ;
     p->jit_rhs = jm.rhs;
+    p->jit_roll = jm.roll;
     // Rosenbrock pairs keep nx^2 doubles per lane in LDS: past 48 KB per workgroup (nx >= 10) a kernel has to be told.
     // Decided HERE, so that a plan that cannot run says so at creation and not at its first step.
     const int jnx = cfg->model_id == PCG_MODEL_USER ? cfg->nx : kernels(p->kid).nx;
@@ -1141,7 +1153,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   const DevConst& c = p->hc;
   if ((c.flags & PCG_F_A_DELTA) && !io->a_save) return PCG_E_NULL;
   if ((c.flags & PCG_F_REWARD_TRACK) && !io->u_prev) return PCG_E_NULL;
-  if (c.nunc > 0 || p->jit_fn[0]) return PCG_E_UNSUPPORTED;  // parameter uncertainty / user expressions: per-step kernel only
+  if (c.nunc > 0 || (p->jit_fn[0] && !p->jit_roll)) return PCG_E_UNSUPPORTED;  // per-env parameters: per-step kernel only
   a.t_scalar = t0;
   a.seed = seed;
   a.T = T;
@@ -1152,6 +1164,11 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   a.o_ss = obs_step_stride; a.o_cs = obs_comp_stride;
   a.r_ss = rew_step_stride;
   if (a.a_cs < io->B || (obs_seq && a.o_cs < io->B)) return PCG_E_DIM;
+  if (p->jit_fn[0]) {  // run-time compiled rollout kernel with the plan's user expressions (general step, one env per lane)
+    void* argv[1] = {&a};
+    const int jb = tb(false, p->integrator_id);
+    return (int)hipModuleLaunchKernel(p->jit_roll, grid_for(io->B, jb), 1, 1, jb, 1, 1, 0, (hipStream_t)stream, argv, nullptr);
+  }
   const Kernels& k = kernels(p->kid);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
   const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH | PCG_F_REWARD_TRACK)) ||

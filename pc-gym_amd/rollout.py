@@ -80,8 +80,9 @@ def collect_rollouts(env, policy=None, actions=None):
     obs, _ = env.reset()
     # the fused rollout records observations and rewards, not the constraint rows; per-env parameters need the
     # per-step kernel; the 20-state DOPRI5 rollout kernel is slower than stepping (tools/rollout_probe.py)
+    # (user models: the run-time compiled module carries its own rollout kernel for the register-only integrators)
     fused_ok = (not s.ncon and not s.nunc and (s.integrator not in ("rodas3", "rodas4", "tsit5") or (s.integrator == "rodas4" and s.model.name == "multistage_extraction"))
-                and s.user_rhs_src is None
+                and (s.user_rhs_src is None or s.integrator in ("rk4", "cv8", "dopri5"))
                 and (s.integrator in ("rk4", "cv8") or s.nx <= 10))
     if actions is not None:
         actions = actions.to(device=dev, dtype=f64)

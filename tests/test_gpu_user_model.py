@@ -192,10 +192,16 @@ def test_user_model_facade_collector_and_errors():
     o, r, d, tr, info = env.step(np.array([0.2]))
     assert o.shape == (3,) and isinstance(float(r), float) and d is False or d is True or d in (0, 1)
     venv = VecEnv(copy.deepcopy(p), n_envs=128, seed=2)
-    with pytest.raises(PcgError):  # no fused rollout kernel for run-time compiled models ...
+    out = collect_rollouts(venv, actions=torch.zeros((30, 1, 128), dtype=torch.float64, device=venv.device))
+    assert torch.isfinite(out["x"]).all() and out["x"].shape == (3, 30, 128)
+    venv.close()
+    stiff = _chemostat_params(integrator="rodas3", rtol=1e-6, atol=1e-8)  # Rosenbrock matrices live in LDS: per-step kernel only
+    venv = VecEnv(stiff, n_envs=128, seed=2)
+    venv.reset()
+    with pytest.raises(PcgError):
         venv.rollout(torch.zeros((3, 1, 128), dtype=torch.float64, device=venv.device))
     out = collect_rollouts(venv, actions=torch.zeros((30, 1, 128), dtype=torch.float64, device=venv.device))  # ... it steps
-    assert torch.isfinite(out["x"]).all() and out["x"].shape == (3, 30, 128)
+    assert torch.isfinite(out["x"]).all()
     venv.close()
     bad = _chemostat_params()
     bad["custom_model"]["rhs"][0] = "(mu - D)*Xx"  # unknown name: rejected before any compiler sees it
@@ -512,4 +518,58 @@ def test_coupled_oscillators_of_any_ring_size(N):
     xe = env.x.cpu().numpy()
     energy = 0.5 * (xe[N:] ** 2).sum(0) / m.m + 0.5 * m.k * ((xe[:N] - np.roll(xe[:N], 1, axis=0)) ** 2).sum(0)
     assert np.max(np.abs(energy - energy0) / energy0) <= 1e-7
+    env.close()
+
+
+@pytest.mark.parametrize("integrator", ["rk4", "dopri5", "cv8"])
+def test_fused_rollout_of_a_user_model_matches_stepping(integrator):
+    """pcg_rollout on PCG_MODEL_USER: the run-time compiled module carries the rollout kernel (state in registers for T
+    steps) -- same observations, rewards and final state as T pcg_step launches"""
+    torch = _torch()
+    from pcgym_amd import VecEnv
+
+    p = _chemostat_params(integrator=integrator)
+    if integrator != "dopri5":
+        p["substeps"] = 6
+    B = 700
+    env = VecEnv(p, n_envs=B, seed=3)
+    N = env.spec.N
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    acts = 2 * torch.rand((N - 1, 1, B), generator=gen, device="cuda", dtype=torch.float64) - 1
+    env.reset()
+    obs_seq, rew_seq = env.rollout(acts, collect_obs=True)
+    x_roll = env.x.clone()
+    env.reset()
+    for t in range(N - 1):
+        o, r, d, _, _ = env.step(acts[t])
+        assert torch.allclose(env.obs_soa, obs_seq[t], rtol=1e-12, atol=1e-13), t
+        assert torch.allclose(r, rew_seq[t], rtol=1e-11, atol=1e-13), t
+    assert torch.allclose(env.x, x_roll, rtol=1e-12, atol=1e-14) and bool(d.all())
+    env.close()
+
+
+def test_fused_rollout_with_a_reward_expression_matches_stepping():
+    """a built-in model whose plan carries a user reward expression: pcg_rollout goes through the run-time compiled kernel"""
+    torch = _torch()
+    from pcgym_amd import VecEnv
+
+    p = copy.deepcopy(SC.scenarios()["cstr_expr_reward_q3"]["env_params"]) if "cstr_expr_reward_q3" in SC.scenarios() else None
+    if p is None:
+        pytest.skip("scenario missing")
+    p.pop("constraints", None), p.pop("done_on_cons_vio", None), p.pop("r_penalty", None)
+    B = 512
+    env = VecEnv(p, n_envs=B, seed=5)
+    N = env.spec.N
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    acts = 2 * torch.rand((N - 1, env.spec.na, B), generator=gen, device="cuda", dtype=torch.float64) - 1
+    if not env.spec.normalise_a:
+        lo, hi = torch.tensor(env.spec.a_low, device="cuda")[None, :, None], torch.tensor(env.spec.a_high, device="cuda")[None, :, None]
+        acts = lo + (acts + 1) / 2 * (hi - lo)
+    env.reset()
+    obs_seq, rew_seq = env.rollout(acts, collect_obs=True)
+    env.reset()
+    for t in range(N - 1):
+        o, r, d, _, _ = env.step(acts[t])
+        assert torch.allclose(env.obs_soa, obs_seq[t], rtol=1e-11, atol=1e-12), t
+        assert torch.allclose(r, rew_seq[t], rtol=1e-10, atol=1e-12), t
     env.close()
