@@ -312,14 +312,23 @@ def committed_pmc(workload):
 
 def clock_preheat(torch, dev, ms):
     """Untimed, workload-independent GPU busy loop: an idle MI355X needs ~50 ms of work to reach steady clocks.
-    Uses a plain torch matmul, NOT the bench's own launches, so that `warmup` is exactly the warm-up that ran."""
+    Plain torch operations, NOT the bench's own launches, so that `warmup` is exactly the warm-up that ran: a matmul (core
+    clock) and a 256 MB streaming copy (memory / fabric clocks: the headline kernel is HBM-bound) alternate."""
     if ms <= 0:
         return 0.0
+    import os
+
+    mode = os.environ.get("PCG_BENCH_PREHEAT", "both")  # experiment switch: matmul | copy | both
     a = torch.randn((2048, 2048), device=dev, dtype=torch.float32)
+    src = torch.empty(32 << 20, device=dev, dtype=torch.float64)
+    dst = torch.empty_like(src)
     t0 = time.perf_counter()
     while (time.perf_counter() - t0) * 1e3 < ms:
         for _ in range(20):
-            a = torch.tanh(a @ a * 1e-3)
+            if mode != "copy":
+                a = torch.tanh(a @ a * 1e-3)
+            if mode != "matmul":
+                dst.copy_(src)
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) * 1e3
 
