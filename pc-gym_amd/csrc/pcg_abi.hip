@@ -893,6 +893,10 @@ static int queue_geometry(pcg_plan* p, const Kernels& k, int pe, size_t sched_by
     // (the whole CU's LDS: a launch may also park its tile's state there when that fits, see step_impl)
     e = hipFuncSetAttribute((const void*)qfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
     if (e != hipSuccess) return (int)e;
+    if (p->integrator_id == PCG_INT_RODAS4 && k.queue_r4w1[pe]) {
+      e = hipFuncSetAttribute((const void*)k.queue_r4w1[pe], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
+      if (e != hipSuccess) return (int)e;
+    }
   }
   return PCG_OK;
 }
@@ -1007,7 +1011,14 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       // explicit pair (profiles/r3/queue_prio_sweep.txt).
       a.q_prio = r4q ? 128 : 0;
       if (const char* ev = std::getenv("PCG_Q_PRIO")) a.q_prio = std::atoi(ev);  // measurement switch: issue priority
-      const int q_bpc = p->q_bpc[pe];
+      // Rodas4, launches of at most ~one full tile per CU (measured: 1024 envs per CU 0.361 -> 0.337 ms; 1366 per CU no
+      // difference; 4096 per CU 1.47 -> 1.71 ms): ONE workgroup per CU on the instantiation that keeps the whole loop in
+      // registers, every wave alone on its SIMD
+      bool w1 = r4q && k.queue_r4w1[pe] && p->q_tile1[pe] >= QBLOCK && io->B <= (int64_t)p->num_cus * 1200 &&
+                io->B > (int64_t)p->num_cus * QBLOCK;
+      if (const char* ev = std::getenv("PCG_Q_W1")) w1 = w1 && std::atoi(ev) != 0;  // measurement switch
+      if (w1) a.q_tile = (a.q_tile & ~0xFFFF) | p->q_tile1[pe];
+      const int q_bpc = w1 ? 1 : p->q_bpc[pe];
       int64_t nwg = (int64_t)p->num_cus * q_bpc;
       const int64_t cap = (io->B + QBLOCK - 1) / QBLOCK;  // no workgroup with less than one env per lane
       if (nwg > cap) nwg = cap;
@@ -1033,7 +1044,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
         a.q_tile |= 0x20000;
         qsh = k.queue_lds_x(Tq) + sb;
       }
-      hipLaunchKernelGGL(qtab[pe], dim3((unsigned)nwg), dim3(QBLOCK), qsh, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(w1 ? k.queue_r4w1[pe] : qtab[pe], dim3((unsigned)nwg), dim3(QBLOCK), qsh, (hipStream_t)stream, a);
       return (int)hipGetLastError();
       }
     }

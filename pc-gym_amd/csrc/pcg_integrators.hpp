@@ -927,7 +927,7 @@ PCG_DEV bool rodas4_try(const F& f, const LS& ls, const double (&x)[NX], const d
                         double (&xn)[NX], double (&err)[NX]) {
 #pragma clang fp contract(off)
   // gamma = 1/4: 1 / (gamma h) == 4 (1 / h) bit for bit (scaling by a power of two commutes with rounding): one division
-  const double ih = 1.0 / h, igh = 4.0 * ih;
+  const double ih = rcp_ieee(h), igh = 4.0 * ih;  // (h is a positive normal number: == 1.0 / h)
   static_assert(r4::GAM == 0.25, "igh = 4 / h");
   const bool lu_ok = ls.factor(x, f0, igh);
   double U1[NX], U2[NX], U3[NX], U4[NX], U5[NX], y[NX], fy[NX];

@@ -1662,6 +1662,7 @@ struct Kernels {
   StepFn step_unc[PCG_INT_COUNT][2]; // per-env parameter uncertainty [integrator][per_env_t] (null for affine)
   StepFn queue[2];                   // DOPRI5 with the in-workgroup work queue [per_env_t] (null for affine)
   StepFn queue_r4[2];                // Rodas4 through the same work queue [per_env_t] (models with structured W only)
+  StepFn queue_r4w1[2];              // ... compiled for ONE workgroup per CU (no register spills in the loop)
   bool ros_structured;               // Rodas4 runs in registers (launch shape of the explicit adaptive pair)
   bool queue_default;                // route adaptive plans to it unless told otherwise (models with a cost key)
   size_t (*queue_lds)(int);          // LDS bytes of a tile of T slots
@@ -1730,6 +1731,8 @@ Kernels make_kernels() {
   if constexpr (ros_structured<M>::value && !M::DYNAMIC) {
     k.queue_r4[0] = step_kernel_queue<M, false, true, PCG_INT_RODAS4>;
     k.queue_r4[1] = step_kernel_queue<M, true, true, PCG_INT_RODAS4>;
+    k.queue_r4w1[0] = step_kernel_queue<M, false, true, PCG_INT_RODAS4, 1>;
+    k.queue_r4w1[1] = step_kernel_queue<M, true, true, PCG_INT_RODAS4, 1>;
     // registers only: the fused rollout works as for the explicit pair (64-thread workgroups, no LDS)
     k.rollout[PCG_INT_RODAS4][0] = k.rollout[PCG_INT_RODAS4][1] = rollout_kernel<M, PCG_INT_RODAS4, false>;
   }

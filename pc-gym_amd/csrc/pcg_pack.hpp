@@ -117,6 +117,17 @@ PCG_PK double rcp_fast(double x) {
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   return r;
 }
+// 1/x CORRECTLY ROUNDED for a finite, normal x whose reciprocal is normal too: the arithmetic core of the compiler's IEEE
+// division (estimate, two Newton steps, quotient residual, final fused correction) without the operand scaling
+// (v_div_scale x2) and the special-case fix-up (v_div_fixup) that bracket it -- 6 dependent instructions instead of 10.
+// Bit-identical to `1.0 / x` on such arguments (the bit-exact Rodas4 parity tests against the oracle's `1.0 / x` hold it
+// to that); zero, infinite or NaN arguments give NaN where the division gives inf / 0 (callers reject those steps anyway).
+PCG_PK double rcp_ieee(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
 // a/b to ~0.5 ulp: Newton reciprocal, then one residual correction of the quotient (8 instructions)
 PCG_PK double div_fast(double a, double b) {
   const double r = rcp_fast(b);

@@ -328,8 +328,11 @@ struct QLayout {
   PCG_HD static size_t bytes_x(int T) { return bytes(T) + sizeof(double) * (size_t)M::NX * T; }
 };
 
-template <class M, bool PER_ENV_T, bool EXTRAS, int INTEG = PCG_INT_DOPRI5>
-__global__ __launch_bounds__(QBLOCK, wpe(M::NX, PCG_INT_DOPRI5, false)) void step_kernel_queue(const StepArgs A) {  // wpe = waves per SIMD = workgroups per CU
+// WAVES: waves per SIMD = workgroups per CU the register allocator is asked to leave room for (0 = the model's default,
+// wpe()).  The Rosenbrock loop wants ~316 registers: at two waves per SIMD it spills 34 scratch accesses per attempt, at
+// one (256 VGPRs + AGPRs) none -- the instantiation for launches that fit ONE tile per CU (me10 at B = 2^18: 0.361 -> 0.337 ms)
+template <class M, bool PER_ENV_T, bool EXTRAS, int INTEG = PCG_INT_DOPRI5, int WAVES = 0>
+__global__ __launch_bounds__(QBLOCK, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, false)) void step_kernel_queue(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   static_assert(!M::DYNAMIC, "the work-queue kernel is built for the fixed-size models");
   CDevConst& c = *A.C;
