@@ -23,7 +23,8 @@ launch, pcg_step_autoreset).  value = total env-steps / wall time (max over rank
   me20       the 20-state reactive variant, same protocol
   cryst      configs[3]: crystallization B = 262,144, RK4 x32 per dt = 1, a_delta on
   mixed      configs[4], one shard: 1,048,572 envs = 349,524 each of cstr + Ti ~ N(350, 2) / four_tank /
-             multistage_extraction + X0 ~ N(0.6, 0.02), set-point step changes, three plans on three streams;
+             multistage_extraction + X0 ~ N(0.6, 0.02), set-point step changes, three plans on three streams, each episode
+             of a segment replayed as one HIP graph (pcg_graph_*; --eager: plain launches);
              --gpus 8 = 8,388,576 envs (weak scaling, global env index keys the RNG)
 
 Multi-GPU: the env batch shards embarrassingly (weak scaling, B per GPU fixed); no collective on the hot path --
@@ -364,7 +365,9 @@ def main():
     ap.add_argument("--separate-reset", action="store_true",
                     help="end each episode with a separate pcg_reset launch instead of the fused pcg_step_autoreset (A/B)")
     ap.add_argument("--graph", action="store_true",
-                    help="cstr workload: replay whole episodes as one HIP graph (pcg_graph_*) instead of eager launches")
+                    help="replay whole episodes as HIP graphs (pcg_graph_*) instead of eager launches (the mixed workload "
+                         "does by default: one graph per segment and episode)")
+    ap.add_argument("--eager", action="store_true", help="mixed workload: eager pcg_step launches instead of the graphs")
     ap.add_argument("--substeps", type=int, default=None,
                     help="cstr workload: RK4 sub-steps per env step (1 = the headline; other values are probes)")
     ap.add_argument("--status", type=int, default=1, help="write the per-env status byte (0 = off, A/B)")
@@ -443,10 +446,32 @@ def main():
         N = envs[0].N
         assert all(e.N == N for e in envs)
 
+        # --graph: one HIP graph per segment = a reset + a whole episode of step launches on that segment's stream
+        # (pcg_graph_*); the timed region replays them -- same kernels, no launch-to-launch gaps
+        graphs = None
+        if not args.eager and K % (N - 1) == 0:
+            graphs = [e.capture_steps([a[j % n_act] for j in range(N - 1)], with_reset=True) for e, a in zip(envs, acts)]
+        graph_steps = [0]
+
         def run(n, timed):
             # actions are resident and nothing consumes the outputs between steps (as for the single-model workloads,
             # whose launches queue back to back on one stream): no cross-stream hand-shake per step, one join at the end
             menv.timing = timed
+            if graphs is not None and n % (N - 1) == 0:
+                for ep in range(n // (N - 1)):
+                    for i, (g, st) in enumerate(zip(graphs, menv.streams)):
+                        with torch.cuda.stream(st):
+                            if timed:
+                                eb, ee = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                                eb.record(st)
+                            g.replay()
+                            if timed:
+                                ee.record(st)
+                                menv._events[i].append((eb, ee))
+                if timed:
+                    graph_steps[0] = N - 1
+                menv.join()
+                return
             for i in range(n):
                 menv.step([a[i % n_act] for a in acts], join=False)
             menv.join()
@@ -594,7 +619,7 @@ def main():
         if mixed:
             segs_out = []
             for e, (tot_ms, n) in zip(envs, menv.segment_times()):
-                kern_s = tot_ms * 1e-3 / max(n, 1)
+                kern_s = tot_ms * 1e-3 / max(n * max(graph_steps[0], 1), 1)  # (a graph bracket holds a whole episode)
                 alg = float(e.bytes_per_env_step) * e.B
                 d = {"segment": e.spec.model.name, "envs": e.B, "integrator": e.spec.integrator,
                      "kernel_avg_us": kern_s * 1e6, "algorithmic_bytes_per_env_step": int(e.bytes_per_env_step),
@@ -606,6 +631,8 @@ def main():
                     d.update(attempted_steps_mean=att, fp64_TFLOPs=fl / kern_s / 1e12,
                              fp64_frac=fl / kern_s / 1e12 / FP64_PEAK_TFLOPS)
                 segs_out.append(d)
+            out["config"]["launch"] = ("eager pcg_step launches, one stream per segment" if graphs is None else
+                                       "one HIP graph per segment and episode (reset + 59 steps, pcg_graph_*), one stream per segment")
             pmx = committed_pmc("mixed") if B == (1 << 20) and not args.integrator else None
             if pmx:
                 for d in segs_out:

@@ -37,7 +37,7 @@ def test_single_rank_line():
     assert d["config"]["ranks_seen"] == 1
 
 
-@pytest.mark.parametrize("wl,batch,steps", [("mixed", 30000, 8), ("me10", 8192, 6), ("me10_ros4", 8192, 6), ("cryst", 8192, 6), ("four_tank", 65536, 20)])
+@pytest.mark.parametrize("wl,batch,steps", [("mixed", 30000, 8), ("mixed", 30000, 59), ("me10", 8192, 6), ("me10_ros4", 8192, 6), ("cryst", 8192, 6), ("four_tank", 65536, 20)])
 def test_other_workloads_line(wl, batch, steps):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--batch", str(batch), "--steps",
                         str(steps), "--warmup", "2", "--preheat-ms", "10", "--no-cpu-baseline"], capture_output=True,
@@ -51,6 +51,7 @@ def test_other_workloads_line(wl, batch, steps):
     if wl == "mixed":
         assert [s["segment"] for s in rf["segments"]] == ["cstr", "four_tank", "multistage_extraction"]
         assert d["config"]["envs_per_gpu"] == 3 * ((batch // 3) & ~1)
+        assert ("graph" in d["config"]["launch"]) == (steps % 59 == 0)  # whole episodes replay as one graph per segment
 
 
 def _free_port():
