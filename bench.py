@@ -367,6 +367,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay whole episodes as HIP graphs (pcg_graph_*) instead of eager launches (the mixed workload "
                          "does by default: one graph per segment and episode)")
+    ap.add_argument("--work-queue", action="store_true",
+                    help="single-model adaptive workloads: route the plan through the in-workgroup work queue whatever the "
+                         "model (PCG_OPT_VARIANT 5), e.g. --workload cstr_safe --integrator dopri5 --work-queue")
     ap.add_argument("--eager", action="store_true", help="mixed workload: eager pcg_step launches instead of the graphs")
     ap.add_argument("--substeps", type=int, default=None,
                     help="cstr workload: RK4 sub-steps per env step (1 = the headline; other values are probes)")
@@ -486,7 +489,7 @@ def main():
             wl_name = wl_name.replace("dopri5_1e-8", args.integrator)
         if args.integrator and args.workload in ("four_tank", "cstr_safe"):
             params["integrator"] = args.integrator
-            wl_name = wl_name.replace("cv8x1", args.integrator).replace("(tsit5g)", "(" + args.integrator + ")")
+            wl_name = wl_name.replace("cv8x1", args.integrator).replace("default-plan(tsit5g)", "plan(" + args.integrator + ")")
         B = args.batch or Bd
         K = args.steps if args.steps is not None else Kd
         W = args.warmup if args.warmup is not None else Wd
@@ -494,7 +497,9 @@ def main():
             params["substeps"] = args.substeps
         # shard: rank r owns global envs [r*B, (r+1)*B)  (weak scaling; RNG streams keyed by global index)
         env = VecEnv(params, n_envs=B, device=dev, seed=1234, auto_reset=True, env_offset=rank * B,
-                     track_status=bool(args.status))
+                     track_status=bool(args.status), variant=(5 if args.work_queue else None))
+        if args.work_queue:
+            wl_name += "+work-queue"
         B_eff = B
         spec = env.spec
         acts = act_box(spec) * (2 * torch.rand((n_act, spec.na, B), generator=gen, device=dev, dtype=torch.float64) - 1) \

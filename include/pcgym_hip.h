@@ -397,7 +397,12 @@ PCG_API int pcg_plan_set_env_offset(pcg_plan* plan, int64_t env_offset);
                                  (64-thread workgroups) instead of VGPRs; default 0           */
 #define PCG_OPT_VARIANT 3     /* step-kernel selection: 0 auto (default), 1 classic one-env-per-lane
                                  grid, 2 streaming persistent kernel 1 env/lane, 3 streaming 2 envs/lane
-                                 (16 B per lane accesses); non-auto values are for A/B measurement      */
+                                 (16 B per lane accesses), 4 software-pipelined lean kernel; 5 = the in-workgroup
+                                 WORK QUEUE for an adaptive plan of any model (by default only models with a cost
+                                 key, the extraction columns, go through it): pays when the step counts of a batch
+                                 are heavy-tailed -- cstr envs on the ignition branch under PCG_INT_DOPRI5: 572 ->
+                                 451 us per 2^20-env step; costs when they are not (canonical cstr loop: 38 -> 90 us).
+                                 1-4 are for A/B measurement                                                     */
 #define PCG_OPT_STREAM_BLOCKS_PER_CU 4 /* streaming kernel: resident workgroups per CU (0 = occupancy query) */
 #define PCG_OPT_NT_STORES 5   /* streaming kernel: non-temporal stores for obs / reward (not re-read by the step) */
 PCG_API int pcg_plan_set_option(pcg_plan* plan, int option, int64_t value);

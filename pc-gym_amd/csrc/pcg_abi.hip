@@ -796,7 +796,7 @@ int pcg_plan_set_option(pcg_plan* p, int option, int64_t value) {
     case PCG_OPT_STREAM_BLOCKS_PER_CU: p->stream_bpc = (int)value; return PCG_OK;
     case PCG_OPT_NT_STORES: p->nt_stores = value ? 1 : 0; return PCG_OK;
     case PCG_OPT_VARIANT:
-      if (value < 0 || value > 4) return PCG_E_VALUE;
+      if (value < 0 || value > 5) return PCG_E_VALUE;
       p->variant = (int)value;
       return PCG_OK;
     default: return PCG_E_VALUE;
@@ -988,8 +988,9 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   // PCG_OPT_VARIANT 1 keeps the classic one-env-per-lane kernel (A/B measurement), PCG_OPT_LDS_STAGES too.
   const bool r4q = p->integrator_id == PCG_INT_RODAS4;
   const StepFn* qtab = r4q ? k.queue_r4 : k.queue;
-  if ((p->integrator_id == PCG_INT_DOPRI5 || r4q) && !lds_st && p->variant == 0 && qtab[per_env_t ? 1 : 0] &&
-      (k.queue_default || std::getenv("PCG_Q_FORCE") != nullptr)) {
+  const bool q_forced = p->variant == 5 || std::getenv("PCG_Q_FORCE") != nullptr;  // PCG_OPT_VARIANT 5: any model
+  if ((p->integrator_id == PCG_INT_DOPRI5 || r4q) && !lds_st && (p->variant == 0 || p->variant == 5) && qtab[per_env_t ? 1 : 0] &&
+      (k.queue_default || q_forced)) {
     const int pe = per_env_t ? 1 : 0;
     const size_t sb = (per_env_t && a.sched_in_lds) ? sizeof(double) * (size_t)(c.nsp + c.nd) * c.N : 0;
     rc = queue_geometry(p, k, pe, sb);
@@ -1029,7 +1030,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       int Tq = a.q_tile & 0xFFFF;
       const int64_t nsub = (per + Tq - 1) / Tq;
       const int64_t sub = (per + nsub - 1) / nsub;
-      const bool filled = sub >= (7 * QBLOCK) / 4 || std::getenv("PCG_Q_FORCE") != nullptr;
+      const bool filled = sub >= (7 * QBLOCK) / 4 || q_forced;
       if (filled) {
       // LDS for the sub-tile this launch actually walks, not for the largest one the plan could (the kernel derives the
       // same number of sub-tiles from the smaller stride); the tile's state goes to LDS too when that still leaves room
@@ -1060,10 +1061,10 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   const int ls = lean_scheme(p->integrator_id);  // fixed-step schemes with a lean pipelined kernel (RK4, CV8)
   const StepFn* const pipe = ls >= 0 ? k.pipe[ls] : nullptr;
   const bool stream_ok = ls >= 0 || p->variant == 2 || p->variant == 3;
-  const bool lean_ar_ok = !auto_reset || ((p->variant == 4 || p->variant == 0) && pipe && pipe[0]);
+  const bool lean_ar_ok = !auto_reset || ((p->variant == 4 || p->variant == 0 || p->variant == 5) && pipe && pipe[0]);
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto al2 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 1u) == 0; };
-  const bool pipe_ok = (p->variant == 4 || p->variant == 0) && pipe && pipe[0];
+  const bool pipe_ok = (p->variant == 4 || p->variant == 0 || p->variant == 5) && pipe && pipe[0];
   if (!per_env_t && !extras && !lds_st && !io->viol && (!io->status || pipe_ok) && p->variant != 1 && stream_ok && lean_ar_ok &&
       (k.stream[p->integrator_id][0] || pipe_ok)) {
     const bool epl2_ok = (k.stream[p->integrator_id][1] || (pipe_ok && pipe[1])) && (io->B % 2 == 0) && al16(io->x) &&
@@ -1097,7 +1098,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   // Feature-masked pipelined kernel (pcg_step_feat.hpp): RK4 plans of the small models with anything beyond the
   // lean step switched on.  Needs two envs per lane (even B, 16-byte rows); the smallest instantiation whose mask
   // covers what this launch uses is taken.  PCG_OPT_VARIANT 1 forces the classic one-env-per-lane kernel (A/B).
-  if (p->integrator_id == PCG_INT_RK4 && k.nfeat > 0 && !lds_st && (p->variant == 0 || p->variant == 4)) {
+  if (p->integrator_id == PCG_INT_RK4 && k.nfeat > 0 && !lds_st && (p->variant == 0 || p->variant == 4 || p->variant == 5)) {
     unsigned need = 0;
     if (c.ncon > 0) need |= FT_CONS;
     if (c.flags & PCG_F_A_DELTA) need |= FT_ADELTA;

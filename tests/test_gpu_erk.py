@@ -228,3 +228,28 @@ def test_guarded_plans_closed_loop_is_never_escalated_and_matches_tight(integrat
         orc.x[:] = env.x[:, :2048].cpu().numpy()  # one-step errors
     assert worst <= 1e-6, worst
     env.close()
+
+
+def test_work_queue_option_on_a_model_without_cost_key():
+    """PCG_OPT_VARIANT 5: the adaptive pair of ANY model through the in-workgroup work queue (default only for the extraction
+    models) -- same step sequences and states as the classic one-env-per-lane kernel, on a batch with a heavy tail (cstr
+    over the ignition box)"""
+    torch = _torch()
+    from pcgym_amd import VecEnv
+
+    p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+    p.pop("noise", None), p.pop("noise_percentage", None)
+    p.update(x0=np.array([0.85, 330.0, 0.85]), uncertainty_percentages={"x0": [0.15 / 0.85, 20.0 / 330.0]}, integrator="dopri5")
+    B = 20000
+    q, c = VecEnv(p, n_envs=B, seed=4, variant=5), VecEnv(p, n_envs=B, seed=4, variant=1)
+    q.reset(), c.reset()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    tail = 0
+    for i in range(12):
+        a = 2 * torch.rand((1, B), generator=gen, device="cuda", dtype=torch.float64) - 1
+        oq, rq, dq, _, _ = q.step(a)
+        oc, rc, dc, _, _ = c.step(a)
+        assert torch.equal(q.nsteps, c.nsteps) and torch.equal(q.x, c.x) and torch.equal(rq, rc), i
+        tail = max(tail, int(q.nsteps.sum(dim=0).max()))
+    assert tail > 3 * int(q.nsteps.sum(dim=0).median())  # the tail is really there (ignition fronts)
+    q.close(), c.close()
