@@ -253,3 +253,47 @@ def test_work_queue_option_on_a_model_without_cost_key():
         tail = max(tail, int(q.nsteps.sum(dim=0).max()))
     assert tail > 3 * int(q.nsteps.sum(dim=0).median())  # the tail is really there (ignition fronts)
     q.close(), c.close()
+
+
+def test_full_size_default_plans_of_four_tank_and_cryst():
+    """BASELINE sizes under the round-3 default plans: four_tank B = 2^20 (one order-8 step, lean pipelined kernel) and
+    crystallization B = 2^18 (four order-8 steps, general kernel): lane independence under a permutation (bitwise), an
+    oracle slice to round-off, a tight solve of the slice inside the plan's accuracy class, physical state boxes."""
+    torch = _torch()
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+    from pcgym_amd.config import EnvSpec
+
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    for name, B, steps, tol_tight in (("four_tank_canonical", 1 << 20, 12, 1e-6), ("cryst_adelta", 1 << 18, 8, 1e-6)):
+        p = copy.deepcopy(SC.scenarios()[name]["env_params"])
+        env, env2 = VecEnv(p, n_envs=B, seed=3), VecEnv(p, n_envs=B, seed=3)
+        assert env.spec.integrator == "cv8"
+        env.reset(), env2.reset()
+        x0 = env.x * (1 + 0.02 * (2 * torch.rand(env.x.shape, generator=gen, device="cuda", dtype=torch.float64) - 1))
+        perm = torch.randperm(B, generator=gen, device="cuda")
+        env.x.copy_(x0), env2.x.copy_(x0[:, perm])
+        n_or = 2048
+        orc = O.OracleEnv(env.spec, n_or, seed=3)
+        pt = copy.deepcopy(p)
+        pt.update(integrator="dopri5", rtol=1e-13, atol=1e-13)
+        tru = O.OracleEnv(EnvSpec(pt), n_or, seed=3)
+        orc.reset(), tru.reset()
+        orc.x[:] = x0[:, :n_or].cpu().numpy()
+        tru.x[:] = orc.x
+        na = env.spec.na
+        for i in range(steps):
+            a = 1.5 * torch.rand((na, B), generator=gen, device="cuda", dtype=torch.float64) - 0.5  # (four_tank: levels stay positive)
+            o1, r1, d1, _, _ = env.step(a)
+            o2, r2, d2, _, _ = env2.step(a[:, perm].contiguous())
+            orc.step(a[:, :n_or].cpu().numpy()), tru.step(a[:, :n_or].cpu().numpy())
+            assert torch.equal(env.x[:, perm], env2.x) and torch.equal(r1[perm], r2), (name, i)
+        xg = env.x[:, :n_or].cpu().numpy()
+        sc = np.maximum(np.abs(orc.x), 1e-9 * np.abs(orc.x).max(axis=1, keepdims=True))
+        assert np.max(np.abs(xg - orc.x) / sc) <= 1e-11, name
+        st = np.maximum(np.abs(tru.x), 1e-9 * np.abs(tru.x).max(axis=1, keepdims=True))
+        assert np.max(np.abs(xg - tru.x) / st) <= tol_tight, (name, np.max(np.abs(xg - tru.x) / st))
+        assert bool(torch.isfinite(env.x).all()) and not env.status.any()
+        if name.startswith("four_tank"):
+            assert bool((env.x > 0).all()) and bool((env.x < 5.0).all())
+        env.close(), env2.close()
