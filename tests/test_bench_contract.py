@@ -37,7 +37,7 @@ def test_single_rank_line():
     assert d["config"]["ranks_seen"] == 1
 
 
-@pytest.mark.parametrize("wl,batch,steps", [("mixed", 30000, 8), ("mixed", 30000, 59), ("me10", 8192, 6), ("me10_ros4", 8192, 6), ("cryst", 8192, 6), ("four_tank", 65536, 20)])
+@pytest.mark.parametrize("wl,batch,steps", [("mixed", 30000, 8), ("mixed", 30000, 59), ("me10", 8192, 6), ("me10_ros4", 8192, 6), ("cryst", 8192, 6), ("cryst_cv8", 8192, 6), ("cstr_safe", 65536, 20), ("four_tank", 65536, 20)])
 def test_other_workloads_line(wl, batch, steps):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--batch", str(batch), "--steps",
                         str(steps), "--warmup", "2", "--preheat-ms", "10", "--no-cpu-baseline"], capture_output=True,
