@@ -134,16 +134,24 @@ def collect_rollouts(env, policy=None, actions=None):
 
 
 class reproducibility_metric:
-    """Same constructor / methods / dict shapes as the reference class
-    (evaluation_metrics.py:182-327), computed with torch on whatever device the data lives on.
-    The reductions run along the last axis (the reps / env axis)."""
+    """Same constructor / methods / dict shapes as the reference class (evaluation_metrics.py:182-327), computed with
+    torch on whatever device the data lives on.  The reductions run along the last axis (the reps / env axis).
 
-    def __init__(self, dispersion: str, performance: str, scalarised_weight: float):
+    Pinned to the reference's own outputs (tests/golden/metrics_ref.npz, generated by importing evaluation_metrics.py).
+    Quirk Q14 (`reference_compat=True`, the default): the reference's MAD subtracts the median WITHOUT keeping the reduced
+    axis (evaluation_metrics.py:127-130, "currently only works for the reward component"), so `data - median` follows
+    NumPy broadcasting: on (n, N, reps) data it raises unless N == reps (and then subtracts the median of another
+    time index), on the constraint component (N, 1, reps) it returns an (N, N) table, 1-D data is reshaped to (n, 1)
+    first.  All of that is reproduced, including the ValueError.  `reference_compat=False` gives the median absolute
+    deviation about each row's own median, for every shape."""
+
+    def __init__(self, dispersion: str, performance: str, scalarised_weight: float, reference_compat: bool = True):
         if dispersion not in ("std", "mad"):
             raise ValueError("Invalid dispersion metric")
         if performance not in ("mean", "median"):
             raise ValueError("Invalid performance metric")
         self.dispersion, self.performance, self.scalarised_weight = dispersion, performance, scalarised_weight
+        self.reference_compat = bool(reference_compat)
 
     @staticmethod
     def _median(t):
@@ -158,11 +166,20 @@ class reproducibility_metric:
         return t.mean(dim=-1) if self.performance == "mean" else self._median(t)
 
     def _disp(self, t):
-        torch = _torch()
         if self.dispersion == "std":
             return t.std(dim=-1, unbiased=False)  # np.std default (ddof = 0)
+        if not self.reference_compat:
+            return self._median((t - self._median(t).unsqueeze(-1)).abs())
+        if t.dim() < 2:  # evaluation_metrics.py:112-114
+            t = t.reshape(t.shape[0], 1)
         med = self._median(t)
-        return self._median((t - med.unsqueeze(-1)).abs())
+        try:
+            dev = t - med  # NumPy broadcasting of (.., reps) against (..): evaluation_metrics.py:127-130
+        except RuntimeError as e:
+            raise ValueError(f"operands could not be broadcast together with shapes {tuple(t.shape)} "
+                             f"{tuple(med.shape)} (the reference's MAD, evaluation_metrics.py:127-130: quirk Q14; "
+                             "reference_compat=False gives the deviation about each row's own median)") from e
+        return self._median(dev.abs())
 
     def _apply(self, fn, data, component):
         out = {k: {} for k in data}

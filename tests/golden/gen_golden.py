@@ -15,6 +15,9 @@ here (gymnasium, casadi, diffrax, jax, do_mpc, matplotlib), and records
                    by LSODA(rtol 1e-12) on the env's own model (zero-order hold on uk,
                    interval [0,dt] -- integrator.py:163-182)
 
+  metrics_ref.npz  outputs of the reference's reproducibility_metric (evaluation_metrics.py:81-327, numpy only) on
+                   small random rollout dictionaries, incl. the shapes on which its MAD raises or broadcasts (:127-130)
+
 Only data leaves this script (small .npz under tests/golden/); no reference source
 or bytecode is copied.  The script refuses to run when /root/reference is absent.
 """
@@ -324,7 +327,50 @@ def gen_steps(P, out, only_new=False):
         print(f"  step {name}: T={T} nobs={nobs} ncon={ncon} sum_r={rew.sum():.6g} done_at={int(np.argmax(done)) if done.any() else -1}")
 
 
+METRIC_CASES = [  # (name, {component: shape}); the last axis is the reps axis
+    ("n7_reps5", {"r": (1, 7, 5), "x": (3, 7, 5), "u": (1, 7, 5), "g": (2, 7, 1, 5)}),
+    ("n6_reps6", {"r": (1, 6, 6), "x": (2, 6, 6), "u": (2, 6, 6), "g": (3, 6, 1, 6)}),   # N == reps: MAD broadcasts
+    ("n1_reps4", {"r": (1, 1, 4), "x": (3, 1, 4), "u": (1, 1, 4)}),                      # N == 1
+    ("flat", {"r": (9,), "x": (4, 8)}),                                                  # 1-D (reshaped) and 2-D data
+    ("reps1", {"r": (1, 5, 1), "x": (2, 5, 1), "g": (2, 5, 1, 1)}),
+]
+
+
+def gen_metrics(out):
+    """The reference's own metric classes (evaluation_metrics.py, imported by path: numpy is its only dependency) on
+    seeded random data; a combination on which the reference raises is recorded as such (`<key>_raises`)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("ref_evaluation_metrics",
+                                                  os.path.join(REF_SRC, "pcgym", "evaluation_metrics.py"))
+    EM = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(EM)
+    rng = np.random.default_rng(20260929)
+    rec = {}
+    for name, shapes in METRIC_CASES:
+        data = {"pi": {c: rng.normal(size=sh) * (1 + 3 * rng.random()) for c, sh in shapes.items()}}
+        for c, v in data["pi"].items():
+            rec[f"{name}__in__{c}"] = v
+        for disp in ("std", "mad"):
+            for perf in ("mean", "median"):
+                m = EM.reproducibility_metric(disp, perf, -1.25)
+                for kind, fn in (("perf", m.policy_performance_metric), ("disp", m.policy_dispersion_metric),
+                                 ("scal", m.scalarised_performance)):
+                    for c in shapes:
+                        key = f"{name}__{disp}__{perf}__{kind}__{c}"
+                        try:
+                            rec[key] = np.asarray(fn(data, c)["pi"][c])
+                        except ValueError:
+                            rec[key + "_raises"] = np.int64(1)
+    np.savez(os.path.join(out, "metrics_ref.npz"), **rec)
+    n_raise = sum(1 for k in rec if k.endswith("_raises"))
+    print(f"  metrics_ref.npz: {len(rec)} arrays, {n_raise} combinations on which the reference raises")
+
+
 def main():
+    if "--metrics-only" in sys.argv:
+        gen_metrics(HERE)
+        return
     P, M = _import_reference()
     out = HERE
     only_new = "--only-new" in sys.argv  # keep committed fixtures untouched, add the missing ones
@@ -332,6 +378,7 @@ def main():
     if not only_new:
         print("paper trajectories"); gen_paper(out)
     print("full-step tuples"); gen_steps(P, out, only_new)
+    print("evaluation metrics"); gen_metrics(out)
     tot = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out) if f.endswith(".npz"))
     print(f"total fixture bytes: {tot}")
 

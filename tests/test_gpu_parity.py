@@ -470,6 +470,49 @@ def test_observation_noise_vs_oracle(name, B):
         e.close()
 
 
+@pytest.mark.parametrize("name,pct", [("cstr_canonical", {"T": 0.03}), ("four_tank_canonical", {"h2": 0.01, "h4": 0.04})])
+def test_per_state_noise_percentage_dict_vs_oracle(name, pct):
+    """noise_percentage as a per-state dict (pcgym.py:459-466): only the listed states are perturbed, each with its own
+    percentage; same Philox streams as the oracle; default dispatch and the forced general kernel agree."""
+    torch = _torch()
+    import copy
+
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    B = 4096
+    p = copy.deepcopy(SC.scenarios()[name]["env_params"])
+    _rk4_if_cstr(p)
+    p.update(noise=True, noise_percentage=dict(pct))
+    env = VecEnv(p, n_envs=B, seed=21, env_offset=3 * 10**9)
+    gen = VecEnv(p, n_envs=B, seed=21, env_offset=3 * 10**9, variant=1)
+    orc = O.OracleEnv(env.spec, B, seed=21, env_offset=3 * 10**9)
+    names = list(env.spec.model.states)
+    want_pct = np.array([pct.get(n, 0.0) for n in names])
+    assert np.array_equal(env.spec.noise_pct, want_pct)
+    for e in (env, gen, orc):
+        e.reset()
+    acts = _rand_actions(env.spec, 4, B, 2)
+    for i in range(4):
+        a = torch.tensor(acts[i], device=env.device)
+        og, rg, _, _, _ = env.step(a)
+        o2, r2, _, _, _ = gen.step(a)
+        oc, rc, _ = orc.step(acts[i])
+        assert np.max(np.abs(og.cpu().numpy().T - oc)) <= 1e-11, i
+        assert torch.allclose(og, o2, rtol=0, atol=1e-12) and torch.allclose(rg, r2, rtol=1e-12, atol=1e-12)
+        assert np.allclose(rg.cpu().numpy(), rc, rtol=1e-11, atol=1e-12)
+    lo, hi = env.spec.o_low[: env.spec.nx, None], env.spec.o_high[: env.spec.nx, None]
+    obs_phys = (og.cpu().numpy().T[: env.spec.nx] + 1) / 2 * (hi - lo) + lo
+    rel = obs_phys / env.x.cpu().numpy() - 1
+    for i, n in enumerate(names):
+        if n in pct:  # N(0, pct) relative perturbation
+            assert 0.85 * pct[n] < rel[i].std() < 1.15 * pct[n] and abs(rel[i].mean()) < 0.1 * pct[n], (n, rel[i].std())
+        else:  # untouched: the observation IS the (normalised) state
+            assert np.max(np.abs(rel[i])) <= 1e-12, n
+    for e in (env, gen):
+        e.close()
+
+
 def test_noise_and_gaussian_disturbance_vs_oracle():
     """counter-based RNG: same Philox stream on both sides -> same noise to ~1e-13"""
     torch = _torch()
