@@ -209,6 +209,9 @@ def cpu_baseline(spec, seconds_target=10.0, threads=None):
 
     one, _, _ = rate(1, 2.0)
     value, reps, dt = rate(cores, seconds_target)
+    # the same leg on EVERY logical CPU of the host (SURVEY.md section 8(d) asks for "all host cores"): the workload is
+    # memory-bound on the CPU too, so more threads than memory channels buy little -- both numbers are on the line
+    all_value, all_reps, all_dt = (value, reps, dt) if avail == cores else rate(avail, 4.0)
     # accuracy of the workload's integrator setting vs a tight adaptive solve, same starts
     p2 = dict(spec.env_params)
     p2.update(integrator="dopri5", rtol=1e-12, atol=1e-14)
@@ -251,6 +254,8 @@ def cpu_baseline(spec, seconds_target=10.0, threads=None):
         "unit": "env-steps/s",
         "cores": cores,
         "one_thread_env_steps_per_s": one,
+        "all_host_cpus": {"value": all_value, "unit": "env-steps/s", "cores": avail,
+                          "sample": f"{all_reps} steps x {Bs} envs, OpenMP over all {avail} logical CPUs ({all_dt:.1f} s)"},
         "host_cpu": cpu_model,
         "host_logical_cpus": os.cpu_count(),
         "kind": "port",
@@ -295,20 +300,28 @@ def x0_box(spec):
 _PMC = None
 
 
-def committed_pmc(workload):
-    """per-launch counters of this workload's dominant kernel from the committed rocprofv3 PMC passes (profiles/r3/pmc.json,
+def committed_pmc(workload, build_id):
+    """per-launch counters of this workload's dominant kernel from the committed rocprofv3 PMC passes (profiles/r*/pmc.json,
     made by tools/prof_all.sh + tools/pmc_json.py on the GPU box; FETCH_SIZE x 2 per MI355X_MICROARCH.md's gfx950 note).
-    NOT measured in this run: hardware counters cannot be read from inside the process."""
+    NOT measured in this run: hardware counters cannot be read from inside the process.  An entry is quoted only when it was
+    taken on THIS build of the library (pcg_build_id(): a digest of the kernel headers): -> (entry or None, reason)."""
     global _PMC
     if _PMC is None:
         _PMC = {}
-        for tp in ("profiles/r3/pmc.json",):
+        for tp in ("profiles/r4/pmc.json", "profiles/r3/pmc.json"):
             tpath = os.path.join(ROOT, tp)
             if os.path.exists(tpath):
                 with open(tpath) as fh:
                     _PMC = json.load(fh)
+                _PMC["__file__"] = tp
                 break
-    return _PMC.get(workload)
+    e = _PMC.get(workload)
+    if not e:
+        return None, "no committed counter pass for this workload"
+    if e.get("build_id") != build_id:
+        return None, (f"stale profile: {_PMC.get('__file__')} was taken on build {e.get('build_id', 'unrecorded')}, "
+                      f"this library is {build_id}")
+    return e, None
 
 
 def clock_preheat(torch, dev, ms):
@@ -420,6 +433,7 @@ def main():
             raise SystemExit(f"communicator spans {ranks_seen} ranks, expected {world}")
 
     lib = _lib.load()
+    build_id = lib.pcg_build_id().decode()
     stream = torch.cuda.current_stream(dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     mixed = args.workload == "mixed"
@@ -518,32 +532,41 @@ def main():
         brackets = []
         stepsum = [0.0, 0.0, 0]  # accepted, rejected, samples (adaptive workloads)
 
+        # Everything the launch loop needs is looked up ONCE, outside the timed region: the action slabs' device addresses
+        # (indexing a tensor costs the host 3-4 us per step -- a quarter of this kernel's run time, visible as idle GPU at
+        # the start of a 20-step region), the entry points, a pool of event pairs.
+        a_ptrs = [acts[i].data_ptr() for i in range(n_act)]
+        step_fn, step_ar_fn = lib.pcg_step, lib.pcg_step_autoreset
+        n_pairs = 2 + (max(Kd, K) + last_t - 1) // last_t
+        ev_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_pairs)]
+
         def run(n, timed):
             # hipEvent pairs on the launch stream, one pair around each run of consecutive step launches of an episode
             i = 0
             while i < n:
-                m = min(last_t - env.t, n - i)  # steps left in this episode
+                t = env.t
+                m = min(last_t - t, n - i)  # steps left in this episode
                 if timed:
-                    eb = torch.cuda.Event(enable_timing=True)
-                    ee = torch.cuda.Event(enable_timing=True)
+                    eb, ee = ev_pool[len(brackets)]
                     eb.record(stream)
-                if graph is not None and env.t == 0 and m == last_t:
+                if graph is not None and t == 0 and m == last_t:
                     graph.replay()
                 else:
+                    seed = env._episode_seed()
                     for j in range(m):
-                        buf.a = acts[(env.t) % n_act].data_ptr()
-                        if env.t == last_t - 1 and not args.separate_reset:
+                        buf.a = a_ptrs[t % n_act]
+                        if t == last_t - 1 and not args.separate_reset:
                             # last step of the episode: the reset of the (lock-stepped) batch happens inside the same
                             # launch (pcg_step_autoreset), with the next episode's RNG key
-                            seed = env._episode_seed()
                             env.episode += 1
-                            rc = lib.pcg_step_autoreset(plan, bufp, env.t, seed, env._episode_seed(), sptr)
-                            env.t = -1
+                            rc = step_ar_fn(plan, bufp, t, seed, env._episode_seed(), sptr)
+                            t = -1
                         else:
-                            rc = lib.pcg_step(plan, bufp, env.t, env._episode_seed(), sptr)
+                            rc = step_fn(plan, bufp, t, seed, sptr)
                         if rc:
                             _lib.check(rc, "pcg_step")
-                        env.t += 1
+                        t += 1
+                    env.t = t
                 if timed:
                     ee.record(stream)
                     brackets.append((eb, ee, m))
@@ -551,6 +574,15 @@ def main():
                 if env.t == last_t:  # after a graph replay or with --separate-reset
                     env.reset()
 
+    # what each rank owns, as the communicator sees it: the global index of every rank's first env (the RNG key of an env is
+    # its global index: shards must not overlap) -- one all-reduce outside the timed region
+    rank_offsets = [0]
+    if dist is not None:
+        first = (envs[0].env_offset if mixed else env.env_offset)
+        offs = torch.zeros(world, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        offs[rank] = float(first)
+        dist.all_reduce(offs)
+        rank_offsets = [int(v) for v in offs.tolist()]
     preheat_ms = clock_preheat(torch, dev, args.preheat_ms)
     run(W, False)
     torch.cuda.synchronize()
@@ -559,15 +591,17 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(K, True)
+    t_host = time.perf_counter() - t0  # the launch loop alone (asynchronous launches: the host's cost per step while it is ahead)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    host_us = t_host / max(K, 1) * 1e6
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed, host_us], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, host_us = float(tt[0].item()), float(tt[1].item())
 
     # sanity: a fast kernel producing garbage is not a result.  Physical boxes, not just finiteness (a diverged RK4
     # yields finite values up to 1e91), and the per-env status byte of the last step.
@@ -617,6 +651,9 @@ def main():
             "ranks_seen": ranks_seen,
             "clock_preheat_ms": round(preheat_ms, 1),
             "status_byte": bool(args.status),
+            "library_build_id": build_id,
+            "rank_first_env": rank_offsets,
+            "host_launch_loop_us_per_step_max_over_ranks": round(host_us, 2),
             "sane": finite,
         },
     }
@@ -638,7 +675,7 @@ def main():
                 segs_out.append(d)
             out["config"]["launch"] = ("eager pcg_step launches, one stream per segment" if graphs is None else
                                        "one HIP graph per segment and episode (reset + 59 steps, pcg_graph_*), one stream per segment")
-            pmx = committed_pmc("mixed") if B == (1 << 20) and not args.integrator else None
+            pmx, pm_why = committed_pmc("mixed", build_id) if B == (1 << 20) and not args.integrator else (None, "non-default run")
             if pmx:
                 for d in segs_out:
                     q = pmx.get("segments", {}).get(d["segment"])
@@ -655,6 +692,7 @@ def main():
                 "frac": dom.get("fp64_frac", dom["hbm_frac"]),
                 "traffic": dom.get("traffic"),
                 "traffic_measured_in_run": False,
+                **({} if pmx else {"traffic_reason": pm_why}),
                 "kernel": f"dominant segment: {dom['segment']} ({dom['integrator']}); the three segments run concurrently "
                           "on their own streams",
                 "kernel_avg_us": dom["kernel_avg_us"],
@@ -697,7 +735,10 @@ def main():
                           rhs_evals_per_env_step=rhs)
             # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside
             # this process): the committed measurement of this kernel + workload, if present -- NOT measured in this run
-            pm = committed_pmc(args.workload) if (B == Bd and args.substeps is None and not args.integrator) else None
+            pm, pm_why = (committed_pmc(args.workload, build_id) if (B == Bd and args.substeps is None and not args.integrator)
+                          else (None, "non-default run"))
+            if not pm:
+                rl["traffic_reason"] = pm_why
             if pm:
                 rl["traffic"] = pm["traffic_bytes_per_launch"]
                 rl["traffic_over_algorithmic"] = pm["traffic_bytes_per_launch"] / alg_bytes

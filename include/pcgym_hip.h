@@ -49,7 +49,7 @@ typedef unsigned long uintptr_t;
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 10
+#define PCG_ABI_VERSION 11
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -149,15 +149,20 @@ enum pcg_integrator {
                           rate (rho h <= 1) at every sub-step start and at the end state, finite result; an env that
                           fails the guard is re-integrated from its start state by PCG_INT_DOPRI5 at rtol / atol inside
                           the same launch (nsteps reports (0,0) for accepted envs, the pair's counts otherwise).  Models
-                          with a guard hook only (cstr: the ignition branch; the default plan of that model).  General
+                          with a guard hook only (cstr: the ignition branch).  The guard is the ONLY test -- RK4 carries no
+                          error estimate -- and it is calibrated on the cstr's observation box and action box: an opt-in
+                          for that box (the model's default plan is PCG_INT_T5G, which also checks an estimate).  General
                           kernel, pcg_step_autoreset, pcg_graph_*, pcg_integrate, pcg_rollout; not with per-env uncertain
                           parameters */
-  PCG_INT_T5G = 6,     /* GUARDED FIXED-STEP TSIT5: `substeps` equal steps of Tsit5's fifth-order solution weights (six
-                          right-hand sides per step, no error estimate), accepted per env while the model's guard holds at
-                          EVERY stage state and at the end state (g <= 0, rho h <= 2); otherwise PCG_INT_DOPRI5 from the
-                          start state inside the same launch, as PCG_INT_RK4G (same nsteps convention).  12 evaluations per
-                          canonical cstr step for the accuracy RK4G reaches with 20 (37 against 45 us per 2^20-env step):
-                          the default plan of the cstr.  Models with a guard hook only; general kernel,
+  PCG_INT_T5G = 6,     /* GUARDED FIXED-STEP TSIT5: `substeps` equal steps of Tsit5's fifth-order solution weights, TRUSTED per
+                          env while (i) the model's guard holds at EVERY stage state and at the end state (g <= 0, rho h <= 2)
+                          and (ii) the pair's own embedded 5(4) error estimate of every step stays below 4e-7 |x| + 4e-9 (RMS;
+                          the seventh stage it needs is the next step's first stage and the end-state guard: no extra
+                          evaluation); otherwise PCG_INT_DOPRI5 from the start state at rtol / atol inside the same launch, as
+                          PCG_INT_RK4G (same nsteps convention).  Calibrated so that the canonical cstr loop is never
+                          escalated and every trusted env of a wide state / input / step-size box lies inside 3 x the
+                          reference's CVODES tolerances (1e-6 |x| + 1e-8) of the true solution.  12 + 1 evaluations per
+                          canonical cstr step: the default plan of the cstr.  Models with a guard hook only; general kernel,
                           pcg_step_autoreset, pcg_graph_*, pcg_integrate, pcg_rollout; not with per-env uncertain
                           parameters */
   PCG_INT_CV8 = 7,     /* Cooper & Verner's explicit Runge-Kutta method of order 8 (11 stages), `substeps` equal steps per
@@ -351,6 +356,10 @@ typedef struct pcg_plan pcg_plan; /* opaque */
 
 /* library / ABI version (PCG_ABI_VERSION). */
 PCG_API int pcg_version(void);
+/* Build id: a digest of the kernel headers (csrc/*.hpp) and of this header at build time (the Makefile's PCG_SRC_HASH;
+   "unknown-build" for a build made without it).  Measurements that cannot be taken in-process -- the hardware-counter
+   passes under profiles/ -- record it, and bench.py reports their traffic figures only for the build they were taken on. */
+PCG_API const char* pcg_build_id(void);
 
 /* human-readable text for a status returned by any entry point (static storage). */
 PCG_API const char* pcg_strerror(int status);

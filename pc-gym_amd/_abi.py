@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PCG_ABI_VERSION = 10
+PCG_ABI_VERSION = 11
 PCG_MAX_NX = 24
 PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
@@ -159,6 +159,7 @@ class pcg_buffers(C.Structure):
 # every extern "C" symbol the header declares (tests check the .so exports all)
 EXPORTS = [
     "pcg_version",
+    "pcg_build_id",
     "pcg_strerror",
     "pcg_model_info",
     "pcg_model_default_params",
@@ -189,6 +190,8 @@ def declare(lib):
     vp = C.c_void_p
     lib.pcg_version.restype = C.c_int
     lib.pcg_version.argtypes = []
+    lib.pcg_build_id.restype = C.c_char_p
+    lib.pcg_build_id.argtypes = []
     lib.pcg_strerror.restype = C.c_char_p
     lib.pcg_strerror.argtypes = [C.c_int]
     lib.pcg_model_info.restype = C.c_int

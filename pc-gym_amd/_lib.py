@@ -11,7 +11,8 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcgym_hip.so")
+# PCGYM_HIP_LIB: another build of the same library (same ABI version, checked below) -- A/B measurements of kernel variants
+LIB_PATH = os.environ.get("PCGYM_HIP_LIB") or os.path.join(_HERE, "libpcgym_hip.so")
 _lib = None
 
 

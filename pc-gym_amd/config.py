@@ -333,38 +333,44 @@ class _ModelInfo:
 def trace_reward_callable(fn, spec):
     """``custom_reward(self, obs, uk, violated)`` (pcgym.py:201-205, 470-471) -> ONE C expression over o[], u[], sp[],
     violated, t, N for the batched kernel.  The callable is run twice on symbolic scalars, once per value of
-    ``violated`` (a plain bool, so ``if con:`` works), with ``float`` neutralised inside its module for the duration
-    (the usual ``return float(...)``); the result is checked numerically against the callable itself."""
+    ``violated`` (a plain bool, so ``if con:`` works), with ``float`` neutralised
+    (the usual ``return float(...)``) -- in a COPY of the function over a copy of its globals, the module itself is left
+    alone; the result is checked numerically against the callable itself."""
     import math
 
-    g = getattr(fn, "__globals__", None)
-    had = g is not None and "float" in g
-    old = g.get("float") if had else None
+    # `float(...)` of a symbolic scalar has to hand the scalar back.  The callable's module is NOT touched (another thread
+    # may be running it): a copy of the function is executed over a copy of its globals in which `float` is neutral; a
+    # callable that is not a plain function / bound method is run as it is (`float()` of a symbolic scalar then raises a
+    # trace error, and the caller is told to use the declarative forms).
+    import types
+
+    def neutral_float(v=0.0):
+        return v if isinstance(v, _Sym) else float(v)
+
+    run = fn
+    f0 = getattr(fn, "__func__", fn)
+    if isinstance(f0, types.FunctionType):
+        g2 = dict(f0.__globals__)
+        g2["float"] = neutral_float
+        f2 = types.FunctionType(f0.__code__, g2, f0.__name__, f0.__defaults__, f0.__closure__)
+        f2.__kwdefaults__ = f0.__kwdefaults__
+        run = types.MethodType(f2, fn.__self__) if isinstance(fn, types.MethodType) else f2
     exprs = {}
-    try:
-        if g is not None:
-            g["float"] = lambda v=0.0: v if isinstance(v, _Sym) else float(v)
-        for con in (False, True):
-            o = np.array([_Sym(f"o[{i}]") for i in range(spec.nobs)], dtype=object)
-            u = np.array([_Sym(f"u[{j}]") for j in range(spec.nu)], dtype=object)
-            try:
-                r = fn(_RewardSelf(spec, True), o, u, con)
-            except _TraceError as e:
-                raise ValueError(f"custom_reward: {e}") from None
-            except Exception as e:  # noqa: BLE001
-                raise ValueError("custom_reward: the callable could not be traced into an expression "
-                                 f"({type(e).__name__}: {e}); it probably keeps state on the env (self.u_prev ...) -- use "
-                                 "the declarative {'kind': 'sp_track'} form or {'expr': ...}") from None
-            r = np.asarray(r, dtype=object).reshape(-1)
-            if r.size != 1:
-                raise ValueError("custom_reward: the callable must return one number")
-            exprs[con] = r[0].e if isinstance(r[0], _Sym) else _Sym._lit(r[0])
-    finally:
-        if g is not None:
-            if had:
-                g["float"] = old
-            else:
-                g.pop("float", None)
+    for con in (False, True):
+        o = np.array([_Sym(f"o[{i}]") for i in range(spec.nobs)], dtype=object)
+        u = np.array([_Sym(f"u[{j}]") for j in range(spec.nu)], dtype=object)
+        try:
+            r = run(_RewardSelf(spec, True), o, u, con)
+        except _TraceError as e:
+            raise ValueError(f"custom_reward: {e}") from None
+        except Exception as e:  # noqa: BLE001
+            raise ValueError("custom_reward: the callable could not be traced into an expression "
+                             f"({type(e).__name__}: {e}); it probably keeps state on the env (self.u_prev ...) -- use "
+                             "the declarative {'kind': 'sp_track'} form or {'expr': ...}") from None
+        r = np.asarray(r, dtype=object).reshape(-1)
+        if r.size != 1:
+            raise ValueError("custom_reward: the callable must return one number")
+        exprs[con] = r[0].e if isinstance(r[0], _Sym) else _Sym._lit(r[0])
     text = exprs[False] if exprs[False] == exprs[True] else f"((violated) ? ({exprs[True]}) : ({exprs[False]}))"
     # numeric confirmation against the callable itself: random observations in the observation box, inputs in the
     # action box (+ nominal disturbance inputs), random step counters, both values of `violated`
@@ -600,7 +606,11 @@ class EnvSpec:
                 self.d_sched[j] = v[:self.N]
             self.d_default = np.array([float(info["parameters"][str(k)]) for k in mdist])
             pnames = list(self.model.parameters.keys())
-            self.d_param_index = np.array([pnames.index(str(k)) if str(k) in pnames else 0 for k in mdist], dtype=np.int32)
+            missing = [str(k) for k in mdist if str(k) not in pnames]
+            if missing:
+                raise ValueError(f"model '{self.model.name}': disturbance input(s) {missing} are not among its parameters "
+                                 f"{pnames} (an unconfigured disturbance input reads the parameter of the same name)")
+            self.d_param_index = np.array([pnames.index(str(k)) for k in mdist], dtype=np.int32)
             o_low = np.concatenate([o_low, _arr(p["disturbance_bounds"]["low"])])
             o_high = np.concatenate([o_high, _arr(p["disturbance_bounds"]["high"])])
         self.o_low, self.o_high = o_low, o_high
@@ -853,6 +863,9 @@ class EnvSpec:
         self.integrator = p.get("integrator", d_int)
         if self.integrator not in INTEGRATOR_IDS:
             raise ValueError("integrator must be one of " + ", ".join(repr(k) for k in INTEGRATOR_IDS))
+        if self.nunc > 0 and self.integrator in ("rodas4", "rodas3", "rk4g", "tsit5g", "cv8", "tsit5"):
+            raise ValueError(f"integrator '{self.integrator}' has no kernel for per-env uncertain parameters "
+                             "(uncertainty_percentages on model parameters): use 'rk4' or 'dopri5'")
         if self.integrator in ("rk4g", "tsit5g") and self.model.model_id != M.CSTR:
             raise ValueError(f"integrator '{self.integrator}' (guarded fixed step) needs a model with a guard hook: cstr")
         epc = p.get("endpoint_control", True)

@@ -104,6 +104,7 @@ struct pcg_plan {
   DevConst* dC;      // device copy
   double* dsched;    // [nsp+nd][N]
   size_t sched_bytes;
+  LeanStep* dlean;   // [N] wave-uniform values of each lock-stepped step (inside the dsched allocation)
   int cfg_nu;        // na + ndm as the caller counts them
   hipFunction_t jit_fn[2];  // run-time compiled general step kernel with user expressions [per_env_t] (or null)
   hipFunction_t jit_integ, jit_rhs;  // PCG_MODEL_USER: the run-time compiled test hooks (pcg_integrate / pcg_rhs)
@@ -121,6 +122,11 @@ static constexpr uint32_t PLAN_MAGIC = 0x50434731u;  // 'PCG1'
 extern "C" {
 
 int pcg_version(void) { return PCG_ABI_VERSION; }
+#ifndef PCG_SRC_HASH
+#define PCG_SRC_HASH "unknown-build"  // the Makefile passes a digest of csrc/*.hpp + include/pcgym_hip.h
+#endif
+const char* pcg_build_id(void) { return PCG_SRC_HASH; }
+
 
 const char* pcg_strerror(int status) {
   switch (status) {
@@ -383,6 +389,8 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   }
   d->dt = c->dt;
   d->h = c->dt / (c->substeps > 0 ? c->substeps : 1);
+  d->h2 = 0.5 * d->h;
+  d->h6 = d->h / 6.0;
   d->rtol = c->rtol;
   d->dt_edge = c->dt * (1.0 - 1e-14);
   d->h_floor = 1e-13 * c->dt;
@@ -399,6 +407,35 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   d->flags = c->flags;
   if (cfg_nu_out) *cfg_nu_out = cnu;
   return PCG_OK;
+}
+
+// The wave-uniform values of every lock-stepped step t -> t + 1 (LeanStep, pcg_kernels.hpp), computed here once per plan
+// with the operations the kernels used to repeat per tile: the observation slots through the folded OMap as one fused
+// multiply-add of (v - lo), the schedule indices of pcgym.py:394,438,555 (quirks Q5, Q6) clamped to the last column.
+static std::vector<LeanStep> lean_table(const DevConst& d, const pcg_env_cfg* c) {
+  const int N = d.N > 0 ? d.N : 1;
+  std::vector<LeanStep> tab((size_t)N);
+  for (int t = 0; t < N; ++t) {
+    LeanStep& L = tab[(size_t)t];
+    std::memset(&L, 0, sizeof(L));
+    const int tc = t < N - 1 ? t : N - 1, tn = t + 1 < N - 1 ? t + 1 : N - 1;
+    for (int k = 0; k < d.nsp && k < PCG_MAX_NSP; ++k) {
+      L.spn[k] = c->sp[(size_t)k * N + tn];
+      if (k < d.nsp_obs) {
+        const OMap& m = d.omap[d.nx + k];
+        L.osp[k] = std::fma(c->sp[(size_t)k * N + tc] - m.lo, m.sc, m.off);
+      }
+    }
+    for (int j = 0; j < PCG_MAX_NDM; ++j) L.ud[j] = d.d_default[j];
+    for (int k = 0; k < d.nd && k < PCG_MAX_NDM; ++k) {
+      const double v = c->d_sched[(size_t)k * N + tn];
+      const OMap& m = d.omap[d.nx + d.nsp_obs + k];
+      L.od[k] = std::fma(v - m.lo, m.sc, m.off);
+      const int slot = d.d_slot[k];
+      if (slot >= 0 && slot < PCG_MAX_NDM) L.ud[slot] = v;
+    }
+  }
+  return tab;
 }
 
 // eq_exponent == 2 (the reference default) selects the multiply-only instantiation of the extraction models;
@@ -702,6 +739,7 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   p->env_offset = 0;
   p->dC = nullptr;
   p->dsched = nullptr;
+  p->dlean = nullptr;
   p->jit_fn[0] = p->jit_fn[1] = nullptr;
   p->jit_integ = p->jit_rhs = p->jit_roll = nullptr;
   p->nx = cfg->nx;
@@ -712,9 +750,16 @@ int pcg_plan_create(pcg_plan** out, const pcg_env_cfg* cfg) {
   const bool emp = (cfg->flags & PCG_F_UNC_EMPIRICAL) && cfg->nunc > 0;
   const size_t n_emp = emp ? (size_t)cfg->unc_emp_off[cfg->nunc] : 0;
   p->sched_bytes = sizeof(double) * (size_t)(rows > 0 ? rows : 1) * cfg->N;
-  const size_t sched_alloc = sizeof(double) * ((size_t)(rows > 0 ? rows : 1) * cfg->N + n_emp);
+  // behind the schedule rows and the sample tables: the per-step table of the lean kernels (LeanStep[N], 128-byte records)
+  const size_t lean_off = (((size_t)(rows > 0 ? rows : 1) * cfg->N + n_emp) + 15) & ~(size_t)15;  // in doubles
+  const size_t sched_alloc = sizeof(double) * lean_off + sizeof(LeanStep) * (size_t)cfg->N;
   e = hipMalloc((void**)&p->dC, sizeof(DevConst));
   if (e == hipSuccess) e = hipMalloc((void**)&p->dsched, sched_alloc);
+  if (e == hipSuccess) {
+    p->dlean = reinterpret_cast<LeanStep*>(p->dsched + lean_off);
+    const std::vector<LeanStep> lt = lean_table(p->hc, cfg);
+    e = hipMemcpy(p->dlean, lt.data(), sizeof(LeanStep) * lt.size(), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) e = hipMemcpy(p->dC, &p->hc, sizeof(DevConst), hipMemcpyHostToDevice);
   if (e == hipSuccess && cfg->nsp)
     e = hipMemcpy(p->dsched, cfg->sp, sizeof(double) * (size_t)cfg->nsp * cfg->N, hipMemcpyHostToDevice);
@@ -794,7 +839,7 @@ int pcg_plan_set_option(pcg_plan* p, int option, int64_t value) {
     case PCG_OPT_ENV_OFFSET: p->env_offset = value; return PCG_OK;
     case PCG_OPT_LDS_STAGES: p->lds_stages = value ? 1 : 0; return PCG_OK;
     case PCG_OPT_STREAM_BLOCKS_PER_CU: p->stream_bpc = (int)value; return PCG_OK;
-    case PCG_OPT_NT_STORES: p->nt_stores = value ? 1 : 0; return PCG_OK;
+    case PCG_OPT_NT_STORES: p->nt_stores = (int)(value & 7); return PCG_OK;  // bit 0 obs / reward, 1 state, 2 loads
     case PCG_OPT_VARIANT:
       if (value < 0 || value > 5) return PCG_E_VALUE;
       p->variant = (int)value;
@@ -825,6 +870,7 @@ static int fill_args(const pcg_plan* p, const pcg_buffers* io, StepArgs* a) {
   if (io->B < 0) return PCG_E_DIM;
   std::memset(a, 0, sizeof(*a));
   a->C = (CDevConst*)p->dC; a->sched = (const PCG_CONSTANT double*)p->dsched;
+  a->lean = (const PCG_CONSTANT LeanStep*)p->dlean;
   a->x = io->x; a->a = io->a; a->d = io->d; a->t = io->t; a->a_save = io->a_save; a->obs = io->obs;
   a->rew = io->rew; a->done = io->done; a->viol = io->viol; a->g = io->g; a->g_pre = io->g_pre;
   a->nsteps = io->nsteps; a->B = io->B; a->env_offset = p->env_offset;
@@ -1065,8 +1111,9 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto al2 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 1u) == 0; };
   const bool pipe_ok = (p->variant == 4 || p->variant == 0 || p->variant == 5) && pipe && pipe[0];
+  // (the lean kernels index envs and row offsets in 32 bits: B < 2^28; larger batches take the classic kernel)
   if (!per_env_t && !extras && !lds_st && !io->viol && (!io->status || pipe_ok) && p->variant != 1 && stream_ok && lean_ar_ok &&
-      (k.stream[p->integrator_id][0] || pipe_ok)) {
+      io->B < ((int64_t)1 << 28) && (k.stream[p->integrator_id][0] || pipe_ok)) {
     const bool epl2_ok = (k.stream[p->integrator_id][1] || (pipe_ok && pipe[1])) && (io->B % 2 == 0) && al16(io->x) &&
                          al16(io->a) && al16(io->obs) && al16(io->rew) && al2(io->done);
     int epl = (p->variant == 2) ? 1 : (epl2_ok ? 2 : 1);
@@ -1088,10 +1135,20 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
     const int64_t tile_envs = (int64_t)BLOCK * epl;
     const int64_t ntile = (io->B + tile_envs - 1) / tile_envs;
     int bpc = occ;
-    if (p->stream_bpc > 0 && p->stream_bpc < bpc) bpc = p->stream_bpc;
+    // HBM-bound lean kernels: five resident workgroups per CU.  More waves per SIMD only lengthen every wave's integration
+    // phase (they share the vector unit round-robin), so the grid's stores leave later and in a shorter burst -- measured on
+    // the cstr headline, interleaved runs of one box (profiles/r4/headline_bisect.txt): 4 / 5 / 6 / 8 per CU = 13.96 /
+    // 12.60 / 13.58 / 15.1 us.  PCG_OPT_STREAM_BLOCKS_PER_CU overrides.
+    if (piped && bpc > 5) bpc = 5;
+    if (p->stream_bpc > 0 && p->stream_bpc <= occ) bpc = p->stream_bpc;
     int64_t grid = (int64_t)p->num_cus * bpc;
     if (grid > ntile) grid = ntile;
     a.nt_stores = p->nt_stores;
+    if (piped) {  // issue priority by residency slot (step_kernel_pipe); PCG_LEAN_PRIO: measurement override (hex, 2 bits per slot)
+      static const int prio_env = [] { const char* ev = std::getenv("PCG_LEAN_PRIO"); return ev ? (int)std::strtol(ev, nullptr, 16) : -1; }();
+      a.q_prio = prio_env >= 0 ? prio_env : 0;
+      a.q_tile = p->num_cus;
+    }
     hipLaunchKernelGGL(sfn, dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }

@@ -20,10 +20,11 @@
 
 namespace pcg {
 
+// h2 = 0.5 h and h6 = h / 6.0 come folded from the host (DevConst): both are wave-uniform, and the vector unit is the only
+// floating-point unit -- the division alone was eleven instructions per call.
 template <int NX, class F, class R>
-PCG_DEV void rk4(const F& f, R (&x)[NX], double h, int nsub) {
+PCG_DEV void rk4(const F& f, R (&x)[NX], double h, double h2, double h6, int nsub) {
   R k[NX], acc[NX], y[NX];
-  const double h2 = 0.5 * h, h6 = h / 6.0;
   for (int s = 0; s < nsub; ++s) {
     f(x, k);
 #pragma unroll
@@ -57,9 +58,7 @@ struct has_guard<M, tt::void_t<decltype(M::GUARD)>> : tt::true_type {};
 // RK4 with the model's guard (PCG_INT_RK4G): the same arithmetic as rk4(); returns 0 when the guard holds at every
 // sub-step start and at the end state, 2 when a growing mode was seen (g > 0, or a non-finite value: errors amplify, the
 // fallback needs the plan's tight tolerance), 1 when only the fastest rate is unresolved (rho h > 1 with g <= 0 throughout:
-// a contracting, stiff state -- the hot branch of the cstr -- where local errors do not grow and the fallback runs at
-// GUARD_LOOSE_TOL).
-constexpr double GUARD_LOOSE_TOL = 1e-7;
+// a contracting, stiff state -- the hot branch of the cstr).  The fallback runs at the plan's tolerance either way.
 template <class M, class K, class F>
 PCG_DEV int rk4_guarded(const F& f, const K& kp, const typename M::Hold& hold, double (&x)[M::NX], double h, int nsub) {
   constexpr int NX = M::NX;
@@ -351,11 +350,19 @@ PCG_DEV R ch(const R& acc, const R& k, double a) {
   return pk_fma(k, a, acc);
 }
 
-// Guarded fixed-step Tsit5 (PCG_INT_T5G): nsub steps of the Tsit5 solution weights with the model's guard evaluated at
-// every stage state (it shares the right-hand side's Arrhenius factor) and at the end state.  gc[j] per env of the lane:
-// 0 accepted, 2 growing mode seen (g > 0 or non-finite), 1 only the fastest rate unresolved (rho h > T5G_SLOW_LIMIT) --
-// as rk4_guarded().  12 right-hand sides per canonical cstr step for the accuracy of RK4 x 5 (20).
+// Guarded fixed-step Tsit5 (PCG_INT_T5G): nsub steps of the Tsit5 solution weights.  A step is TRUSTED when the model's guard
+// holds at every stage state and at the end state (it shares the right-hand side's Arrhenius factor) AND -- round 4 -- the
+// pair's own embedded 5(4) error estimate of every step stays below T5G_EST_RTOL |x| + T5G_EST_ATOL (RMS over the
+// components, the norm of the adaptive pairs).  The estimate needs k7 = f(x_new): that evaluation is the next step's first
+// stage (FSAL) and the end-state guard, so the estimate costs its seven weights only.  Calibration
+// (tools/prototypes/t5g_est_calib.py, tests/test_erk.py): the canonical closed loop at dt = 26/60 is never escalated
+// (0 of 600,000 env steps), and on a deliberately wide box -- Ca in [0, 1.44], T in [290, 600] K, jacket 280..320 K, dt =
+// 1/60, 5/60, 26/60 -- every TRUSTED env is inside 3 x the reference's own CVODES tolerances (1e-6 |x| + 1e-8) of a 1e-13
+// solve.  (Round 3 trusted the guard alone: outside its calibration box that passed steps 4e-4 ... 6e-3 off)
+// gc[j] per env of the lane: 0 trusted, 2 growing mode seen (g > 0 or non-finite), 1 fastest rate unresolved (rho h >
+// T5G_SLOW_LIMIT), 3 estimate too large.  12 + 1 right-hand sides per canonical cstr step for the accuracy of RK4 x 5 (20).
 constexpr double T5G_SLOW_LIMIT = 2.0;
+constexpr double T5G_EST_RTOL = 4e-7, T5G_EST_ATOL = 4e-9;
 template <class R, int W>
 PCG_DEV void guard_acc(const R& g, const R& rho, double h, double lim, bool (&calm)[W], bool (&slow)[W]) {
 #pragma unroll
@@ -371,13 +378,13 @@ PCG_DEV void t5_guarded(const K& kp, const typename M::template HoldT<R>& hold, 
 #pragma clang fp contract(off)
   using namespace t5;
   constexpr int NX = M::NX, W = pack_w<R>::W;
-  R k1[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX], y[NX], g, rho;
-  bool calm[W], slow[W];
+  R k1[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX], k7[NX], y[NX], xn[NX], g, rho;
+  bool calm[W], slow[W], sharp[W];
 #pragma unroll
-  for (int j = 0; j < W; ++j) calm[j] = slow[j] = true;
+  for (int j = 0; j < W; ++j) calm[j] = slow[j] = sharp[j] = true;
+  M::rhs_guard(kp, hold, x, k1, g, rho);
+  guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
   for (int s = 0; s < nsub; ++s) {
-    M::rhs_guard(kp, hold, x, k1, g, rho);
-    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
 #pragma unroll
     for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch0(k1[i], a21), h, x[i]);
     M::rhs_guard(kp, hold, y, k2, g, rho);
@@ -401,12 +408,36 @@ PCG_DEV void t5_guarded(const K& kp, const typename M::template HoldT<R>& hold, 
     guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
 #pragma unroll
     for (int i = 0; i < NX; ++i)
-      x[i] = pk_fma(ch(ch(ch(ch(ch(ch0(k1[i], b1), k2[i], b2), k3[i], b3), k4[i], b4), k5[i], b5), k6[i], b6), h, x[i]);
-  }
-  M::guard(kp, hold, x, g, rho);
-  guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+      xn[i] = pk_fma(ch(ch(ch(ch(ch(ch0(k1[i], b1), k2[i], b2), k3[i], b3), k4[i], b4), k5[i], b5), k6[i], b6), h, x[i]);
+    // the step's end state: its right-hand side is the seventh stage of the estimate, the next step's first stage, and
+    // the guard there is the end-state guard
+    M::rhs_guard(kp, hold, xn, k7, g, rho);
+    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+    {
+      double s2[W];
 #pragma unroll
-  for (int j = 0; j < W; ++j) gc[j] = !calm[j] ? 2 : (slow[j] ? 0 : 1);
+      for (int j = 0; j < W; ++j) s2[j] = 0.0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const R err = ch(ch(ch(ch(ch(ch(ch0(k1[i], e1), k2[i], e2), k3[i], e3), k4[i], e4), k5[i], e5), k6[i], e6), k7[i], e7) * h;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const double a0 = fabs(pk_at(x[i], j)), a1 = fabs(pk_at(xn[i], j));
+          const double q = pk_at(err, j) / (T5G_EST_ATOL + T5G_EST_RTOL * (a0 > a1 ? a0 : a1));
+          s2[j] += q * q;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < W; ++j) sharp[j] = sharp[j] && (s2[j] * (1.0 / NX) < 1.0);  // (NaN fails)
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      x[i] = xn[i];
+      k1[i] = k7[i];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < W; ++j) gc[j] = !calm[j] ? 2 : (!slow[j] ? 1 : (sharp[j] ? 0 : 3));
 }
 
 // Cooper & Verner (1972), order 8 in 11 stages, fixed step (PCG_INT_CV8; coefficients in sqrt(21) as correctly rounded

@@ -87,6 +87,8 @@ struct OMap {
 struct DevConst {
   double dt, h, rtol, atol;
   double dt_edge, h_floor;            // dt (1 - 1e-14) and 1e-13 dt of the DOPRI5 loop, folded on the host
+  double h2, h6;                      // 0.5 h and h / 6.0 of rk4(), folded on the host (there is no scalar fp unit: a
+                                      // wave-uniform division in the kernel is eleven VALU instructions per tile)
   uint32_t flags;
   int32_t nx, na, ndm, nd, nsp, nsp_obs, ncon, nrew, N, substeps, max_steps, nobs, has_x0_unc, nunc;
   int32_t sp_index[PCG_MAX_NSP], d_slot[PCG_MAX_NDM];
@@ -127,9 +129,19 @@ struct DevConst {
 
 using CDevConst = const PCG_CONSTANT DevConst;
 
+// Wave-uniform values of one lock-stepped step t -> t + 1 (lean plans), folded on the host at plan creation
+// (pcg_abi.hip: lean_table): what env_step_lean() used to compute on the vector unit once per tile.
+struct LeanStep {
+  double osp[PCG_MAX_NSP];  // observation SP slots, normalised: SP[k][min(t, N-1)]                (quirk Q5)
+  double spn[PCG_MAX_NSP];  // reward set-points SP[k][min(t+1, N-1)]
+  double od[PCG_MAX_NDM];   // observation disturbance slots, normalised: D[k][min(t+1, N-1)]    (quirk Q6)
+  double ud[PCG_MAX_NDM];   // model disturbance inputs held over the step (defaults, overridden by the configured ones)
+};
+
 struct StepArgs {
   CDevConst* C;                       // constant address space: uniform reads -> s_load
   const PCG_CONSTANT double* sched;   // [nsp + nd][N]
+  const PCG_CONSTANT LeanStep* lean;  // [N] (lock-stepped lean kernels)
   double* x;
   const double* a;
   const double* d;
@@ -456,8 +468,8 @@ PCG_DEV int finite_status(int status, const double (&x)[NX], int nx) {
 }
 
 // Guarded fixed-step plans on one env (PCG_INT_RK4G, PCG_INT_T5G): the fixed-step scheme under the model's guard; an env
-// that trips it is re-integrated from its start state by the adaptive pair -- at the plan's tolerance when a growing mode
-// was seen, at GUARD_LOOSE_TOL on contracting stiff states.  Returns the pair's status (PCG_ST_OK for accepted envs).
+// that is not trusted (guard tripped; PCG_INT_T5G: or the embedded error estimate too large) is re-integrated from its start
+// state by the adaptive pair at the plan's tolerance.  Returns the pair's status (PCG_ST_OK for trusted envs).
 template <class M, int INTEG, class K, class F>
 PCG_DEV int guarded_env(const F& f, const K& kp, const typename M::Hold& hold, double (&x)[M::NX], CDevConst& c, int nx,
                         int& nacc, int& nrej) {
@@ -479,8 +491,8 @@ PCG_DEV int guarded_env(const F& f, const K& kp, const typename M::Hold& hold, d
 #pragma unroll
       for (int i = 0; i < NX; ++i) x[i] = x0[i];
       RegStages<NX> Kst;
-      const double rt = gc == 2 ? c.rtol : fmax(c.rtol, GUARD_LOOSE_TOL), at = gc == 2 ? c.atol : fmax(c.atol, GUARD_LOOSE_TOL);
-      status = dopri5<NX>(f, Kst, x, nx, c.dt, rt, at, c.max_steps, nacc, nrej);
+      // at the PLAN's tolerance, whatever tripped (round 3 ran contracting states at 1e-7 whatever the user had asked for)
+      status = dopri5<NX>(f, Kst, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
       poison_if_failed<NX>(status, x);
     }
   } else {
@@ -497,7 +509,7 @@ PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const do
   const RhsFn<M, double, K> f{kp, hold};
   int status = PCG_ST_OK;
   if (INTEG == PCG_INT_RK4) {
-    rk4<NX>(f, x, c.h, c.substeps);
+    rk4<NX>(f, x, c.h, c.h2, c.h6, c.substeps);
   } else if (INTEG == PCG_INT_RODAS3) {
     int nacc = 0, nrej = 0;
     const RosLds<NX> Lm(stage_l);
@@ -976,8 +988,6 @@ template <class M, int W>
 struct LeanOut {
   Pack<W> ox[M::NX];
   Pack<W> rew;
-  double osp[PCG_MAX_NSP];  // wave-uniform
-  double od[PCG_MAX_NDM];   // wave-uniform
   bool done;                // wave-uniform
 };
 
@@ -985,51 +995,45 @@ struct LeanOut {
 // kernel was built and measured: 41.3 us against 37 us in the general kernel on the canonical cstr loop -- the fallback's
 // registers leave one env per lane at four waves per SIMD -- and 26 % slower when half the batch escalates, because a
 // 256-thread workgroup then waits for its slowest env.)
+// Round 4: the kernel's time follows its vector-instruction count (profiles/r4/headline_bisect.txt: +8 % instructions,
+// +9 % time), so everything wave-uniform is gone from the vector unit -- the SP / disturbance slots of step t come
+// finished from the host (LeanStep, scalar loads), h/2 and h/6 too, and the normalised-action branch is a scalar branch
+// instead of both values and a select.
 template <class M, int W, int INTEG = PCG_INT_RK4>
-PCG_DEV void env_step_lean(const StepArgs& A, CDevConst& c, int t, const Pack<W> (&a_in)[M::NA],
-                           Pack<W> (&x)[M::NX], LeanOut<M, W>& out) {
+PCG_DEV void env_step_lean(const StepArgs& A, CDevConst& c, const PCG_CONSTANT LeanStep& L, int t,
+                           const Pack<W> (&a_in)[M::NA], Pack<W> (&x)[M::NX], LeanOut<M, W>& out) {
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM;
   using R = Pack<W>;
   const int nx = M::DYNAMIC ? c.nx : NX;
   const int na = M::DYNAMIC ? c.na : NA;
-  const int N = c.N, nsp = c.nsp, nso = c.nsp_obs, nd = c.nd;
-  const int tn = min(t + 1, N - 1), tc = min(t, N - 1);
+  const int N = c.N, nsp = c.nsp;
   typename M::CKP& kp = model_kp<M>(c);
   // action map (pcgym.py:371-375) and held disturbance inputs (pcgym.py:386-404)
   R u[NA + NDM];
 #pragma unroll
-  for (int i = 0; i < NA; ++i)
-    u[i] = (i < na) ? action_map(a_in[i], c.a_lo[i], c.a_hi[i], (c.flags & PCG_F_NORMALISE_A) != 0, false) : R(0.0);
-  double ud[NDM > 0 ? NDM : 1];
+  for (int i = 0; i < NA; ++i) u[i] = (i < na) ? a_in[i] : R(0.0);
+  if (c.flags & PCG_F_NORMALISE_A) {
 #pragma unroll
-  for (int j = 0; j < NDM; ++j) ud[j] = c.d_default[j];
+    for (int i = 0; i < NA; ++i)
+      if (i < na) u[i] = action_map(a_in[i], c.a_lo[i], c.a_hi[i], true, false);
+    asm volatile("");  // keep it a (scalar) branch
+  }
 #pragma unroll
-  for (int k = 0; k < NDM; ++k)
-    if (k < nd) {
-      const double v = A.sched[(size_t)(nsp + k) * N + tn];  // Q6: index t+1
-      out.od[k] = (v - c.omap[nx + nso + k].lo) * c.omap[nx + nso + k].sc + c.omap[nx + nso + k].off;
-      const int slot = c.d_slot[k];
-#pragma unroll
-      for (int j = 0; j < NDM; ++j) ud[j] = (j == slot) ? v : ud[j];
-    }
-#pragma unroll
-  for (int j = 0; j < NDM; ++j) u[NA + j] = R(ud[j]);
+  for (int j = 0; j < NDM; ++j) u[NA + j] = R(L.ud[j]);
   // integrate over [0,dt] with the input held (integrator.py:163-182)
   const typename M::template HoldT<R> hold = M::template hold<R>(kp, u);
   const RhsFn<M, R> f{kp, hold};
   if constexpr (INTEG == PCG_INT_CV8) {
     cv8<NX>(f, x, c.h, c.substeps);
   } else {
-    rk4<NX>(f, x, c.h, c.substeps);
+    rk4<NX>(f, x, c.h, c.h2, c.h6, c.substeps);
   }
-  // SP slot = SP[t_old] (Q5), reward against SP[t_new] (pcgym.py:432-441, 535-558)
+  // reward against SP[t_new] (pcgym.py:535-558)
   R r(0.0);
 #pragma unroll
   for (int k = 0; k < PCG_MAX_NSP; ++k)
     if (k < nsp) {
-      const double spv = A.sched[(size_t)k * N + tc], spn = A.sched[(size_t)k * N + tn];
-      if (k < nso) out.osp[k] = (spv - c.omap[nx + k].lo) * c.omap[nx + k].sc + c.omap[nx + k].off;
-      const R dd = pick<NX, W>(x, c.sp_index[k]) - spn;
+      const R dd = pick<NX, W>(x, c.sp_index[k]) - L.spn[k];
       r = r + (-(dd * dd)) * c.r_scale[k];
     }
   out.rew = r;
@@ -1048,6 +1052,7 @@ struct Vec<1> {
   PCG_DEV static T make(const double (&s)[1]) { return s[0]; }
   // streaming store: the data is not re-read by this kernel (obs / reward go to the policy)
   PCG_DEV static void store_nt(double* p, const double (&s)[1]) { __builtin_nontemporal_store(s[0], p); }
+  PCG_DEV static T load_nt(const double* p) { return __builtin_nontemporal_load(p); }
 };
 template <>
 struct Vec<2> {
@@ -1058,6 +1063,10 @@ struct Vec<2> {
   PCG_DEV static void store_nt(double* p, const double (&s)[2]) {
     __builtin_nontemporal_store(d2{s[0], s[1]}, reinterpret_cast<d2*>(p));
   }
+  PCG_DEV static T load_nt(const double* p) {
+    const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2*>(p));
+    return make_double2(v.x, v.y);
+  }
 };
 
 PCG_DEV void land(double& v) { asm volatile("" : "+v"(v)); }
@@ -1066,41 +1075,54 @@ PCG_DEV void land(double2& v) {
   asm volatile("" : "+v"(v.y));
 }
 
-// stores of one lean tile: the state back in place, observation / reward (non-temporal on request), done flags
+// stores of one lean tile: the state back in place, observation / reward (non-temporal on request), done flags.
+// Rows are addressed as (uniform row base) + (32-bit byte offset of the lane): the row bases stay in scalar registers and the
+// lane's offset is ONE vector register for every row (the 64-bit per-row addresses of rounds 1-3 were two dozen vector
+// instructions per tile).  Callers guarantee B < 2^28.
+template <class T>
+PCG_DEV T* row_at(double* base, uint32_t off8) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + off8);
+}
+template <class T>
+PCG_DEV const T* row_at(const double* base, uint32_t off8) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + off8);
+}
 template <class M, int EPL>
-PCG_DEV void store_lean(const StepArgs& A, CDevConst& c, int64_t e0, const Pack<EPL> (&xs)[M::NX],
-                        const LeanOut<M, EPL>& out, bool nt) {
+PCG_DEV void store_lean(const StepArgs& A, CDevConst& c, const PCG_CONSTANT LeanStep& L, uint32_t e0,
+                        const Pack<EPL> (&xs)[M::NX], const LeanOut<M, EPL>& out, bool nt) {
   using V = typename Vec<EPL>::T;
   constexpr int NX = M::NX;
-  const int64_t B = A.B;
+  const size_t B = (size_t)A.B;
   const int nx = M::DYNAMIC ? c.nx : NX;
   const int nso = c.nsp_obs;
+  const uint32_t o8 = e0 * 8u;
   double tmp[EPL];
 #pragma unroll
   for (int i = 0; i < NX; ++i)
     if (i < nx) {
-      *reinterpret_cast<V*>(A.x + (size_t)i * B + e0) = Vec<EPL>::make(xs[i].v);
-      if (nt) Vec<EPL>::store_nt(A.obs + (size_t)i * B + e0, out.ox[i].v);
-      else *reinterpret_cast<V*>(A.obs + (size_t)i * B + e0) = Vec<EPL>::make(out.ox[i].v);
+      if (A.nt_stores & 2) Vec<EPL>::store_nt(row_at<double>(A.x + (size_t)i * B, o8), xs[i].v);
+      else *row_at<V>(A.x + (size_t)i * B, o8) = Vec<EPL>::make(xs[i].v);
+      if (nt) Vec<EPL>::store_nt(row_at<double>(A.obs + (size_t)i * B, o8), out.ox[i].v);
+      else *row_at<V>(A.obs + (size_t)i * B, o8) = Vec<EPL>::make(out.ox[i].v);
     }
 #pragma unroll
   for (int k = 0; k < PCG_MAX_NSP; ++k)
     if (k < nso) {
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) tmp[j] = out.osp[k];
-      if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + k) * B + e0, tmp);
-      else *reinterpret_cast<V*>(A.obs + (size_t)(nx + k) * B + e0) = Vec<EPL>::make(tmp);
+      for (int j = 0; j < EPL; ++j) tmp[j] = L.osp[k];
+      if (nt) Vec<EPL>::store_nt(row_at<double>(A.obs + (size_t)(nx + k) * B, o8), tmp);
+      else *row_at<V>(A.obs + (size_t)(nx + k) * B, o8) = Vec<EPL>::make(tmp);
     }
 #pragma unroll
   for (int k = 0; k < M::NDM; ++k)
     if (k < c.nd) {
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) tmp[j] = out.od[k];
-      if (nt) Vec<EPL>::store_nt(A.obs + (size_t)(nx + nso + k) * B + e0, tmp);
-      else *reinterpret_cast<V*>(A.obs + (size_t)(nx + nso + k) * B + e0) = Vec<EPL>::make(tmp);
+      for (int j = 0; j < EPL; ++j) tmp[j] = L.od[k];
+      if (nt) Vec<EPL>::store_nt(row_at<double>(A.obs + (size_t)(nx + nso + k) * B, o8), tmp);
+      else *row_at<V>(A.obs + (size_t)(nx + nso + k) * B, o8) = Vec<EPL>::make(tmp);
     }
-  if (nt) Vec<EPL>::store_nt(A.rew + e0, out.rew.v);
-  else *reinterpret_cast<V*>(A.rew + e0) = Vec<EPL>::make(out.rew.v);
+  if (nt) Vec<EPL>::store_nt(row_at<double>(A.rew, o8), out.rew.v);
+  else *row_at<V>(A.rew, o8) = Vec<EPL>::make(out.rew.v);
   if (EPL == 2) *reinterpret_cast<uint16_t*>(A.done + e0) = out.done ? (uint16_t)0x0101u : (uint16_t)0;
   else A.done[e0] = out.done ? 1 : 0;
 }
@@ -1177,7 +1199,7 @@ void step_kernel_stream(const StepArgs A) {
   const int na = M::DYNAMIC ? c.na : NA;
   const int nso = c.nsp_obs;
   const int t = A.t_scalar;
-  const bool nt = A.nt_stores != 0;
+  const bool nt = (A.nt_stores & 1) != 0;
   constexpr int64_t SUB = (int64_t)BLOCK * EPL;  // envs per sub-tile
   const int64_t tile = SUB * UNR;
   const int64_t ntile = (B + tile - 1) / tile;
@@ -1226,8 +1248,8 @@ void step_kernel_stream(const StepArgs A) {
 #pragma unroll
           for (int j = 0; j < EPL; ++j) as[i].v[j] = (i < na) ? Vec<EPL>::get(av[u][i], j) : 0.0;
         LeanOut<M, EPL> out;
-        env_step_lean<M, EPL>(A, c, t, as, xs, out);
-        store_lean<M, EPL>(A, c, e0, xs, out, nt);
+        env_step_lean<M, EPL>(A, c, A.lean[min(t, c.N - 1)], t, as, xs, out);
+        store_lean<M, EPL>(A, c, A.lean[min(t, c.N - 1)], (uint32_t)e0, xs, out, nt);
       } else {
       EnvOut<M> out[EPL];
       double xs[EPL][NX];
@@ -1303,40 +1325,80 @@ __global__ __launch_bounds__(BLOCK, INTEG == PCG_INT_RK4 ? PCG_LEAN_WPE : 4) voi
   CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA;
   using V = typename Vec<EPL>::T;
-  const int64_t B = A.B;
+  const uint32_t B = (uint32_t)A.B;  // < 2^28 (step_impl): 32-bit env indices and byte offsets, row bases in scalar registers
+  const size_t Bs = (size_t)A.B;
   const int nx = M::DYNAMIC ? c.nx : NX;
   const int na = M::DYNAMIC ? c.na : NA;
-  const int nso = c.nsp_obs;
   const int t = A.t_scalar;
-  const bool nt = A.nt_stores != 0;
-  constexpr int64_t TILE = (int64_t)BLOCK * EPL;
-  const int64_t ntile = (B + TILE - 1) / TILE;
-  int64_t it = blockIdx.x;
+  const PCG_CONSTANT LeanStep& L = A.lean[min(t, c.N - 1)];
+  const bool nt = (A.nt_stores & 1) != 0;
+  const bool ntl = (A.nt_stores & 4) != 0;
+  constexpr uint32_t TILE = (uint32_t)BLOCK * EPL;
+  const uint32_t ntile = (B + TILE - 1) / TILE;
+  uint32_t it = blockIdx.x;
   if (it >= ntile) return;
   V xv[NX], av[NA];
-  int64_t e0 = it * TILE + (int64_t)threadIdx.x * EPL;
+  uint32_t e0 = it * TILE + threadIdx.x * EPL;
   bool live = e0 < B;
-  auto load = [&](int64_t ee, V (&xd)[NX], V (&ad)[NA]) {
+  auto load = [&](uint32_t ee, V (&xd)[NX], V (&ad)[NA]) {
+    const uint32_t o8 = ee * 8u;
+    if (ntl) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i)
-      if (i < nx) xd[i] = *reinterpret_cast<const V*>(A.x + (size_t)i * B + ee);
+      for (int i = 0; i < NX; ++i)
+        if (i < nx) xd[i] = Vec<EPL>::load_nt(row_at<double>(A.x + (size_t)i * Bs, o8));
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
-      if (i < na) ad[i] = *reinterpret_cast<const V*>(A.a + (size_t)i * B + ee);
+      for (int i = 0; i < NA; ++i)
+        if (i < na) ad[i] = Vec<EPL>::load_nt(row_at<double>(A.a + (size_t)i * Bs, o8));
+    } else {
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        if (i < nx) xd[i] = *row_at<V>(A.x + (size_t)i * Bs, o8);
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        if (i < na) ad[i] = *row_at<V>(A.a + (size_t)i * Bs, o8);
+    }
   };
+  // Issue priority by residency slot (q_prio: 2 bits per slot, q_tile: workgroups per slot = CUs; 0 = off).  The waves of a
+  // SIMD all receive their inputs within a microsecond of each other; at equal priority they share the vector unit
+  // round-robin and finish TOGETHER, microseconds later, so the stores of the whole grid leave in one burst at the end
+  // (tools/timeline_probe.py).  Distinct priorities let them finish one after the other: stores flow while the rest computes.
+  int pr = 0;
+  if (A.q_prio != 0 && A.q_tile > 0) {
+    const int slot = (int)(blockIdx.x / (uint32_t)A.q_tile);
+    pr = (A.q_prio >> (2 * (slot < 8 ? slot : 7))) & 3;
+  }
+  const bool pr_late = (A.q_prio & 0x10000) != 0;  // raise the priority only once the inputs have landed and the prefetch is out
+  auto raise = [&]() {
+    if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+  };
+  if (!pr_late) raise();
+#ifdef PCG_TIMELINE  // measurement build (tools/timeline_probe.py): per-wave stamps of the 100 MHz wall clock into A.g
+  int tl_it = 0;
+#define PCG_TL(k)                                                                                              \
+  if ((threadIdx.x & 63) == 0 && A.g)                                                                          \
+  reinterpret_cast<unsigned long long*>(A.g)[((size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + tl_it) * 8 + (k)] = \
+      wall_clock64()
+#else
+#define PCG_TL(k)
+#endif
+  PCG_TL(0);
   if (live) load(e0, xv, av);
   for (;;) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) land(xv[i]);
 #pragma unroll
     for (int i = 0; i < NA; ++i) land(av[i]);
-    const int64_t itn = it + gridDim.x;
-    const int64_t e1 = itn * TILE + (int64_t)threadIdx.x * EPL;
+    PCG_TL(1);
+    const uint32_t itn = it + gridDim.x;
+    const uint32_t e1 = itn * TILE + threadIdx.x * EPL;
     const bool live_n = (itn < ntile) && (e1 < B);
     V xn[NX], an[NA];
     asm volatile("" ::: "memory");
     if (live_n) load(e1, xn, an);
     asm volatile("" ::: "memory");
+    if (pr_late) raise();
     if (live) {
       Pack<EPL> xs[NX], as[NA];
 #pragma unroll
@@ -1348,7 +1410,8 @@ __global__ __launch_bounds__(BLOCK, INTEG == PCG_INT_RK4 ? PCG_LEAN_WPE : 4) voi
 #pragma unroll
         for (int j = 0; j < EPL; ++j) as[i].v[j] = (i < na) ? Vec<EPL>::get(av[i], j) : 0.0;
       LeanOut<M, EPL> out;
-      env_step_lean<M, EPL, INTEG>(A, c, t, as, xs, out);
+      env_step_lean<M, EPL, INTEG>(A, c, L, t, as, xs, out);
+      PCG_TL(2);
       if (A.status) {  // per-env health: a fixed step can only leave a non-finite state; only failures are written
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
@@ -1365,11 +1428,20 @@ __global__ __launch_bounds__(BLOCK, INTEG == PCG_INT_RK4 ? PCG_LEAN_WPE : 4) voi
         else *reinterpret_cast<V*>(A.rew + e0) = Vec<EPL>::make(out.rew.v);
         if (EPL == 2) *reinterpret_cast<uint16_t*>(A.done + e0) = (uint16_t)0x0101u;
         else A.done[e0] = 1;
-        reset_lean<M, EPL>(A, c, e0, A.reset_seed, nt);
+        reset_lean<M, EPL>(A, c, (int64_t)e0, A.reset_seed, nt);
       } else {
-        store_lean<M, EPL>(A, c, e0, xs, out, nt);
+        store_lean<M, EPL>(A, c, L, e0, xs, out, nt);
       }
     }
+    if (pr_late) __builtin_amdgcn_s_setprio(0);
+    PCG_TL(3);
+#ifdef PCG_TIMELINE
+    if (itn >= ntile) {
+      __builtin_amdgcn_s_waitcnt(0);  // all stores of this wave acknowledged
+      PCG_TL(4);
+    }
+    tl_it = 1;
+#endif
     if (itn >= ntile) break;
     it = itn;
     e0 = e1;
@@ -1423,7 +1495,8 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel_lean(const StepArgs A) {
         if (i < na) an[i] = *reinterpret_cast<const V*>(nxt + (size_t)i * A.a_cs + e0);
     }
     asm volatile("" ::: "memory");
-    env_step_lean<M, EPL>(A, c, A.t_scalar + s, as, xs, out);
+    const PCG_CONSTANT LeanStep& L = A.lean[min(A.t_scalar + s, c.N - 1)];
+    env_step_lean<M, EPL>(A, c, L, A.t_scalar + s, as, xs, out);
     if (A.rew_seq) Vec<EPL>::store_nt(A.rew_seq + (size_t)s * A.r_ss + e0, out.rew.v);
     if (A.obs_seq) {
       double* o = A.obs_seq + (size_t)s * A.o_ss + e0;
@@ -1436,14 +1509,14 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel_lean(const StepArgs A) {
       for (int k = 0; k < PCG_MAX_NSP; ++k)
         if (k < nso) {
 #pragma unroll
-          for (int j = 0; j < EPL; ++j) tmp[j] = out.osp[k];
+          for (int j = 0; j < EPL; ++j) tmp[j] = L.osp[k];
           Vec<EPL>::store_nt(o + (size_t)(nx + k) * ocs, tmp);
         }
 #pragma unroll
       for (int k = 0; k < M::NDM; ++k)
         if (k < c.nd) {
 #pragma unroll
-          for (int j = 0; j < EPL; ++j) tmp[j] = out.od[k];
+          for (int j = 0; j < EPL; ++j) tmp[j] = L.od[k];
           Vec<EPL>::store_nt(o + (size_t)(nx + nso + k) * ocs, tmp);
         }
     }
@@ -1458,6 +1531,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel_lean(const StepArgs A) {
     }
   }
   // final state and the last step's outputs into the regular per-step buffers
+  const PCG_CONSTANT LeanStep& L = A.lean[min(A.t_scalar + A.T - 1, c.N - 1)];
   double tmp[EPL];
 #pragma unroll
   for (int i = 0; i < NX; ++i)
@@ -1469,14 +1543,14 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel_lean(const StepArgs A) {
   for (int k = 0; k < PCG_MAX_NSP; ++k)
     if (k < nso) {
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) tmp[j] = out.osp[k];
+      for (int j = 0; j < EPL; ++j) tmp[j] = L.osp[k];
       *reinterpret_cast<V*>(A.obs + (size_t)(nx + k) * B + e0) = Vec<EPL>::make(tmp);
     }
 #pragma unroll
   for (int k = 0; k < M::NDM; ++k)
     if (k < c.nd) {
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) tmp[j] = out.od[k];
+      for (int j = 0; j < EPL; ++j) tmp[j] = L.od[k];
       *reinterpret_cast<V*>(A.obs + (size_t)(nx + nso + k) * B + e0) = Vec<EPL>::make(tmp);
     }
   *reinterpret_cast<V*>(A.rew + e0) = Vec<EPL>::make(out.rew.v);
@@ -1561,7 +1635,7 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX, ros_structured<M>::val
   const typename M::Hold hold = M::hold(kp, u);
   const RhsFn<M> f{kp, hold};
   if (INTEG == PCG_INT_RK4) {
-    rk4<NX>(f, x, c.h, c.substeps);
+    rk4<NX>(f, x, c.h, c.h2, c.h6, c.substeps);
   } else if (INTEG == PCG_INT_RODAS3) {
     int nacc = 0, nrej = 0;
     const RosLds<NX> Lm(lds);

@@ -128,21 +128,38 @@ PCG_PK double rcp_ieee(double x) {
   r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
   return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
 }
-// a/b to ~0.5 ulp: Newton reciprocal, then one residual correction of the quotient (8 instructions)
+// a/b to ~0.5 ulp: hardware estimate, ONE Newton step, then one residual correction of the quotient (6 instructions).
+// v_rcp_f64 is good to 2^-24.4 (tools/issuebench.hip, 4M arguments), so r carries 2^-48.8 after one step and the corrected
+// quotient q + r (a - b q) an error of (2^-48.8)^2 relative -- below its own rounding: the second Newton step of rounds
+// 1-3 bought nothing.  (rcp_fast() keeps two: its result is used as it is.)
 PCG_PK double div_fast(double a, double b) {
-  const double r = rcp_fast(b);
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
   double q = a * r;
   q = __builtin_fma(__builtin_fma(-b, q, a), r, q);
   return q;
 }
-// exp(x) for x in [-745, 700] (clamped below; NaN propagates): Cody-Waite reduction by ln2 and a degree-13 Taylor
-// polynomial on |r| <= ln2/2 (truncation 4e-18), ~1-2 ulp.  20 VALU instructions against ~30 for the
-// library exp(), whose extra work is overflow / underflow / NaN selection.
+// exp(x) for x in [-745, 700] (clamped below; NaN propagates): Cody-Waite reduction by ln2, then 1 + r + r^2 q(r) on
+// |r| <= ln2/2 with q of degree 9: the minimax fit of tools/prototypes/exp_minimax.py (truncation 9e-18 relative with these
+// doubles; round 1-3 used the degree-13 Taylor polynomial, 4e-18: two more multiply-adds for nothing), ~1 ulp like the
+// library's.  18 VALU instructions against ~30 for the library exp(), whose extra work is overflow / underflow / NaN
+// selection.  The lower clamp replaces only the HIGH word of an argument below -745 (one compare + one 32-bit select
+// instead of a 64-bit select: the low word of such an argument moves -745 by < 5e-4, the result is the smallest
+// denormal or 0 either way), and a NaN fails the compare and stays NaN (fmax would return -745).
 PCG_PK double exp_bounded(double x) {
-  x = (x < -745.0) ? -745.0 : x;  // compare + select, not fmax: a NaN argument stays NaN (fmax would return -745)
+#ifdef PCG_EXP_TAYLOR13  // the polynomial and clamp of rounds 1-3 (A/B builds)
+  x = (x < -745.0) ? -745.0 : x;
+#else
+  {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned hi = (x < -745.0) ? 0xC0874800u : (unsigned)(b >> 32);
+    x = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (b & 0xFFFFFFFFull)));
+  }
+#endif
   const double n = __builtin_rint(x * 1.44269504088896338700e+00);
   double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
   r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+#ifdef PCG_EXP_TAYLOR13
   double p = 1.6059043836821613e-10;             // 1/13!
   p = __builtin_fma(p, r, 2.08767569878681e-09);   // 1/12!
   p = __builtin_fma(p, r, 2.505210838544172e-08);  // 1/11!
@@ -155,6 +172,18 @@ PCG_PK double exp_bounded(double x) {
   p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/4!
   p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/3!
   p = __builtin_fma(p, r, 0.5);
+#else
+  double p = 2.511003840733968e-08;
+  p = __builtin_fma(p, r, 2.7632640819274376e-07);
+  p = __builtin_fma(p, r, 2.7557242367156263e-06);
+  p = __builtin_fma(p, r, 2.4801487365644137e-05);
+  p = __builtin_fma(p, r, 0.00019841269886564062);
+  p = __builtin_fma(p, r, 0.001388888894778586);
+  p = __builtin_fma(p, r, 0.008333333333322215);
+  p = __builtin_fma(p, r, 0.041666666666522106);
+  p = __builtin_fma(p, r, 0.16666666666666674);
+  p = __builtin_fma(p, r, 0.500000000000001);
+#endif
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
   return __builtin_ldexp(p, (int)n);

@@ -185,7 +185,7 @@ PCG_DEV void env_step_feat(const StepArgs& A, CDevConst& c, int64_t e0, int t, c
   {
     const typename M::template HoldT<R> hold = M::template hold<R>(kp, u);
     const RhsFn<M, R> f{kp, hold};
-    rk4<NX>(f, x, c.h, c.substeps);
+    rk4<NX>(f, x, c.h, c.h2, c.h6, c.substeps);
   }
   // ---- SP slot uses SP[t_old] (pcgym.py:432-438, quirk Q5); t += 1 ----
   double spv[PCG_MAX_NSP], spn[PCG_MAX_NSP];
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel_feat(const StepArgs A) {
   using In = FeatIn<M, W, FT>;
   const int64_t B = A.B;
   const uint32_t flags = c.flags;
-  const bool nt = A.nt_stores != 0;
+  const bool nt = (A.nt_stores & 1) != 0;
   constexpr int64_t TILE = (int64_t)BLOCK * W;
   const int64_t ntile = (B + TILE - 1) / TILE;
   int64_t it = blockIdx.x;

@@ -111,7 +111,8 @@ class VecEnv:
             _lib.check(self._lib.pcg_plan_create(C.byref(plan), C.byref(cfg)), "pcg_plan_create")
         del keep
         self._plan = plan
-        _lib.check(self._lib.pcg_plan_set_env_offset(plan, int(env_offset)), "pcg_plan_set_env_offset")
+        self.env_offset = int(env_offset)
+        _lib.check(self._lib.pcg_plan_set_env_offset(plan, self.env_offset), "pcg_plan_set_env_offset")
         if lds_stages:
             _lib.check(self._lib.pcg_plan_set_option(plan, abi.PCG_OPT_LDS_STAGES, 1), "pcg_plan_set_option")
         if variant is None:

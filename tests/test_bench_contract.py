@@ -98,3 +98,32 @@ def test_gpus_n_as_typed_starts_its_own_ranks():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["collective_backend"] == "gloo"
     assert d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"] and d["config"]["sane"]
+
+
+@pytest.mark.parametrize("wl,batch,steps", [("cstr", 65536, 70), ("mixed", 30000, 8)])
+def test_eight_rank_launch_path_on_one_device(wl, batch, steps):
+    """No 8-GPU node is available to the builder: the EIGHT-rank code path of the command the driver types
+    (`python bench.py --gpus 8`: bench.py starts its own ranks) runs here with the ranks sharing this box's GPU over gloo,
+    for the headline and for the mixed shard.  Checked: one JSON line, eight ranks seen by the communicator, the global batch
+    = 8 x the per-GPU batch, every rank's shard starts where the previous one ends (the RNG key of an env is its global
+    index: shards must not overlap), and the host-side cost of the launch loop with eight Python ranks on one host is
+    reported on the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PCG_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", wl, "--batch", str(batch),
+                        "--steps", str(steps), "--warmup", "6", "--preheat-ms", "10"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["ranks_seen"] == 8 and c["collective_backend"] == "gloo" and c["sane"]
+    assert c["global_envs"] == 8 * c["envs_per_gpu"] and "cpu_baseline" not in d
+    assert abs(d["value"] - c["global_envs"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    offs = c["rank_first_env"]
+    assert len(offs) == 8 and offs[0] == 0 and offs == sorted(offs) and len(set(offs)) == 8
+    if wl == "cstr":
+        assert offs == [r_ * c["envs_per_gpu"] for r_ in range(8)]
+    else:  # global layout [cstr x 8 | four_tank x 8 | ME x 8]: a rank's first env is its slice of the first segment
+        n = c["envs_per_gpu"] // 3
+        assert offs == [r_ * n for r_ in range(8)]
+    assert 0 < c["host_launch_loop_us_per_step_max_over_ranks"] < 5000

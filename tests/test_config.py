@@ -523,3 +523,55 @@ def test_custom_model_without_inputs_takes_the_traced_route():
     with pytest.raises(ValueError):
         EnvSpec({"custom_model": Osc(13), "N": 20, "tsim": 10.0, "x0": np.zeros(26), "a_space": {"low": np.zeros(0), "high": np.zeros(0)},
                  "o_space": {"low": -np.ones(26), "high": np.ones(26)}, "reward_states": ["x1"], "maximise_reward": True})
+
+
+def test_tracing_a_reward_callable_leaves_its_module_alone():
+    """the trace used to swap `float` in the callable's module globals for its duration (visible to every
+    other user of that module, not thread-safe).  Now a copy of the function runs over a copy of its globals."""
+    import threading
+
+    from pcgym_amd.config import trace_reward_callable
+
+    spec = EnvSpec(copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"]))
+    seen, stop = [], threading.Event()
+
+    def reward(self, x, u, con):
+        seen.append(float is reward.__globals__.get("float", float))  # the module's own binding, untouched
+        return -float((x[0] - self.SP["Ca"][self.t]) ** 2)
+
+    def watcher():
+        g = reward.__globals__
+        while not stop.is_set():
+            if "float" in g and g["float"] is not float:
+                seen.append("mutated")
+
+    th = threading.Thread(target=watcher)
+    th.start()
+    try:
+        for _ in range(20):
+            text = trace_reward_callable(reward, spec)
+    finally:
+        stop.set()
+        th.join()
+    assert "sp[0]" in text and "mutated" not in seen and all(v is True for v in seen)
+    assert "float" not in reward.__globals__ or reward.__globals__["float"] is float
+
+    class AsMethod:
+        def r(self, env, x, u, con):
+            return -float((x[1] - 320.0) ** 2)
+
+    bound = AsMethod().r
+    assert "o[1]" in trace_reward_callable(bound, spec)
+
+
+def test_integrators_without_a_per_env_parameter_kernel_are_refused_by_name():
+    """an explicit integrator that has no per-env-parameter kernel used to surface as PCG_E_UNSUPPORTED at
+    plan creation; a disturbance input that is not a model parameter used to fall back to parameter 0 silently."""
+    p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+    p.update(uncertainty_percentages={"q": 0.1}, uncertainty_bounds={"low": np.array([80.0]), "high": np.array([120.0])},
+             distribution="uniform")
+    assert EnvSpec(copy.deepcopy(p)).integrator == "dopri5"  # the default moves to a pair that has the kernel
+    for integ in ("rodas4", "rodas3", "tsit5g", "rk4g", "cv8", "tsit5"):
+        with pytest.raises(ValueError, match="use 'rk4' or 'dopri5'"):
+            EnvSpec(dict(copy.deepcopy(p), integrator=integ))
+    assert EnvSpec(dict(copy.deepcopy(p), integrator="rk4")).nunc == 1

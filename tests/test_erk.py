@@ -151,7 +151,7 @@ def test_t5g_accepts_only_accurate_steps_and_escalates_the_rest(tsim):
         hot = max(hot, float((want[1] > 400).mean()))
         x = want
     assert worst_acc <= 1e-6 and worst_esc <= 1e-6, (worst_acc, worst_esc)
-    assert 0.25 < frac[0] < 0.6 and hot > 0.02  # the ignition branch really is in the sample
+    assert 0.25 < frac[0] < 0.7 and hot > 0.02  # the ignition branch really is in the sample
     if tsim < 2:
         return
     # the canonical closed loop (x0 = (0.8, 330 K), random jacket temperatures): never escalated
@@ -160,3 +160,32 @@ def test_t5g_accepts_only_accurate_steps_and_escalates_the_rest(tsim):
         u = rng.uniform(295, 302, (1, B))
         x, ns = O.integrate(plan, x, u)
         assert ns.sum() == 0, t
+
+
+def test_t5g_trusts_nothing_outside_the_reference_tolerance_class_on_a_wide_box():
+    """the guard alone (round 3) passed steps that were 4e-4 ... 6e-3 off outside the calibrated box.  With the
+    embedded 5(4) estimate in the acceptance (round 4) every TRUSTED env of a deliberately wide box -- Ca in [0, 1.44], T in
+    [290, 600] K, jacket 280 ... 320 K, three step sizes -- lies inside 3 x the reference's own CVODES tolerances
+    (CasADi defaults: 1e-6 |x| + 1e-8) of a 1e-13 solve (measured worst over 450,000 samples: 2.5 x at dt = 26/60, 0.43 x at
+    5/60, 0.08 x at 1/60; the reference's own known-answer test is 2 ... 7 x its tolerance away from the exact solution);
+    the two states the review named are escalated.  A tighter threshold would escalate envs of the canonical loop
+    (3e-7: 16 of 600,000 env steps; 2.5e-7: 498), tools/prototypes/t5g_est_calib.py."""
+    rng = np.random.default_rng(7)
+    for tsim in (1.0, 5.0, 26.0):
+        ref = _spec("cstr_canonical", integrator="dopri5", rtol=1e-13, atol=1e-13, tsim=tsim)
+        plan = _spec("cstr_canonical", integrator="tsit5g", tsim=tsim)
+        B = 12000
+        x = np.stack([rng.uniform(0.0, 1.2, B) ** 2, rng.uniform(290, 600, B)])
+        u = rng.uniform(280, 320, (1, B))
+        want, _ = O.integrate(ref, x, u)
+        got, ns = O.integrate(plan, x, u)
+        trusted = ns.sum(axis=0) == 0
+        scaled = (np.abs(got - want) / (1e-6 * np.abs(want) + 1e-8)).max(axis=0)
+        ok = np.isfinite(scaled)
+        assert 0.01 < trusted.mean() < 0.5, (tsim, trusted.mean())
+        assert scaled[trusted & ok].max() <= 3.0, (tsim, scaled[trusted & ok].max())
+        assert scaled[~trusted & ok].max() <= 3.0, (tsim, scaled[~trusted & ok].max())  # (the escalated ones: 1e-10 pair)
+    for ca, T, Tc, tsim in ((0.0036, 375.5, 285.7, 26.0), (0.005, 380.0, 300.0, 5.0)):
+        plan = _spec("cstr_canonical", integrator="tsit5g", tsim=tsim)
+        _, ns = O.integrate(plan, np.array([[ca], [T]]), np.array([[Tc]]))
+        assert ns.sum() > 0, (ca, T, Tc)

@@ -769,3 +769,30 @@ def test_step_graph_with_adaptive_kernels(name, B):
     assert torch.equal(e1.obs_soa, e2.obs_soa) and not e2.status.any()
     g.destroy()
     e1.close(), e2.close()
+
+
+def test_collector_steps_a_rosenbrock_plan_that_carries_a_reward_expression():
+    """multistage_extraction defaults to Rodas4; with a reward expression (or a traced custom_reward callable)
+    the plan runs from its run-time compiled module, which has no fused rollout kernel for the Rosenbrock pairs --
+    collect_rollouts(env, actions=...) used to raise PCG_E_UNSUPPORTED there instead of stepping."""
+    torch = _torch()
+    from pcgym_amd import VecEnv, collect_rollouts
+
+    p = copy.deepcopy(SC.scenarios()["me_canonical"]["env_params"])
+    p["custom_reward"] = {"expr": "-1e2*(X5 - SP_X5)*(X5 - SP_X5)"}
+    env = VecEnv(copy.deepcopy(p), n_envs=192, seed=4)
+    assert env.spec.integrator == "rodas4" and env.spec.user_reward_src
+    ref = VecEnv(copy.deepcopy(p), n_envs=192, seed=4)
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    acts = 0.3 * (2 * torch.rand((env.spec.N, env.spec.na, 192), generator=gen, device="cuda", dtype=torch.float64) - 1) - 0.6
+    out = collect_rollouts(env, actions=acts)
+    assert out["r"].shape == (1, env.spec.N, 192) and torch.isfinite(out["x"]).all() and torch.isfinite(out["r"]).all()
+    ref.reset()
+    for i in range(env.spec.N - 1):  # the same episode, stepped by hand
+        o, r, d, _, _ = ref.step(acts[i])
+        assert torch.equal(out["r"][0, i + 1], r), i
+    # the expression really is the reward: -1e2 (X5 - SP)^2 on the recorded (physical) states, reward against SP[t_new]
+    sp = torch.tensor(np.asarray(p["SP"]["X5"], dtype=float), device="cuda")
+    want = -1e2 * (out["x"][8, 1:] - sp[1:, None]) ** 2
+    assert torch.allclose(out["r"][0, 1:], want, rtol=1e-10, atol=1e-12)
+    env.close(), ref.close()

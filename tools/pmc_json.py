@@ -2,7 +2,9 @@
 """Condense the PMC passes of tools/prof_all.sh into one JSON (committed as profiles/r3/pmc.json, read by bench.py):
 per workload the dominant step kernel's mean counters per launch, HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE: the gfx950
 FETCH_SIZE correction of /opt/skills/guides/MI355X_MICROARCH.md "HBM"), and the VALU issue fraction
-4 SQ_INSTS_VALU / (1024 SIMDs x SQ_BUSY_CYCLES / 32).   usage: pmc_json.py <gpurun_out> <workload ...>"""
+4 SQ_INSTS_VALU / (1024 SIMDs x SQ_BUSY_CYCLES / 32).  Every entry carries the build id of the library the passes ran on
+(pcg_build_id(): digest of the kernel headers), and bench.py quotes an entry only for that build.
+usage: pmc_json.py <gpurun_out> <workload ...>      PMC_ROUND=r4 names the profiles/ directory in the source note"""
 import csv
 import glob
 import json
@@ -11,6 +13,14 @@ import sys
 from collections import defaultdict
 
 root, wls = sys.argv[1], sys.argv[2:]
+RND = os.environ.get("PMC_ROUND", "r4")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from pcgym_amd import _lib
+
+    BUILD_ID = _lib.load().pcg_build_id().decode()
+except Exception as e:  # noqa: BLE001
+    BUILD_ID = f"unknown ({type(e).__name__})"
 SEG = {"Model<0>": "cstr", "Model<1>": "four_tank", "Model<2>": "multistage_extraction", "Model<18>": "multistage_extraction",
        "Model<3>": "multistage_extraction_reactive", "Model<19>": "multistage_extraction_reactive", "Model<4>": "crystallization"}
 
@@ -60,7 +70,8 @@ def entry(kname, c, dur, wl):
         e["valu_issue_frac"] = 4.0 * c["SQ_INSTS_VALU"] / (1024.0 * cyc)
         if kname in dur:
             e["sq_clock_GHz"] = cyc / dur[kname][1]
-    e["source"] = (f"profiles/r3/{wl}/rocprofv3_summary.txt (tools/prof_all.sh: FETCH_SIZE, WRITE_SIZE, SQ and GRBM counters in "
+    e["build_id"] = BUILD_ID
+    e["source"] = (f"profiles/{RND}/{wl}/rocprofv3_summary.txt (tools/prof_all.sh: FETCH_SIZE, WRITE_SIZE, SQ and GRBM counters in "
                    "separate --pmc passes with --kernel-trace only; FETCH_SIZE x 2 per MI355X_MICROARCH.md HBM section); NOT "
                    "measured in the bench run itself")
     return e
@@ -78,7 +89,7 @@ for wl in wls:
             name = next((v for q, v in SEG.items() if q in k), None)
             if name and (name not in segs or c["_n"] > segs[name]["launches_in_pmc_pass"]):
                 segs[name] = entry(k, c, dur, wl)
-        res[wl] = {"segments": segs}
+        res[wl] = {"segments": segs, "build_id": BUILD_ID}
     else:
         k = max(cs, key=lambda q: cs[q]["_n"])  # the kernel of (almost) every launch of the workload
         res[wl] = entry(k, cs[k], dur, wl)
