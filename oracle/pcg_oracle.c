@@ -1014,7 +1014,7 @@ static void ep_exponents(const orc_model* m, const double* u, double ep_c, int k
     const double ct = ep_c * tau;
     const int ks = ep_trunc(ct * fmin(a, c), kmax);
     kg[0] = kg[1] = ks;
-    if (m->model_id == PCG_MODEL_ME) {
+    if (m->model_id == PCG_MODEL_ME && m->p[4] == 2.0) { /* the coupling bound is the slope of the eq_exponent == 2 curve */
       const double inv_m = 1 / m->p[2], KlaVl = m->p[3] * m->p[0];
       const double klap = iVl * KlaVl, e = iVg * KlaVl;
       const double kappa2 = (klap * 2.0 * inv_m) * 2.0, e2 = e * 2.0; /* x safety 2 */

@@ -248,6 +248,10 @@ struct MEImpl {
     const double a = u[0] * k.iVl, c = u[1] * k.iVg;
     const double ct = ep_c * tau;
     const int ks = ep_trunc(ct * __builtin_fmin(a, c), kmax);
+    if constexpr (!SQ) {  // the coupling bound below is the slope 2 Y / m of the eq_exponent == 2 curve: other exponents
+      kg[0] = kg[1] = ks;  // keep the one exponent every component is entitled to
+      return;
+    }
     const double klap = k.iVl * k.KlaVl, e = k.iVg * k.KlaVl;
     const double kappa2 = (klap * 2.0 * k.inv_m) * 2.0, e2 = e * 2.0;  // x safety 2
     const int kX = ks + ep_ilog2((a + klap) / e2), kY = ks + ep_ilog2(c / kappa2);
