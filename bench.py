@@ -585,17 +585,21 @@ def main():
         rank_offsets = [int(v) for v in offs.tolist()]
     preheat_ms = clock_preheat(torch, dev, args.preheat_ms)
     run(W, False)
+    # the timed region: K steps between (synchronize, barrier, synchronize) brackets.  With ONE rank there is no barrier and
+    # the second synchronize of each bracket has nothing to wait for -- but still costs its ~15 us round trip through the
+    # runtime (tools/region_probe.py), 5 % of a 20-step region of this kernel: it is only issued when there is a barrier
+    # whose (RCCL) work it has to drain.
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(K, True)
     t_host = time.perf_counter() - t0  # the launch loop alone (asynchronous launches: the host's cost per step while it is ahead)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     host_us = t_host / max(K, 1) * 1e6
     if dist is not None:

@@ -776,30 +776,36 @@ class EnvSpec:
         self.unc_emp = np.zeros(0)
         self.unc_emp_off = np.zeros(1, dtype=np.int32)
         self.unc_empirical = emp is not None
+        self.unc_inert = []  # quirk Q15: empirical_distribution['x0'] -- sampled and observed, never applied
         if emp is not None:
             if "x0" in emp:
-                raise ValueError("empirical_distribution['x0'] is not supported (the reference would setattr the "
-                                 "sample onto the model object, pcgym.py:311-315); use uncertainty_percentages['x0']")
+                # The reference treats 'x0' like every other key of the dict (pcgym.py:311-316): np.random.choice(table) --
+                # which needs a 1-D table -- setattr(model, 'x0', sample), and the sample appended to the observation.
+                # The model object's x0 attribute is read by nobody (the env starts from env_params['x0'], :282-284), so
+                # the sample is OBSERVED but never applied: one more slot behind the state, no effect on the dynamics.
+                if np.asarray(emp["x0"]).ndim != 1:
+                    raise ValueError("a must be 1-dimensional (empirical_distribution['x0']: np.random.choice, pcgym.py:313)")
+                self.unc_inert = ["x0"]
             up = {k: 0.0 for k in emp}  # shares the bookkeeping below; the percentages are unused
         if up is not None:
             dist = p.get("distribution", "uniform")
             if dist not in ("uniform", "normal"):
                 raise ValueError("distribution must be 'uniform' or 'normal'")
             self.x0_normal = dist == "normal"
-            if "x0" in up:
+            if "x0" in up and emp is None:
                 # the reference walks "for idx, uncertainty in enumerate(x0_uncertainty)" (pcgym.py:286-288): a
                 # sequence gives per-state fractions; a dict (tests/models/test_model.py:99) yields its KEYS
                 xu = _arr(list(up["x0"]))
                 self.x0_unc = np.zeros(self.nx)
                 n = min(self.nx, xu.shape[0])
                 self.x0_unc[:n] = xu[:n]
-            self.unc_keys = [k for k in up if k != "x0"]
+            self.unc_keys = [k for k in up if k != "x0" or k in self.unc_inert]
             if self.unc_keys:
                 if self.model.model_id in (M.AFFINE, M.USER):
                     raise ValueError("parameter uncertainty is not available for affine / custom models")
                 names = list(self.model.parameters.keys())
                 for k in self.unc_keys:
-                    if k not in names:
+                    if k not in names and k not in self.unc_inert:
                         raise ValueError(f"uncertain parameter '{k}' is not a parameter of model "
                                          f"'{self.model.name}' (available: {names})")
                 # disturbances together with parameter uncertainty: the reference writes the disturbance slots at a
@@ -808,7 +814,9 @@ class EnvSpec:
                 self.nunc = len(self.unc_keys)
                 if self.nunc > abi.PCG_MAX_NUNC:
                     raise ValueError(f"at most {abi.PCG_MAX_NUNC} uncertain parameters are supported")
-                self.unc_index = np.array([names.index(k) for k in self.unc_keys], dtype=np.int32)
+                # (an inert key takes the first index past the model's parameters: the kernels substitute it into
+                # nothing, pcg_abi.hip accepts it for empirical tables only)
+                self.unc_index = np.array([names.index(k) if k in names else len(names) for k in self.unc_keys], dtype=np.int32)
                 self.unc_pct = np.array([float(up[k]) for k in self.unc_keys], dtype=_f64)
                 if emp is not None:
                     tabs = [_arr(emp[k]) for k in self.unc_keys]
@@ -911,8 +919,8 @@ class EnvSpec:
     # ------------------------------------------------------------------------------
     def x0_full(self):
         """reference reset state [x0 | SP slots | d[:,0] | nominal uncertain parameters] (pcgym.py:284-316)."""
-        unc = (np.array([self.model.param_vector()[i] for i in self.unc_index]) if getattr(self, "nunc", 0)
-               else np.zeros(0))
+        pv = self.model.param_vector() if getattr(self, "nunc", 0) else []
+        unc = np.array([pv[i] if i < len(pv) else 0.0 for i in self.unc_index]) if getattr(self, "nunc", 0) else np.zeros(0)
         return np.concatenate([self.x0, self.d_sched[:, 0] if self.nd else np.zeros(0), unc])
 
     def _adopt_custom_model(self, m, p):

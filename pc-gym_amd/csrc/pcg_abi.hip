@@ -376,7 +376,10 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   if (!k.dynamic && !user)
     for (int i = 0; i < k.nraw && i < 32; ++i) d->raw[i] = c->params[i];
   for (int j = 0; j < nunc; ++j) {
-    if (c->unc_index[j] < 0 || c->unc_index[j] >= k.nraw) return PCG_E_DIM;
+    // index == nraw: an INERT entry (sampled at reset and observed, substituted into no model parameter) -- what the
+    // reference does with empirical_distribution['x0'] (pcgym.py:311-316); empirical tables only
+    const bool inert = (c->flags & PCG_F_UNC_EMPIRICAL) && c->unc_index[j] == k.nraw && k.nraw < 32;
+    if ((c->unc_index[j] < 0 || c->unc_index[j] >= k.nraw) && !inert) return PCG_E_DIM;
     d->unc_index[j] = c->unc_index[j];
     d->unc_pct[j] = c->unc_pct[j];
     if (c->flags & PCG_F_UNC_EMPIRICAL) {
@@ -1222,7 +1225,26 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   const DevConst& c = p->hc;
   if ((c.flags & PCG_F_A_DELTA) && !io->a_save) return PCG_E_NULL;
   if ((c.flags & PCG_F_REWARD_TRACK) && !io->u_prev) return PCG_E_NULL;
-  if (c.nunc > 0 || (p->jit_fn[0] && !p->jit_roll)) return PCG_E_UNSUPPORTED;  // per-env parameters: per-step kernel only
+  if (p->jit_fn[0] && !p->jit_roll) return PCG_E_UNSUPPORTED;
+  if (c.nunc > 0) {  // per-env parameters (sampled by the reset before the episode): the general rollout kernel's UNC form
+    if (!io->p_unc) return PCG_E_NULL;
+    const Kernels& ku = kernels(p->kid);
+    const StepFn ufn = p->jit_fn[0] ? nullptr : ku.rollout_unc[p->integrator_id];
+    if (!ufn) return PCG_E_UNSUPPORTED;  // RK4 and the explicit pair only, as for stepping
+    a.t_scalar = t0;
+    a.seed = seed;
+    a.T = T;
+    a.a_seq = a_seq;
+    a.obs_seq = obs_seq;
+    a.rew_seq = rew_seq;
+    a.a_ss = a_step_stride; a.a_cs = a_comp_stride;
+    a.o_ss = obs_step_stride; a.o_cs = obs_comp_stride;
+    a.r_ss = rew_step_stride;
+    if (a.a_cs < io->B || (obs_seq && a.o_cs < io->B)) return PCG_E_DIM;
+    const int ub = tb(false, p->integrator_id);
+    hipLaunchKernelGGL(ufn, dim3(grid_for(io->B, ub)), dim3(ub), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
   a.t_scalar = t0;
   a.seed = seed;
   a.T = T;

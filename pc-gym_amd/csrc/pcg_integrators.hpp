@@ -351,7 +351,8 @@ PCG_DEV R ch(const R& acc, const R& k, double a) {
 }
 
 // Guarded fixed-step Tsit5 (PCG_INT_T5G): nsub steps of the Tsit5 solution weights.  A step is TRUSTED when the model's guard
-// holds at every stage state and at the end state (it shares the right-hand side's Arrhenius factor) AND -- round 4 -- the
+// holds at its start and end state (it shares the right-hand side's Arrhenius factor; the five inner stage states of round
+// 3 change no decision once the estimate is checked, and were a sixth of the step's instructions) AND -- round 4 -- the
 // pair's own embedded 5(4) error estimate of every step stays below T5G_EST_RTOL |x| + T5G_EST_ATOL (RMS over the
 // components, the norm of the adaptive pairs).  The estimate needs k7 = f(x_new): that evaluation is the next step's first
 // stage (FSAL) and the end-state guard, so the estimate costs its seven weights only.  Calibration
@@ -387,25 +388,20 @@ PCG_DEV void t5_guarded(const K& kp, const typename M::template HoldT<R>& hold, 
   for (int s = 0; s < nsub; ++s) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch0(k1[i], a21), h, x[i]);
-    M::rhs_guard(kp, hold, y, k2, g, rho);
-    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+    M::rhs(kp, hold, y, k2);
 #pragma unroll
     for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch(ch0(k1[i], a31), k2[i], a32), h, x[i]);
-    M::rhs_guard(kp, hold, y, k3, g, rho);
-    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+    M::rhs(kp, hold, y, k3);
 #pragma unroll
     for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch(ch(ch0(k1[i], a41), k2[i], a42), k3[i], a43), h, x[i]);
-    M::rhs_guard(kp, hold, y, k4, g, rho);
-    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+    M::rhs(kp, hold, y, k4);
 #pragma unroll
     for (int i = 0; i < NX; ++i) y[i] = pk_fma(ch(ch(ch(ch0(k1[i], a51), k2[i], a52), k3[i], a53), k4[i], a54), h, x[i]);
-    M::rhs_guard(kp, hold, y, k5, g, rho);
-    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+    M::rhs(kp, hold, y, k5);
 #pragma unroll
     for (int i = 0; i < NX; ++i)
       y[i] = pk_fma(ch(ch(ch(ch(ch0(k1[i], a61), k2[i], a62), k3[i], a63), k4[i], a64), k5[i], a65), h, x[i]);
-    M::rhs_guard(kp, hold, y, k6, g, rho);
-    guard_acc<R, W>(g, rho, h, T5G_SLOW_LIMIT, calm, slow);
+    M::rhs(kp, hold, y, k6);
 #pragma unroll
     for (int i = 0; i < NX; ++i)
       xn[i] = pk_fma(ch(ch(ch(ch(ch(ch0(k1[i], b1), k2[i], b2), k3[i], b3), k4[i], b4), k5[i], b5), k6[i], b6), h, x[i]);

@@ -1559,7 +1559,9 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel_lean(const StepArgs A) {
 }
 
 // Open-loop fused rollout: T env steps with x in registers ("next" row f-1).
-template <class M, int INTEG, bool LDS_STAGES>
+// UNC: per-env uncertain parameters (p_unc, sampled by the reset that precedes the episode: pcgym.py:300-316), as in
+// step_kernel<..., UNC>.
+template <class M, int INTEG, bool LDS_STAGES, bool UNC = false>
 __global__ __launch_bounds__(tb(LDS_STAGES, INTEG)) void rollout_kernel(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   CDevConst& c = *A.C;
@@ -1579,10 +1581,10 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG)) void rollout_kernel(const St
     for (int i = 0; i < NA; ++i) a[i] = (i < na) ? as[(size_t)i * A.a_cs + e] : 0.0;
     const bool last = (s == A.T - 1);
     EnvOut<M> out;
-    env_step<M, INTEG, false, LDS_STAGES, true>(A, c, lds, lds, e, A.t_scalar + s, a, x, out);
+    env_step<M, INTEG, false, LDS_STAGES, true, UNC>(A, c, lds, lds, e, A.t_scalar + s, a, x, out);
     if (A.rew_seq) A.rew_seq[(size_t)s * A.r_ss + e] = out.rew;
-    if (A.obs_seq) store_obs<M>(A, c, out, A.obs_seq + (size_t)s * A.o_ss + e, A.o_cs);
-    if (last || !A.obs_seq) store_out<M>(A, c, e, out, A.obs + e);  // io->obs/rew/done hold the last step
+    if (A.obs_seq) store_obs<M, UNC>(A, c, out, A.obs_seq + (size_t)s * A.o_ss + e, A.o_cs);
+    if (last || !A.obs_seq) store_out<M, UNC>(A, c, e, out, A.obs + e);  // io->obs/rew/done hold the last step
   }
 #pragma unroll
   for (int i = 0; i < NX; ++i)
@@ -1745,6 +1747,7 @@ struct Kernels {
   StepFn pipe_ar[2][2];              // the same with the same-launch auto-reset path compiled in
   StepFn roll_lean[2];               // RK4 lean fused rollout [EPL-1] (may be null)
   StepFn rollout[PCG_INT_COUNT][2];  // [integrator][lds_stages]
+  StepFn rollout_unc[PCG_INT_COUNT]; // fused rollout with per-env parameters (RK4, DOPRI5; null for affine)
   RhsKFn rhs;
   IntKFn integ[PCG_INT_COUNT][2];
   int nx, na, ndm, nraw;
@@ -1825,6 +1828,8 @@ Kernels make_kernels() {
     k.step_unc[PCG_INT_RK4][1] = step_kernel<M, PCG_INT_RK4, true, false, true, true>;
     k.step_unc[PCG_INT_DOPRI5][0] = step_kernel<M, PCG_INT_DOPRI5, false, false, true, true>;
     k.step_unc[PCG_INT_DOPRI5][1] = step_kernel<M, PCG_INT_DOPRI5, true, false, true, true>;
+    k.rollout_unc[PCG_INT_RK4] = rollout_kernel<M, PCG_INT_RK4, false, true>;
+    k.rollout_unc[PCG_INT_DOPRI5] = rollout_kernel<M, PCG_INT_DOPRI5, false, true>;
   }
   if constexpr (M::FULL) {
     // DOPRI5 with the stage vectors in LDS (PCG_OPT_LDS_STAGES)

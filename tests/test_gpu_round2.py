@@ -796,3 +796,46 @@ def test_collector_steps_a_rosenbrock_plan_that_carries_a_reward_expression():
     want = -1e2 * (out["x"][8, 1:] - sp[1:, None]) ** 2
     assert torch.allclose(out["r"][0, 1:], want, rtol=1e-10, atol=1e-12)
     env.close(), ref.close()
+
+
+@pytest.mark.parametrize("integrator", ["rk4", "dopri5"])
+def test_fused_rollout_with_per_env_parameters_matches_stepping(integrator):
+    """pcg_rollout refused plans with per-env uncertain parameters (the reference resamples them at
+    every reset(), pcgym.py:300-316, then rolls the episode, policy_evaluation.py:71-130).  The general rollout kernel now
+    has the per-env-parameter form of the step kernels: same states, observations (incl. the parameter slots) and rewards
+    as stepping, and collect_rollouts() takes the fused path."""
+    torch = _torch()
+    from pcgym_amd import VecEnv, collect_rollouts
+
+    p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+    p.pop("noise", None), p.pop("noise_percentage", None)
+    # (small spreads: no env ignites -- a fixed step on the ignition branch ends in NaN on both paths alike)
+    p.update(uncertainty_percentages={"UA": 0.02, "x0": [0.01, 0.003], "Caf": 0.02}, distribution="uniform",
+             uncertainty_bounds={"low": np.array([4e4, 0.9]), "high": np.array([6e4, 1.1])}, integrator=integrator)
+    if integrator == "rk4":
+        p["substeps"] = 4
+    B = 1024
+    e1, e2 = VecEnv(copy.deepcopy(p), n_envs=B, seed=31), VecEnv(copy.deepcopy(p), n_envs=B, seed=31)
+    assert e1.spec.nunc == 2
+    N = e1.spec.N
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    acts = 2 * torch.rand((N, 1, B), generator=gen, device="cuda", dtype=torch.float64) - 1
+    e1.reset(), e2.reset()
+    assert torch.equal(e1.p_unc, e2.p_unc) and float(e1.p_unc[0].std()) > 3e2  # UA really differs from env to env
+    obs_seq, rew_seq = e1.rollout(acts[:N - 1], collect_obs=True)
+    for t in range(N - 1):
+        o, r, d, _, _ = e2.step(acts[t])
+        # (the two kernels contract multiply-adds differently; envs whose UA draw puts them near ignition amplify that
+        # last-bit difference step by step: tight for the bulk, 1e-7 for every env)
+        assert torch.isfinite(e2.obs_soa).all(), t
+        d = (e2.obs_soa - obs_seq[t]).abs()
+        assert float(d.median()) <= 1e-13 and torch.allclose(e2.obs_soa, obs_seq[t], rtol=1e-9, atol=1e-11), (t, float(d.max()))
+        assert torch.allclose(r, rew_seq[t], rtol=1e-8, atol=1e-10), t
+    assert torch.allclose(e1.x, e2.x, rtol=1e-9, atol=1e-11) and not e1.status.any()
+    # the collector: fused now, in the reference's axis order, parameter slots included in x
+    e3 = VecEnv(copy.deepcopy(p), n_envs=B, seed=31)
+    out = collect_rollouts(e3, actions=acts)
+    assert out["x"].shape == (e3.spec.nobs, N, B) and torch.isfinite(out["x"]).all()
+    assert torch.allclose(out["r"][0, 1:], rew_seq.reshape(N - 1, B), rtol=1e-11, atol=1e-13)  # (the same kernel twice)
+    for e in (e1, e2, e3):
+        e.close()

@@ -237,3 +237,57 @@ def test_reference_model_that_cannot_be_traced_is_refused():
     g = H.gold("rhs_nonsmooth_control")
     with pytest.raises(ValueError, match="control flow|not a scalar"):
         trace_callable(lambda xx, uu: m(xx, uu), [2, 1], [np.concatenate([g["x"][0], g["u"][0]])], "nonsmooth_control")
+
+
+def test_empirical_distribution_x0_is_observed_but_never_applied_like_the_reference(ref):
+    """the reference treats the key 'x0' of `empirical_distribution` like any parameter
+    (pcgym.py:311-316): np.random.choice(table), setattr(model, 'x0', sample), sample appended to the state.  Nobody reads
+    the model's x0 attribute, so the initial state is env_params['x0'] whatever was drawn, and the observation grows by one
+    slot holding a table entry.  Same structure here (values differ: the reference draws from np.random, quirk Q8); a 2-D
+    table is refused on both sides (np.random.choice)."""
+    import scenarios as SC
+    from oracle import oracle as O
+    from pcgym_amd.config import EnvSpec
+
+    import helpers as H
+
+    p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+    p.pop("noise", None), p.pop("noise_percentage", None)
+    tab = {"UA": np.linspace(4.5e4, 5.5e4, 7), "x0": np.array([0.1, 0.2, 0.3]), "Caf": np.array([0.95, 1.0, 1.05])}
+    p.update(empirical_distribution=copy.deepcopy(tab), normalise_o=False,
+             uncertainty_bounds={"low": np.array([4e4, 0.0, 0.9]), "high": np.array([6e4, 1.0, 1.1])})
+    np.random.seed(3)
+    env = ref.make_env(copy.deepcopy(p))
+    seen = set()
+    for ep in range(12):
+        o, _ = env.reset()
+        o = np.asarray(o, dtype=float)
+        assert o.shape == (6,) and np.array_equal(o[:3], np.asarray(p["x0"], dtype=float))  # start state untouched
+        assert o[3] in tab["UA"] and o[4] in tab["x0"] and o[5] in tab["Caf"]
+        seen.add(float(o[4]))
+        o2, r, d, _, _ = env.step(np.zeros(1))
+        assert np.asarray(o2)[4] == o[4]  # the slot is carried along, never used
+    assert len(seen) >= 2
+    spec = EnvSpec(dict(copy.deepcopy(p), **H.tight_for(p)))
+    assert spec.unc_keys == ["UA", "x0", "Caf"] and spec.nobs == 6
+    orc = O.OracleEnv(spec, 64, seed=5)
+    oo = orc.reset()
+    assert np.array_equal(oo[:3], np.tile(np.asarray(p["x0"], dtype=float)[:, None], (1, 64)))
+    assert np.isin(oo[3], tab["UA"]).all() and np.isin(oo[4], tab["x0"]).all() and np.isin(oo[5], tab["Caf"]).all()
+    assert len(np.unique(oo[4])) == 3
+    # the dynamics see UA and Caf, not the x0 slot: same step as a spec without the x0 table and the same two draws
+    q = copy.deepcopy(p)
+    q["empirical_distribution"] = {"UA": tab["UA"], "Caf": tab["Caf"]}
+    q["uncertainty_bounds"] = {"low": np.array([4e4, 0.9]), "high": np.array([6e4, 1.1])}
+    o2 = O.OracleEnv(EnvSpec(dict(q, **H.tight_for(q))), 64, seed=5)
+    o2.reset()
+    o2.p_unc[0], o2.p_unc[1] = orc.p_unc[0], orc.p_unc[2]
+    a = np.random.default_rng(0).uniform(-1, 1, (1, 64))
+    orc.step(a), o2.step(a)
+    assert np.array_equal(orc.x, o2.x)
+    bad = copy.deepcopy(p)
+    bad["empirical_distribution"]["x0"] = np.array([[0.8, 330.0], [0.9, 320.0]])
+    with pytest.raises(ValueError, match="1-dimensional"):
+        EnvSpec(bad)
+    with pytest.raises(ValueError):
+        ref.make_env(copy.deepcopy(bad)).reset()
