@@ -344,8 +344,14 @@ def test_empirical_distribution_parsing_and_oracle_sampling():
     p["uncertainty_bounds"] = {"low": np.array([4e4]), "high": np.array([6.5e4])}
     with pytest.raises(ValueError, match="at least one sample"):
         EnvSpec(p)
-    p["empirical_distribution"] = {"x0": [1.0]}
-    with pytest.raises(ValueError, match="not supported"):
+    # 'x0' as a key: an observed-only slot, as in the reference (quirk Q15, tests/test_oracle_vs_reference_live.py); a 2-D
+    # table is refused like np.random.choice refuses it
+    p["empirical_distribution"] = {"x0": [1.0, 2.0]}
+    p["uncertainty_bounds"] = {"low": np.array([0.0]), "high": np.array([3.0])}
+    s1 = EnvSpec(p)
+    assert s1.unc_keys == ["x0"] and s1.nunc == 1 and int(s1.unc_index[0]) == len(s1.model.parameters)
+    p["empirical_distribution"] = {"x0": [[0.8, 330.0], [0.9, 320.0]]}
+    with pytest.raises(ValueError, match="1-dimensional"):
         EnvSpec(p)
 
 

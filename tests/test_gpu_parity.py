@@ -1334,6 +1334,13 @@ def test_parameter_uncertainty_vs_oracle():
     p.update(empirical_distribution={"UA": np.linspace(4.5e4, 5.5e4, 7), "Caf": np.array([0.95, 1.0, 1.05])},
              uncertainty_bounds={"low": np.array([4e4, 0.9]), "high": np.array([6e4, 1.1])})
     cases.append((p, 1e-10))  # UA down to 4.5e4 puts some envs close to ignition: rounding differences grow
+    # quirk Q15: the key 'x0' of empirical_distribution is sampled and OBSERVED, never applied (pcgym.py:311-316): an inert
+    # slot between the two real parameters
+    p = copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"])
+    _rk4_if_cstr(p)
+    p.update(empirical_distribution={"UA": np.linspace(4.8e4, 5.2e4, 5), "x0": np.array([0.1, 0.2, 0.3]), "Caf": np.array([0.98, 1.0, 1.02])},
+             uncertainty_bounds={"low": np.array([4e4, 0.0, 0.9]), "high": np.array([6e4, 1.0, 1.1])})
+    cases.append((p, 1e-11))
     # disturbances TOGETHER with uncertain parameters (quirk Q11: layout [x | SP | d | unc] in reset and step): Ti follows
     # its schedule, Caf -- a model disturbance input that is NOT configured -- takes each env's own uncertain value
     p = copy.deepcopy(SC.scenarios()["cstr_dist_Ti"]["env_params"])
