@@ -301,7 +301,7 @@ _PMC = None
 
 
 def committed_pmc(workload, build_id):
-    """per-launch counters of this workload's dominant kernel from the committed rocprofv3 PMC passes (profiles/r*/pmc.json,
+    """per-launch counters of this workload's dominant kernel from the committed rocprofv3 PMC passes (profiles/r4/pmc.json,
     made by tools/prof_all.sh + tools/pmc_json.py on the GPU box; FETCH_SIZE x 2 per MI355X_MICROARCH.md's gfx950 note).
     NOT measured in this run: hardware counters cannot be read from inside the process.  An entry is quoted only when it was
     taken on THIS build of the library (pcg_build_id(): a digest of the kernel headers): -> (entry or None, reason)."""
@@ -752,6 +752,9 @@ def main():
                     # 1024 SIMDs, cycles = GRBM_GUI_ACTIVE of the dispatch -- independent of any flop weighting
                     rl["valu_issue_frac"] = pm["valu_issue_frac"]
                     rl["valu_insts_per_launch"] = pm["SQ_INSTS_VALU_per_launch"]
+                    if "valu_issue_time_frac_at_2p4ns" in pm:
+                        # the same count priced at the measured 2.4 ns per fp64 wave-instruction per SIMD (tools/issuebench.hip)
+                        rl["valu_issue_time_frac_at_2p4ns"] = pm["valu_issue_time_frac_at_2p4ns"]
             if fp64:
                 f_survey = {"crystallization": 80 + 2 + 3 + 1 + 6}.get(spec.model.name)  # "~80 flop + 2 exp + 3 pow + 1 sqrt + ~6 div" counted as one flop each
                 rl["flop_weighting"] = ("flop per RHS evaluation = SURVEY.md section 8(a)'s count" if f_survey is None else

@@ -70,6 +70,9 @@ def entry(kname, c, dur, wl):
         e["valu_issue_frac"] = 4.0 * c["SQ_INSTS_VALU"] / (1024.0 * cyc)
         if kname in dur:
             e["sq_clock_GHz"] = cyc / dur[kname][1]
+            # the same instruction count priced at the MEASURED issue cost of an fp64 wave-instruction (tools/issuebench.hip:
+            # 2.1-2.5 ns per SIMD, i.e. ~5 cycles, not 4): the share of the launch its SIMDs spend issuing vector work
+            e["valu_issue_time_frac_at_2p4ns"] = c["SQ_INSTS_VALU"] * 2.4 / 1024.0 / dur[kname][1]
     e["build_id"] = BUILD_ID
     e["source"] = (f"profiles/{RND}/{wl}/rocprofv3_summary.txt (tools/prof_all.sh: FETCH_SIZE, WRITE_SIZE, SQ and GRBM counters in "
                    "separate --pmc passes with --kernel-trace only; FETCH_SIZE x 2 per MI355X_MICROARCH.md HBM section); NOT "
