@@ -253,18 +253,17 @@ PCG_PK void sincospi_unit(double x, double& s, double& c) {
 }
 
 // sqrt(x) for x >= 0 in the normal range (exact 0 -> 0; negative -> NaN like the library): hardware reciprocal-
-// square-root estimate (relative error <= 2^-24), one coupled Goldschmidt step (-> 1.5 * 2^-48), one residual
-// correction (-> below the rounding of the operations themselves: <= 1 ulp).  9 VALU instructions against ~25 for the
-// library sqrt(), whose extra work is the 2^+-256 rescaling for huge / denormal arguments.  The estimate is taken at
-// x + 2^-1000, which is x itself for every x >= 2^-947 and turns the 0 * inf of an exact zero into 0 * 2^500 = 0
-// without a compare-and-select (round 2's first version had one, and a second residual correction that only moved
-// the last bit: four_tank spends two thirds of its instructions in this function -- 52.9 -> 46 us per step).
+// square-root estimate y (relative error <= 2^-24), g = x y, then ONE Newton step of the square root with the unrefined
+// half-estimate, g + (y/2)(x - g^2): relative error (2^-24)^2 / 2 = 2^-49 (measured against sqrt(): tests/test_gpu_parity.py
+// RHS parity at 1e-12 holds with two decades to spare).  6 VALU instructions -- one of them the 7.3-ns estimate
+// (profiles/r4/issuebench.txt) -- against ~25 for the library sqrt(), whose extra work is the 2^+-256 rescaling for huge /
+// denormal arguments.  Rounds 2-3 spent 9: a coupled Goldschmidt refinement of BOTH g and y/2 before the same correction,
+// for a last-bit result nothing downstream of a 1e-7-accurate integrator needs; four_tank spends half of its instructions
+// in this function.  The estimate is taken at x + 2^-1000, which is x itself for every x >= 2^-947 and turns the 0 * inf of
+// an exact zero into 0 * 2^500 = 0 without a compare-and-select.
 PCG_PK double sqrt_pos(double x) {
   const double y = __builtin_amdgcn_rsq(x + 0x1p-1000);
-  double g = x * y, h = 0.5 * y;
-  const double r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g);
-  h = __builtin_fma(h, r, h);
+  const double g = x * y, h = 0.5 * y;
   return __builtin_fma(__builtin_fma(-g, g, x), h, g);
 }
 template <int W>
