@@ -996,6 +996,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   a.t_scalar = t;
   a.seed = seed;
   const bool per_env_t = io->t != nullptr;
+  if (!per_env_t && t < 0) return PCG_E_VALUE;  // the lock-stepped counter indexes the schedules (t past N-1 clamps, t < 0 cannot)
   const Kernels& k = kernels(p->kid);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
   const int knx = p->model_id == PCG_MODEL_USER ? p->nx : k.nx;  // the kernels' compile-time state count

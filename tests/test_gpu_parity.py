@@ -1427,3 +1427,25 @@ def test_random_configurations_rosenbrock_vs_oracle(seed):
         assert np.mean(dg.cpu().numpy().astype(np.uint8)[ok] == dc[ok]) >= 0.99, (seed, i)
         env.x.copy_(torch.tensor(orc.x, device=env.device))
     env.close()
+
+
+def test_negative_lock_stepped_counter_is_refused():
+    """the lock-stepped step counter indexes the schedules and the per-step table of the lean kernels: past the end it
+    clamps (the reference's arrays end there), below zero it is a caller error -- PCG_E_VALUE, no launch"""
+    import copy
+
+    torch = _torch()
+    from pcgym_amd import VecEnv, _abi
+
+    env = VecEnv(copy.deepcopy(SC.scenarios()["cstr_canonical"]["env_params"]), n_envs=512, seed=1)
+    env.reset()
+    a = torch.zeros((1, 512), dtype=torch.float64, device=env.device)
+    env._buf.a = a.data_ptr()
+    x0 = env.x.clone()
+    rc = env._lib.pcg_step(env._plan, env._bufp, -1, 1, env._stream())
+    torch.cuda.synchronize()
+    assert rc == _abi.PCG_E_VALUE and torch.equal(env.x, x0)
+    rc = env._lib.pcg_step(env._plan, env._bufp, env.spec.N + 5, 1, env._stream())  # past the end: clamped, steps
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.isfinite(env.x).all() and not torch.equal(env.x, x0)
+    env.close()
