@@ -753,14 +753,23 @@ static int t5g(const orc_model* m, double* x, const double* u, double dt, int ns
     rhs_int(m, xn, u, k7);
     for (int i = 0; i < nx; ++i)
       err[i] = h * lc7(e[0], k1[i], e[1], k2[i], e[2], k3[i], e[3], k4[i], e[4], k5[i], e[5], k6[i], e[6], k7[i]);
-    { /* mean square of err_i / (tol + tol max(|x_i|, |xn_i|)) < 1 (NaN fails) */
-      double s2 = 0.0;
+    { /* mean over the components of (err_i / sc_i)^2 < 1, sc_i = atol + rtol max(|x_i|, |xn_i|) (NaN fails); for two
+       * states written without divisions -- err_0^2 sc_1^2 + err_1^2 sc_0^2 < 2 sc_0^2 sc_1^2 -- as the kernel does */
+      double e2[MAXNX], c2[MAXNX];
       for (int i = 0; i < nx; ++i) {
         double a0 = fabs(x[i]), a1 = fabs(xn[i]);
-        double q = err[i] / (g_t5g_est_atol + g_t5g_est_tol * (a0 > a1 ? a0 : a1));
-        s2 += q * q;
+        double sc = g_t5g_est_atol + g_t5g_est_tol * (a0 > a1 ? a0 : a1);
+        e2[i] = err[i] * err[i];
+        c2[i] = sc * sc;
       }
-      if (!(s2 * (1.0 / nx) < 1.0)) sharp = 0;
+      int ok;
+      if (nx == 2) ok = (e2[0] * c2[1] + e2[1] * c2[0]) < 2.0 * (c2[0] * c2[1]);
+      else {
+        double s2 = 0.0;
+        for (int i = 0; i < nx; ++i) s2 += e2[i] / c2[i];
+        ok = s2 * (1.0 / nx) < 1.0;
+      }
+      if (!ok) sharp = 0;
     }
     for (int i = 0; i < nx; ++i) { x[i] = xn[i]; k1[i] = k7[i]; }
   }

@@ -1358,16 +1358,19 @@ __global__ __launch_bounds__(BLOCK, INTEG == PCG_INT_RK4 ? PCG_LEAN_WPE : 4) voi
         if (i < na) ad[i] = *row_at<V>(A.a + (size_t)i * Bs, o8);
     }
   };
-  // Issue priority by residency slot (q_prio: 2 bits per slot, q_tile: workgroups per slot = CUs; 0 = off).  The waves of a
-  // SIMD all receive their inputs within a microsecond of each other; at equal priority they share the vector unit
-  // round-robin and finish TOGETHER, microseconds later, so the stores of the whole grid leave in one burst at the end
-  // (tools/timeline_probe.py).  Distinct priorities let them finish one after the other: stores flow while the rest computes.
+  // MEASUREMENT SWITCH (PCG_LEAN_PRIO, off by default): issue priority by residency slot -- q_prio holds 2 bits per slot
+  // (slot = blockIdx / CUs, q_tile = CUs), bit 16 raises the priority only once the inputs have landed and the prefetch is
+  // out.  The idea: the waves of a SIMD receive their inputs within a microsecond of each other, share the vector unit
+  // round-robin and finish together, so the grid's stores leave in one burst at the end (tools/timeline_probe.py); distinct
+  // priorities would let them finish one after the other.  Measured (profiles/r4/headline/s4, s5): set at wave start it
+  // delays the low-priority waves' own loads by up to 7 us (+1.3 us per launch); set late it is inside the noise.  Kept for
+  // the next attempt, costs three scalar instructions when off.
   int pr = 0;
   if (A.q_prio != 0 && A.q_tile > 0) {
     const int slot = (int)(blockIdx.x / (uint32_t)A.q_tile);
     pr = (A.q_prio >> (2 * (slot < 8 ? slot : 7))) & 3;
   }
-  const bool pr_late = (A.q_prio & 0x10000) != 0;  // raise the priority only once the inputs have landed and the prefetch is out
+  const bool pr_late = (A.q_prio & 0x10000) != 0;
   auto raise = [&]() {
     if (pr == 3) __builtin_amdgcn_s_setprio(3);
     else if (pr == 2) __builtin_amdgcn_s_setprio(2);
