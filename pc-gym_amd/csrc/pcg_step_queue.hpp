@@ -103,7 +103,14 @@ PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double d
     h = dt - L.t;
     last = true;
   }
-  double y[NX], kk[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX];
+  // ACCUMULATOR FORM.  The stage sums are left-to-right fused multiply-add chains (lcN()): once k4 is there, the partial
+  // sums of the rows still to come (stage 6, the 5th-order solution, the error estimate) are formed and k2..k4 are dead;
+  // k5 and k6 are folded in as they arrive.  The same operations on the same operands in the same order as
+  //   y6 = x + h lc5(a61 k1 .. a65 k5),  y7 = x + h lc5(b1 k1 .. b6 k6),  w = h lc6(e1 k1 .. e7 k7)
+  // -- bit for bit -- with at most six NX-vectors alive instead of eight: the 20-state cascade's attempt carried 216
+  // 8-byte moves to and from the accumulation registers (256 + 166 registers: one wave per SIMD) for 1390 fp64
+  // operations; the 10-state one fits either way.
+  double y[NX], kk[NX], k2[NX], k3[NX], s6[NX], s7[NX], se[NX];
   const double (&x)[NX] = L.x;
   const double (&k1)[NX] = L.k1;
 #pragma unroll
@@ -114,22 +121,34 @@ PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double d
   f(y, k3);
 #pragma unroll
   for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc3(a41, k1[i], a42, k2[i], a43, k3[i]), x[i]);
-  f(y, k4);
+  f(y, kk);  // k4
 #pragma unroll
-  for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc4(a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]), x[i]);
-  f(y, k5);
+  for (int i = 0; i < NX; ++i) {
+    y[i] = axpy(h, lc4(a51, k1[i], a52, k2[i], a53, k3[i], a54, kk[i]), x[i]);
+    s6[i] = lc4(a61, k1[i], a62, k2[i], a63, k3[i], a64, kk[i]);
+    s7[i] = lc3(b1, k1[i], b3, k3[i], b4, kk[i]);
+    se[i] = lc3(e1, k1[i], e3, k3[i], e4, kk[i]);
+  }
+  f(y, k2);  // k5
 #pragma unroll
-  for (int i = 0; i < NX; ++i)
-    y[i] = axpy(h, lc5(a61, k1[i], a62, k2[i], a63, k3[i], a64, k4[i], a65, k5[i]), x[i]);
-  f(y, k6);
+  for (int i = 0; i < NX; ++i) {
+    y[i] = axpy(h, __builtin_fma(a65, k2[i], s6[i]), x[i]);
+    s7[i] = __builtin_fma(b5, k2[i], s7[i]);
+    se[i] = __builtin_fma(e5, k2[i], se[i]);
+  }
+  f(y, k3);  // k6
 #pragma unroll
-  for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc5(b1, k1[i], b3, k3[i], b4, k4[i], b5, k5[i], b6, k6[i]), x[i]);
+  for (int i = 0; i < NX; ++i) {
+    s7[i] = __builtin_fma(b6, k3[i], s7[i]);
+    y[i] = axpy(h, s7[i], x[i]);
+    se[i] = __builtin_fma(e6, k3[i], se[i]);
+  }
   f(y, kk);  // k7 at the 5th-order solution (FSAL)
   // error estimate and its scaled mean square in one pass (ms_scaled() without the intermediate vector)
   double E2 = 0.0;
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    const double wi = h * lc6(e1, k1[i], e3, k3[i], e4, k4[i], e5, k5[i], e6, k6[i], e7, kk[i]);
+    const double wi = h * __builtin_fma(e7, kk[i], se[i]);
     const double sc = atol + rtol * fmax(fabs(x[i]), fabs(y[i]));
     const double r = wi * fast_rcp(sc);  // sc > 0
     E2 += (i < n) ? r * r : 0.0;
