@@ -516,6 +516,17 @@ static double lc6(double c1, double k1, double c2, double k2, double c3, double 
   return fma(c6, k6, lc5(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5));
 }
 static double axpy(double h, double s, double x) { return fma(h, s, x); }
+/* x + c1 k1 + ... + cN kN, left to right from x, the step size folded into the coefficients: twin of xlc1..xlc5 */
+static double xlc1(double x, double c1, double k1) { return fma(c1, k1, x); }
+static double xlc2(double x, double c1, double k1, double c2, double k2) { return fma(c2, k2, xlc1(x, c1, k1)); }
+static double xlc3(double x, double c1, double k1, double c2, double k2, double c3, double k3) { return fma(c3, k3, xlc2(x, c1, k1, c2, k2)); }
+static double xlc4(double x, double c1, double k1, double c2, double k2, double c3, double k3, double c4, double k4) {
+  return fma(c4, k4, xlc3(x, c1, k1, c2, k2, c3, k3));
+}
+static double xlc5(double x, double c1, double k1, double c2, double k2, double c3, double k3, double c4, double k4, double c5,
+                   double k5) {
+  return fma(c5, k5, xlc4(x, c1, k1, c2, k2, c3, k3, c4, k4));
+}
 
 /* Step-size factors are quantised to 6 mantissa bits (truncation) -- part of the controller's specification
  * (DESIGN.md "Adaptive stepping"): the grid makes the step-size sequence independent of how E^(-1/5) is evaluated
@@ -543,6 +554,9 @@ static int dopri5(const orc_model* m, double* x, const double* u, double dt, dou
                       e6 = 22.0 / 525, e7 = -1.0 / 40;
   (void)c2; (void)c3; (void)c4; (void)c5;
   int nx = m->nx;
+  /* the tableau rows with the step size folded into the coefficients where that is cheaper (dp5_fold() in
+   * pcg_integrators.hpp: by the kernel's compile-time state count -- 8 for the padded affine model) */
+  const int fold = (nx > 4 && nx <= 16) || m->model_id == PCG_MODEL_AFFINE;
   double k1[MAXNX], k2[MAXNX], k3[MAXNX], k4[MAXNX], k5[MAXNX], k6[MAXNX], k7[MAXNX];
   double y[MAXNX], ynew[MAXNX], err[MAXNX];
   int acc = 0, rej = 0;
@@ -570,22 +584,40 @@ static int dopri5(const orc_model* m, double* x, const double* u, double dt, dou
     int last = 0;
     if (acc + rej >= max_steps) { status = 1; break; }
     if (t + h >= dt * (1.0 - 1e-14)) { h = dt - t; last = 1; }
-    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc1(a21, k1[i]), x[i]);
-    rhs_int(m, y, u, k2);
-    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc2(a31, k1[i], a32, k2[i]), x[i]);
-    rhs_int(m, y, u, k3);
-    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc3(a41, k1[i], a42, k2[i], a43, k3[i]), x[i]);
-    rhs_int(m, y, u, k4);
-    for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc4(a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]), x[i]);
-    rhs_int(m, y, u, k5);
-    for (int i = 0; i < nx; ++i)
-      y[i] = axpy(h, lc5(a61, k1[i], a62, k2[i], a63, k3[i], a64, k4[i], a65, k5[i]), x[i]);
-    rhs_int(m, y, u, k6);
-    for (int i = 0; i < nx; ++i)
-      ynew[i] = axpy(h, lc5(b1, k1[i], b3, k3[i], b4, k4[i], b5, k5[i], b6, k6[i]), x[i]);
-    rhs_int(m, ynew, u, k7);
-    for (int i = 0; i < nx; ++i)
-      err[i] = h * lc6(e1, k1[i], e3, k3[i], e4, k4[i], e5, k5[i], e6, k6[i], e7, k7[i]);
+    if (fold) { /* x + (h a_i1) k1 + ...: the coefficients times the step size, once per attempt (dp5_row<true>) */
+      const double ha21 = h * a21, ha31 = h * a31, ha32 = h * a32, ha41 = h * a41, ha42 = h * a42, ha43 = h * a43;
+      const double ha51 = h * a51, ha52 = h * a52, ha53 = h * a53, ha54 = h * a54;
+      const double ha61 = h * a61, ha62 = h * a62, ha63 = h * a63, ha64 = h * a64, ha65 = h * a65;
+      const double hb1 = h * b1, hb3 = h * b3, hb4 = h * b4, hb5 = h * b5, hb6 = h * b6;
+      const double he1 = h * e1, he3 = h * e3, he4 = h * e4, he5 = h * e5, he6 = h * e6, he7 = h * e7;
+      for (int i = 0; i < nx; ++i) y[i] = xlc1(x[i], ha21, k1[i]);
+      rhs_int(m, y, u, k2);
+      for (int i = 0; i < nx; ++i) y[i] = xlc2(x[i], ha31, k1[i], ha32, k2[i]);
+      rhs_int(m, y, u, k3);
+      for (int i = 0; i < nx; ++i) y[i] = xlc3(x[i], ha41, k1[i], ha42, k2[i], ha43, k3[i]);
+      rhs_int(m, y, u, k4);
+      for (int i = 0; i < nx; ++i) y[i] = xlc4(x[i], ha51, k1[i], ha52, k2[i], ha53, k3[i], ha54, k4[i]);
+      rhs_int(m, y, u, k5);
+      for (int i = 0; i < nx; ++i) y[i] = xlc5(x[i], ha61, k1[i], ha62, k2[i], ha63, k3[i], ha64, k4[i], ha65, k5[i]);
+      rhs_int(m, y, u, k6);
+      for (int i = 0; i < nx; ++i) ynew[i] = xlc5(x[i], hb1, k1[i], hb3, k3[i], hb4, k4[i], hb5, k5[i], hb6, k6[i]);
+      rhs_int(m, ynew, u, k7);
+      for (int i = 0; i < nx; ++i) err[i] = lc6(he1, k1[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i], he7, k7[i]);
+    } else { /* x + h (a_i1 k1 + ...) (dp5_row<false>) */
+      for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc1(a21, k1[i]), x[i]);
+      rhs_int(m, y, u, k2);
+      for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc2(a31, k1[i], a32, k2[i]), x[i]);
+      rhs_int(m, y, u, k3);
+      for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc3(a41, k1[i], a42, k2[i], a43, k3[i]), x[i]);
+      rhs_int(m, y, u, k4);
+      for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc4(a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]), x[i]);
+      rhs_int(m, y, u, k5);
+      for (int i = 0; i < nx; ++i) y[i] = axpy(h, lc5(a61, k1[i], a62, k2[i], a63, k3[i], a64, k4[i], a65, k5[i]), x[i]);
+      rhs_int(m, y, u, k6);
+      for (int i = 0; i < nx; ++i) ynew[i] = axpy(h, lc5(b1, k1[i], b3, k3[i], b4, k4[i], b5, k5[i], b6, k6[i]), x[i]);
+      rhs_int(m, ynew, u, k7);
+      for (int i = 0; i < nx; ++i) err[i] = h * lc6(e1, k1[i], e3, k3[i], e4, k4[i], e5, k5[i], e6, k6[i], e7, k7[i]);
+    }
     double E = rms_scaled(err, x, ynew, nx, rtol, atol);
     if (E < 1.0) {
       double f = (E == 0.0) ? 10.0 : fmin(10.0, fmax(0.2, qtrunc6(0.9 * pow(E, -0.2))));

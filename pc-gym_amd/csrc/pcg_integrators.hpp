@@ -170,8 +170,83 @@ PCG_DEV double lc7(double c1, double k1, double c2, double k2, double c3, double
                    double k5, double c6, double k6, double c7, double k7) {
   return __builtin_fma(c7, k7, lc6(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5, c6, k6));
 }
+// x + c1 k1 + ... + cN kN as a left-to-right chain of fused multiply-adds STARTING AT x, with the step size already
+// folded into the coefficients (c_j = h a_ij, once per attempt): N operations per component where
+// axpy(h, lcN(...), x) takes N + 1 -- the explicit pairs spend more operations in their stage sums than in the RHS
+// of the small models.  Twin: xlc1..xlc5 in oracle/pcg_oracle.c.
+PCG_DEV double xlc1(double x, double c1, double k1) { return __builtin_fma(c1, k1, x); }
+PCG_DEV double xlc2(double x, double c1, double k1, double c2, double k2) { return __builtin_fma(c2, k2, xlc1(x, c1, k1)); }
+PCG_DEV double xlc3(double x, double c1, double k1, double c2, double k2, double c3, double k3) {
+  return __builtin_fma(c3, k3, xlc2(x, c1, k1, c2, k2));
+}
+PCG_DEV double xlc4(double x, double c1, double k1, double c2, double k2, double c3, double k3, double c4, double k4) {
+  return __builtin_fma(c4, k4, xlc3(x, c1, k1, c2, k2, c3, k3));
+}
+PCG_DEV double xlc5(double x, double c1, double k1, double c2, double k2, double c3, double k3, double c4, double k4,
+                    double c5, double k5) {
+  return __builtin_fma(c5, k5, xlc4(x, c1, k1, c2, k2, c3, k3, c4, k4));
+}
 // x + h * s
 PCG_DEV double axpy(double h, double s, double x) { return __builtin_fma(h, s, x); }
+// The Dormand-Prince coefficients, and one row of the tableau in either form:
+//   FOLD   x + (h c1) k1 + ... + (h cN) kN   N operations per component + N products per row (the compiler forms each
+//          product once per attempt, next to the row that uses it)
+//   !FOLD  x + h (c1 k1 + ... + cN kN)       N + 1 operations per component
+// Folding saves 7 NX operations per attempt and costs 26 products that stay alive across a row: it is used for
+// 4 < NX <= 16 (measured: the two-state CSTR's fallback integrator 2 % slower with it, the 10-state cascade 4 % faster,
+// the 20-state one -- whose attempt already overflows into the accumulation registers -- 1.5 % slower).  Twin: the
+// same rule in dopri5() of oracle/pcg_oracle.c.
+constexpr bool dp5_fold(int nx_capacity) { return nx_capacity > 4 && nx_capacity <= 16; }
+namespace dp5 {
+constexpr double a21 = 1.0 / 5;
+constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
+constexpr double a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9;
+constexpr double a51 = 19372.0 / 6561, a52 = -25360.0 / 2187, a53 = 64448.0 / 6561, a54 = -212.0 / 729;
+constexpr double a61 = 9017.0 / 3168, a62 = -355.0 / 33, a63 = 46732.0 / 5247, a64 = 49.0 / 176, a65 = -5103.0 / 18656;
+constexpr double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
+constexpr double e1 = 71.0 / 57600, e3 = -71.0 / 16695, e4 = 71.0 / 1920, e5 = -17253.0 / 339200, e6 = 22.0 / 525,
+                 e7 = -1.0 / 40;
+}  // namespace dp5
+template <bool FOLD>
+PCG_DEV double dp5_row(double x, double h, double c1, double k1) {
+#pragma clang fp contract(off)
+  if constexpr (FOLD) return xlc1(x, h * c1, k1);
+  else return axpy(h, lc1(c1, k1), x);
+}
+template <bool FOLD>
+PCG_DEV double dp5_row(double x, double h, double c1, double k1, double c2, double k2) {
+#pragma clang fp contract(off)
+  if constexpr (FOLD) return xlc2(x, h * c1, k1, h * c2, k2);
+  else return axpy(h, lc2(c1, k1, c2, k2), x);
+}
+template <bool FOLD>
+PCG_DEV double dp5_row(double x, double h, double c1, double k1, double c2, double k2, double c3, double k3) {
+#pragma clang fp contract(off)
+  if constexpr (FOLD) return xlc3(x, h * c1, k1, h * c2, k2, h * c3, k3);
+  else return axpy(h, lc3(c1, k1, c2, k2, c3, k3), x);
+}
+template <bool FOLD>
+PCG_DEV double dp5_row(double x, double h, double c1, double k1, double c2, double k2, double c3, double k3, double c4,
+                       double k4) {
+#pragma clang fp contract(off)
+  if constexpr (FOLD) return xlc4(x, h * c1, k1, h * c2, k2, h * c3, k3, h * c4, k4);
+  else return axpy(h, lc4(c1, k1, c2, k2, c3, k3, c4, k4), x);
+}
+template <bool FOLD>
+PCG_DEV double dp5_row(double x, double h, double c1, double k1, double c2, double k2, double c3, double k3, double c4,
+                       double k4, double c5, double k5) {
+#pragma clang fp contract(off)
+  if constexpr (FOLD) return xlc5(x, h * c1, k1, h * c2, k2, h * c3, k3, h * c4, k4, h * c5, k5);
+  else return axpy(h, lc5(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5), x);
+}
+// the error row: h (e1 k1 + e3 k3 + ... + e7 k7)
+template <bool FOLD>
+PCG_DEV double dp5_err(double h, double k1, double k3, double k4, double k5, double k6, double k7) {
+#pragma clang fp contract(off)
+  using namespace dp5;
+  if constexpr (FOLD) return lc6(h * e1, k1, h * e3, k3, h * e4, k4, h * e5, k5, h * e6, k6, h * e7, k7);
+  else return h * lc6(e1, k1, e3, k3, e4, k4, e5, k5, e6, k6, e7, k7);
+}
 
 // mean square of v_i / (atol + rtol max(|y0_i|, |y1_i|))  (the RMS norm squared)
 template <int NX>
@@ -197,15 +272,6 @@ template <int NX, class F, class ST>
 PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double rtol, double atol,
                    int max_steps, int& nacc, int& nrej) {
 #pragma clang fp contract(off)
-  constexpr double a21 = 1.0 / 5;
-  constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
-  constexpr double a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9;
-  constexpr double a51 = 19372.0 / 6561, a52 = -25360.0 / 2187, a53 = 64448.0 / 6561, a54 = -212.0 / 729;
-  constexpr double a61 = 9017.0 / 3168, a62 = -355.0 / 33, a63 = 46732.0 / 5247, a64 = 49.0 / 176,
-                   a65 = -5103.0 / 18656;
-  constexpr double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
-  constexpr double e1 = 71.0 / 57600, e3 = -71.0 / 16695, e4 = 71.0 / 1920, e5 = -17253.0 / 339200,
-                   e6 = 22.0 / 525, e7 = -1.0 / 40;
   double y[NX], kk[NX], w[NX];
   int acc = 0, rej = 0, status = 0;
 
@@ -241,42 +307,44 @@ PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double 
       h = dt - t;
       last = true;
     }
+    using namespace dp5;
+    constexpr bool FOLD = dp5_fold(NX);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc1(a21, K.get(0, i)), x[i]);
+    for (int i = 0; i < NX; ++i) y[i] = dp5_row<FOLD>(x[i], h, a21, K.get(0, i));
     f(y, kk);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       K.set(1, i, kk[i]);
-      y[i] = axpy(h, lc2(a31, K.get(0, i), a32, kk[i]), x[i]);
+      y[i] = dp5_row<FOLD>(x[i], h, a31, K.get(0, i), a32, kk[i]);
     }
     f(y, kk);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       K.set(2, i, kk[i]);
-      y[i] = axpy(h, lc3(a41, K.get(0, i), a42, K.get(1, i), a43, kk[i]), x[i]);
+      y[i] = dp5_row<FOLD>(x[i], h, a41, K.get(0, i), a42, K.get(1, i), a43, kk[i]);
     }
     f(y, kk);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       K.set(3, i, kk[i]);
-      y[i] = axpy(h, lc4(a51, K.get(0, i), a52, K.get(1, i), a53, K.get(2, i), a54, kk[i]), x[i]);
+      y[i] = dp5_row<FOLD>(x[i], h, a51, K.get(0, i), a52, K.get(1, i), a53, K.get(2, i), a54, kk[i]);
     }
     f(y, kk);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       K.set(4, i, kk[i]);
-      y[i] = axpy(h, lc5(a61, K.get(0, i), a62, K.get(1, i), a63, K.get(2, i), a64, K.get(3, i), a65, kk[i]), x[i]);
+      y[i] = dp5_row<FOLD>(x[i], h, a61, K.get(0, i), a62, K.get(1, i), a63, K.get(2, i), a64, K.get(3, i), a65, kk[i]);
     }
     f(y, kk);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       K.set(5, i, kk[i]);
-      y[i] = axpy(h, lc5(b1, K.get(0, i), b3, K.get(2, i), b4, K.get(3, i), b5, K.get(4, i), b6, kk[i]), x[i]);
+      y[i] = dp5_row<FOLD>(x[i], h, b1, K.get(0, i), b3, K.get(2, i), b4, K.get(3, i), b5, K.get(4, i), b6, kk[i]);
     }
     f(y, kk);  // k7 at the 5th-order solution (FSAL)
 #pragma unroll
     for (int i = 0; i < NX; ++i)
-      w[i] = h * lc6(e1, K.get(0, i), e3, K.get(2, i), e4, K.get(3, i), e5, K.get(4, i), e6, K.get(5, i), e7, kk[i]);
+      w[i] = dp5_err<FOLD>(h, K.get(0, i), K.get(2, i), K.get(3, i), K.get(4, i), K.get(5, i), kk[i]);
     const double E2 = ms_scaled<NX>(w, x, y, n, rtol, atol);  // accept iff E = sqrt(E2) < 1
     // one evaluation of the controller for both outcomes, the outcome applied by selects (in a wave of 64 lanes some
     // lane rejects in almost every iteration, so an if / else with the controller in both arms executed both; the

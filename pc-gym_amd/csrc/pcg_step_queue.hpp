@@ -87,15 +87,6 @@ template <int NX, class F>
 PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double dt_edge, double h_floor, double rtol,
                            double atol, int max_steps) {
 #pragma clang fp contract(off)
-  constexpr double a21 = 1.0 / 5;
-  constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
-  constexpr double a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9;
-  constexpr double a51 = 19372.0 / 6561, a52 = -25360.0 / 2187, a53 = 64448.0 / 6561, a54 = -212.0 / 729;
-  constexpr double a61 = 9017.0 / 3168, a62 = -355.0 / 33, a63 = 46732.0 / 5247, a64 = 49.0 / 176,
-                   a65 = -5103.0 / 18656;
-  constexpr double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
-  constexpr double e1 = 71.0 / 57600, e3 = -71.0 / 16695, e4 = 71.0 / 1920, e5 = -17253.0 / 339200,
-                   e6 = 22.0 / 525, e7 = -1.0 / 40;
   if (L.acc + L.rej >= max_steps) return PCG_ST_MAX_STEPS;
   bool last = false;
   double h = L.h;
@@ -103,52 +94,69 @@ PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double d
     h = dt - L.t;
     last = true;
   }
-  // ACCUMULATOR FORM.  The stage sums are left-to-right fused multiply-add chains (lcN()): once k4 is there, the partial
-  // sums of the rows still to come (stage 6, the 5th-order solution, the error estimate) are formed and k2..k4 are dead;
-  // k5 and k6 are folded in as they arrive.  The same operations on the same operands in the same order as
-  //   y6 = x + h lc5(a61 k1 .. a65 k5),  y7 = x + h lc5(b1 k1 .. b6 k6),  w = h lc6(e1 k1 .. e7 k7)
-  // -- bit for bit -- with at most six NX-vectors alive instead of eight: the 20-state cascade's attempt carried 216
-  // 8-byte moves to and from the accumulation registers (256 + 166 registers: one wave per SIMD) for 1390 fp64
-  // operations; the 10-state one fits either way.
+  // ACCUMULATOR FORM.  The stage sums are left-to-right fused multiply-add chains (dp5_row(): for NX > 4 starting at x with the step
+  // size folded into the coefficients): once k4 is there, the partial sums of the rows still to come (stage 6, the 5th-order
+  // solution, the error estimate) are formed and k2..k4 are dead; k5 and k6 are folded in as they arrive.  The same
+  // operations on the same operands in the same order as dopri5()'s rows -- bit for bit -- with at most six NX-vectors
+  // alive instead of eight: the 20-state cascade's attempt carried 216 8-byte moves to and from the accumulation
+  // registers (256 + 166 registers: one wave per SIMD) for 1390 fp64 operations; the 10-state one fits either way.
+  using namespace dp5;
+  constexpr bool FOLD = dp5_fold(NX);
   double y[NX], kk[NX], k2[NX], k3[NX], s6[NX], s7[NX], se[NX];
   const double (&x)[NX] = L.x;
   const double (&k1)[NX] = L.k1;
 #pragma unroll
-  for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc1(a21, k1[i]), x[i]);
+  for (int i = 0; i < NX; ++i) y[i] = dp5_row<FOLD>(x[i], h, a21, k1[i]);
   f(y, k2);
 #pragma unroll
-  for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc2(a31, k1[i], a32, k2[i]), x[i]);
+  for (int i = 0; i < NX; ++i) y[i] = dp5_row<FOLD>(x[i], h, a31, k1[i], a32, k2[i]);
   f(y, k3);
 #pragma unroll
-  for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc3(a41, k1[i], a42, k2[i], a43, k3[i]), x[i]);
+  for (int i = 0; i < NX; ++i) y[i] = dp5_row<FOLD>(x[i], h, a41, k1[i], a42, k2[i], a43, k3[i]);
   f(y, kk);  // k4
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    y[i] = axpy(h, lc4(a51, k1[i], a52, k2[i], a53, k3[i], a54, kk[i]), x[i]);
-    s6[i] = lc4(a61, k1[i], a62, k2[i], a63, k3[i], a64, kk[i]);
-    s7[i] = lc3(b1, k1[i], b3, k3[i], b4, kk[i]);
-    se[i] = lc3(e1, k1[i], e3, k3[i], e4, kk[i]);
+    y[i] = dp5_row<FOLD>(x[i], h, a51, k1[i], a52, k2[i], a53, k3[i], a54, kk[i]);
+    if constexpr (FOLD) {  // rows 6 and 7 up to k4, starting at x
+      s6[i] = xlc4(x[i], h * a61, k1[i], h * a62, k2[i], h * a63, k3[i], h * a64, kk[i]);
+      s7[i] = xlc3(x[i], h * b1, k1[i], h * b3, k3[i], h * b4, kk[i]);
+      se[i] = lc3(h * e1, k1[i], h * e3, k3[i], h * e4, kk[i]);
+    } else {
+      s6[i] = lc4(a61, k1[i], a62, k2[i], a63, k3[i], a64, kk[i]);
+      s7[i] = lc3(b1, k1[i], b3, k3[i], b4, kk[i]);
+      se[i] = lc3(e1, k1[i], e3, k3[i], e4, kk[i]);
+    }
   }
   f(y, k2);  // k5
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    y[i] = axpy(h, __builtin_fma(a65, k2[i], s6[i]), x[i]);
-    s7[i] = __builtin_fma(b5, k2[i], s7[i]);
-    se[i] = __builtin_fma(e5, k2[i], se[i]);
+    if constexpr (FOLD) {
+      y[i] = __builtin_fma(h * a65, k2[i], s6[i]);
+      s7[i] = __builtin_fma(h * b5, k2[i], s7[i]);
+      se[i] = __builtin_fma(h * e5, k2[i], se[i]);
+    } else {
+      y[i] = axpy(h, __builtin_fma(a65, k2[i], s6[i]), x[i]);
+      s7[i] = __builtin_fma(b5, k2[i], s7[i]);
+      se[i] = __builtin_fma(e5, k2[i], se[i]);
+    }
   }
   f(y, k3);  // k6
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    s7[i] = __builtin_fma(b6, k3[i], s7[i]);
-    y[i] = axpy(h, s7[i], x[i]);
-    se[i] = __builtin_fma(e6, k3[i], se[i]);
+    if constexpr (FOLD) {
+      y[i] = __builtin_fma(h * b6, k3[i], s7[i]);
+      se[i] = __builtin_fma(h * e6, k3[i], se[i]);
+    } else {
+      y[i] = axpy(h, __builtin_fma(b6, k3[i], s7[i]), x[i]);
+      se[i] = __builtin_fma(e6, k3[i], se[i]);
+    }
   }
   f(y, kk);  // k7 at the 5th-order solution (FSAL)
   // error estimate and its scaled mean square in one pass (ms_scaled() without the intermediate vector)
   double E2 = 0.0;
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    const double wi = h * __builtin_fma(e7, kk[i], se[i]);
+    const double wi = FOLD ? __builtin_fma(h * e7, kk[i], se[i]) : h * __builtin_fma(e7, kk[i], se[i]);
     const double sc = atol + rtol * fmax(fabs(x[i]), fabs(y[i]));
     const double r = wi * fast_rcp(sc);  // sc > 0
     E2 += (i < n) ? r * r : 0.0;
@@ -229,8 +237,12 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
                                                           const uint32_t* sortbuf, int32_t* accs, int32_t* rejs,
                                                           int32_t* flag, int32_t* next, int T, int n, int refill, double dt, double dt_edge,
                                                           double h_floor, double rtol, double atol, int max_steps,
-                                                          double ep_c = 0.0, int ep_kmax = 0, int prio_h = 0, int rot = 0) {
+                                                          double ep_c = 0.0, int ep_kmax = 0, int prio_h = 0, int rot = 0,
+                                                          unsigned long long* qst = nullptr) {
   constexpr int NX = M::NX, NU = M::NA + M::NDM;
+#ifdef PCG_QSTATS  // measurement build (tools/queue_probe.py): per-wave counts of what the loop below did
+  unsigned long long qs_iter = 0, qs_att = 0, qs_busy = 0, qs_refill = 0, qs_refill_clk = 0, qs_pop = 0;
+#endif
   typename M::CKP& kp = *kpp;
   const int tid = threadIdx.x;
   typename QLaneSel<NX, INTEG>::type L;
@@ -257,6 +269,11 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
       }
       break;
     }
+#ifdef PCG_QSTATS
+    ++qs_iter;
+    const unsigned long long qs_any_fresh = __ballot(fresh);
+    const unsigned long long qs_c0 = qs_any_fresh ? wall_clock64() : 0ull;
+#endif
     if (fresh) {  // (re)fill: state from the batch (xg = &x[0][base of the tile]), held input from the slot, k1 = f(x)
 #pragma unroll
       for (int i = 0; i < NX; ++i) L.x[i] = xg[(size_t)i * xstride + slot];
@@ -274,12 +291,21 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
       }
       fresh = false;
     }
+#ifdef PCG_QSTATS
+    if (qs_any_fresh) {
+      ++qs_refill;
+      qs_refill_clk += wall_clock64() - qs_c0;
+    }
+#endif
     const bool busy = slot >= 0;
     const unsigned long long bm = __ballot(busy);
     const int n_idle = 64 - __popcll(bm);
     // the shared queue head is only touched when this wave could use it (>= QREFILL idle lanes, or nothing left
     // in flight) and has not seen it empty yet: the steady-state iteration does no LDS access at all
     if (!drained && (n_idle >= refill || bm == 0ull)) {
+#ifdef PCG_QSTATS
+      ++qs_pop;
+#endif
       // idle lanes pop: one LDS atomic per wave, lane r of the idle set takes sorted position head + r
       const unsigned long long im = ~bm;
       const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
@@ -298,6 +324,10 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
       if (got < n) continue;
     }
     if (bm == 0ull) break;  // nothing in flight in this wave and the queue is empty
+#ifdef PCG_QSTATS
+    ++qs_att;
+    qs_busy += __popcll(bm);
+#endif
     if (prio_h > 0) {  // a launch is as long as its heaviest env: the wave that carries one goes first on its SIMD
       const bool hi = __ballot(busy && pos < prio_h) != 0ull;
       if (hi != wave_hi) {
@@ -332,6 +362,70 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
       }
     }
   }
+#ifdef PCG_QSTATS
+  if ((tid & 63) == 0 && qst) {
+    qst[6] = qs_iter, qst[7] = qs_att, qst[8] = qs_busy, qst[9] = qs_refill, qst[10] = qs_refill_clk, qst[11] = qs_pop;
+  }
+#endif
+}
+
+// ---- the tile's sort: bitonic network over S = E * QBLOCK packed words, DESCENDING, E words per thread in registers ----
+// Element i = tid * E + r.  A compare-exchange at distance j pairs i with i ^ j:
+//   j < E          both in the same thread's registers: no data movement
+//   E <= j < 64 E  the partner sits (j / E) lanes away in the same wave: one cross-lane read, no barrier
+//   j >= 64 E      another wave: through LDS, two barriers -- 3 of the 55 steps of a 1024-slot tile
+// Rounds 2-3 ran all 55 steps through LDS with a barrier each: 16 us of the 20-state cascade's 340 us launch, 9 of the
+// 10-state one's (tools/queue_probe.py); this form takes ~3.  Keys are unique (the slot index is in the low bits).
+template <int E>
+PCG_DEV void sort_tile(uint32_t* sortbuf) {
+  constexpr int S = E * QBLOCK;
+  const int tid = threadIdx.x;
+  uint32_t v[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) v[r] = sortbuf[tid * E + r];
+#pragma unroll
+  for (int k = 2; k <= S; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64 * E) {  // cross-wave
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) sortbuf[tid * E + r] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const int i = tid * E + r;
+          const uint32_t vp = sortbuf[i ^ j];
+          const bool want_max = ((i & j) == 0) == ((i & k) == 0);
+          v[r] = want_max ? (v[r] > vp ? v[r] : vp) : (v[r] < vp ? v[r] : vp);
+        }
+      } else if (j >= E) {  // cross-lane
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const int i = tid * E + r;
+          const uint32_t vp = (uint32_t)__shfl_xor((int)v[r], j / E);
+          const bool want_max = ((i & j) == 0) == ((i & k) == 0);
+          v[r] = want_max ? (v[r] > vp ? v[r] : vp) : (v[r] < vp ? v[r] : vp);
+        }
+      } else {  // in registers
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          if ((r & j) == 0) {
+            const int i = tid * E + r;
+            const uint32_t a = v[r], b = v[r | j];
+            const bool desc = (i & k) == 0;
+            const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+            v[r] = desc ? hi : lo;
+            v[r | j] = desc ? lo : hi;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < E; ++r) sortbuf[tid * E + r] = v[r];
+  __syncthreads();
 }
 
 // LDS layout of one tile (T slots): us[NU][T] | hs[T] | sortbuf[QSORT] u32 | acc[T] rej[T] flag[T] i32 | next
@@ -382,8 +476,16 @@ __global__ __launch_bounds__(QBLOCK, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPR
   const int nsub = (int)((hi - lo + T - 1) / T);
   const int64_t sub = (hi - lo + nsub - 1) / nsub;
   const double dt = c.dt, rtol = c.rtol, atol = c.atol;
+#ifdef PCG_QSTATS  // per-wave record of 16 words in A.g: 0-5 wall-clock stamps (100 MHz), 6-11 the loop's counts (last sub-tile)
+  unsigned long long* qst = A.g ? reinterpret_cast<unsigned long long*>(A.g) + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 16 : nullptr;
+#define PCG_QS(k) if (lane == 0 && qst) qst[k] = wall_clock64()
+#else
+  unsigned long long* qst = nullptr;
+#define PCG_QS(k)
+#endif
   for (int isub = 0; isub < nsub; ++isub) {
     const int64_t base = lo + (int64_t)isub * sub;
+    PCG_QS(0);
     const int n = (int)(min(hi, base + sub) - base);  // envs in this sub-tile
     // ---------------- phase 1: load, pre-integration half, park in LDS ----------------
     const int S = n <= QSORT / 4 ? QSORT / 4 : (n <= QSORT / 2 ? QSORT / 2 : QSORT);  // sort width
@@ -433,31 +535,32 @@ __global__ __launch_bounds__(QBLOCK, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPR
       sortbuf[s] = word;
     }
     if (tid == 0) *next = QBLOCK < n ? QBLOCK : n;
+    PCG_QS(1);
     __syncthreads();
-    // ---------------- sort the slots by decreasing cost key (bitonic, S words, S/2 pairs per stage) ----------------
-    for (int k = 2; k <= S; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int q = tid; q < S / 2; q += QBLOCK) {
-          const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));  // lower index of this pair
-          const int p = i | j;
-          const uint32_t va = sortbuf[i], vb = sortbuf[p];
-          const bool desc = (i & k) == 0;  // descending overall
-          if ((va < vb) == desc) {
-            sortbuf[i] = vb;
-            sortbuf[p] = va;
-          }
-        }
-        __syncthreads();
-      }
+    // ---------------- sort the slots by decreasing cost key ----------------
+    if (S == QSORT / 4) sort_tile<QSORT / 4 / QBLOCK>(sortbuf);
+    else if (S == QSORT / 2) sort_tile<QSORT / 2 / QBLOCK>(sortbuf);
+    else sort_tile<QSORT / QBLOCK>(sortbuf);
+#ifdef PCG_QSTATS  // the results do not depend on the order: only a probe can tell whether the sort sorts
+    {
+      int bad = 0;
+      for (int i = tid; i + 1 < S; i += QBLOCK) bad += sortbuf[i] < sortbuf[i + 1] ? 1 : 0;
+      const unsigned long long bb = __ballot(bad > 0);
+      if (lane == 0 && qst) qst[12] = __popcll(bb);
+    }
+#endif
     // ---------------- phase 2: the work queue ----------------
     // idle lanes that trigger a refill: with at most two envs per lane every lane refills once and waiting for company
     // only idles it (me10: 0.678 ms at 8, 0.656 at 2); with more envs per lane the refill code -- executed by the whole
     // wave -- is worth batching (configs[4] shard: 0.916 ms at 8, 0.929 at 2; profiles/r2/queue_refill_sweep.txt)
     const int refill = refill_hi ? refill_hi : (n <= 2 * QBLOCK ? 2 : QREFILL);
+    PCG_QS(2);
     queue_integrate<M, INTEG>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, A.q_prio,
-                              (A.q_prio > 0 && blockIdx.x >= gridDim.x / 2) ? 2 * 64 : 0);
+                              (A.q_prio > 0 && blockIdx.x >= gridDim.x / 2) ? 2 * 64 : 0, qst);
     if (A.q_prio > 0) __builtin_amdgcn_s_setprio(0);
+    PCG_QS(3);
     __syncthreads();
+    PCG_QS(4);
     // ---------------- phase 3: post-integration half, coalesced stores ----------------
     for (int s = tid; s < n; s += QBLOCK) {
       const int64_t e = base + s;
@@ -502,6 +605,7 @@ __global__ __launch_bounds__(QBLOCK, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPR
       store_out<M>(A, c, e, out, A.obs + e);
       if (PER_ENV_T) A.t[e] = t + 1;
     }
+    PCG_QS(5);
     __syncthreads();  // the tile's LDS is reused by the next sub-tile
   }
 }
