@@ -946,6 +946,10 @@ static int queue_geometry(pcg_plan* p, const Kernels& k, int pe, size_t sched_by
       e = hipFuncSetAttribute((const void*)k.queue_r4w1[pe], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
       if (e != hipSuccess) return (int)e;
     }
+    if (p->integrator_id == PCG_INT_DOPRI5 && k.queue_w[pe]) {
+      e = hipFuncSetAttribute((const void*)k.queue_w[pe], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
+      if (e != hipSuccess) return (int)e;
+    }
   }
   return PCG_OK;
 }
@@ -1069,9 +1073,22 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
                 io->B > (int64_t)p->num_cus * QBLOCK;
       if (const char* ev = std::getenv("PCG_Q_W1")) w1 = w1 && std::atoi(ev) != 0;  // measurement switch
       if (w1) a.q_tile = (a.q_tile & ~0xFFFF) | p->q_tile1[pe];
-      const int q_bpc = w1 ? 1 : p->q_bpc[pe];
+      // The explicit pair at two waves per SIMD: ONE 512-thread workgroup per CU on a tile of up to 2048 slots instead of two
+      // 256-thread workgroups on 1024 each.  The lanes and the envs per lane are the same, the pool is twice as deep, and the
+      // two waves of a SIMD drain the same queue: with two workgroups a wave whose SIMD-mate's tile ran dry early finished
+      // alone (per-wave stamps, tools/queue_probe.py: the 10-state cascade's waves ended between 424 and 737 us of a 737 us
+      // launch).  Taken when every workgroup still gets >= 1.75 envs per lane.
+      bool wide = !r4q && k.queue_w[pe] && p->q_bpc[pe] == 2 && io->B >= (int64_t)p->num_cus * (7 * 2 * QBLOCK / 4);
+      if (const char* ev = std::getenv("PCG_Q_WIDE")) wide = wide && std::atoi(ev) != 0;  // measurement switch
+      const int qb = wide ? 2 * QBLOCK : QBLOCK;
+      if (wide) {
+        int Tw = QSORT;
+        while (Tw >= qb && k.queue_lds(Tw) + sb > (size_t)(160 * 1024 - 2048)) Tw -= 64;
+        a.q_tile = (a.q_tile & ~0xFFFF) | Tw;
+      }
+      const int q_bpc = (w1 || wide) ? 1 : p->q_bpc[pe];
       int64_t nwg = (int64_t)p->num_cus * q_bpc;
-      const int64_t cap = (io->B + QBLOCK - 1) / QBLOCK;  // no workgroup with less than one env per lane
+      const int64_t cap = (io->B + qb - 1) / qb;  // no workgroup with less than one env per lane
       if (nwg > cap) nwg = cap;
       // The queue only pays when its tiles are well filled: with fewer than ~1.75 envs per lane in a sub-tile the
       // re-balancing gain (measured 1.11x at 2.0 on BASELINE configs[2]) no longer covers the bookkeeping (0.99x at
@@ -1080,12 +1097,12 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       int Tq = a.q_tile & 0xFFFF;
       const int64_t nsub = (per + Tq - 1) / Tq;
       const int64_t sub = (per + nsub - 1) / nsub;
-      const bool filled = sub >= (7 * QBLOCK) / 4 || q_forced;
+      const bool filled = sub >= (7 * qb) / 4 || q_forced;
       if (filled) {
       // LDS for the sub-tile this launch actually walks, not for the largest one the plan could (the kernel derives the
       // same number of sub-tiles from the smaller stride); the tile's state goes to LDS too when that still leaves room
       // for the other workgroups of the CU
-      const int Tfit = (int)((sub + 63) / 64 * 64) < QBLOCK ? QBLOCK : (int)((sub + 63) / 64 * 64);
+      const int Tfit = (int)((sub + 63) / 64 * 64) < qb ? qb : (int)((sub + 63) / 64 * 64);
       if (Tfit < Tq && !std::getenv("PCG_Q_TILE")) {
         Tq = Tfit;
         a.q_tile = (a.q_tile & ~0xFFFF) | Tq;
@@ -1095,7 +1112,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
         a.q_tile |= 0x20000;
         qsh = k.queue_lds_x(Tq) + sb;
       }
-      hipLaunchKernelGGL(w1 ? k.queue_r4w1[pe] : qtab[pe], dim3((unsigned)nwg), dim3(QBLOCK), qsh, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(w1 ? k.queue_r4w1[pe] : wide ? k.queue_w[pe] : qtab[pe], dim3((unsigned)nwg), dim3(qb), qsh, (hipStream_t)stream, a);
       return (int)hipGetLastError();
       }
     }

@@ -1740,6 +1740,7 @@ struct Kernels {
   StepFn stream[PCG_INT_COUNT][2];      // persistent streaming kernel [integrator][EPL-1] (entries may be null)
   StepFn step_unc[PCG_INT_COUNT][2]; // per-env parameter uncertainty [integrator][per_env_t] (null for affine)
   StepFn queue[2];                   // DOPRI5 with the in-workgroup work queue [per_env_t] (null for affine)
+  StepFn queue_w[2];                 // ... 512-thread workgroups: both waves of a SIMD on ONE tile (models with a cost key, <= 256 registers)
   StepFn queue_r4[2];                // Rodas4 through the same work queue [per_env_t] (models with structured W only)
   StepFn queue_r4w1[2];              // ... compiled for ONE workgroup per CU (no register spills in the loop)
   bool ros_structured;               // Rodas4 runs in registers (launch shape of the explicit adaptive pair)
@@ -1827,6 +1828,10 @@ Kernels make_kernels() {
     // integration.  The queue is the default only where a model declares a cost key, i.e. where the step count is
     // large and predictable from the input (the extraction models: 1.12-1.23x); PCG_Q_FORCE routes any model to it.
     k.queue_default = has_cost_key<M>::value;
+    if constexpr (has_cost_key<M>::value && wpe(M::NX, PCG_INT_DOPRI5, false) >= 2) {
+      k.queue_w[0] = step_kernel_queue<M, false, true, PCG_INT_DOPRI5, 0, 2 * QBLOCK>;
+      k.queue_w[1] = step_kernel_queue<M, true, true, PCG_INT_DOPRI5, 0, 2 * QBLOCK>;
+    }
     k.step_unc[PCG_INT_RK4][0] = step_kernel<M, PCG_INT_RK4, false, false, true, true>;
     k.step_unc[PCG_INT_RK4][1] = step_kernel<M, PCG_INT_RK4, true, false, true, true>;
     k.step_unc[PCG_INT_DOPRI5][0] = step_kernel<M, PCG_INT_DOPRI5, false, false, true, true>;

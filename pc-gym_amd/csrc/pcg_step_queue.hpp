@@ -232,7 +232,7 @@ PCG_DEV int rodas4_attempt(const K& kp, const typename M::Hold& hold, const F& f
 
 // ---- phase 2: the work queue of one tile.  (Tried as a real, non-inlined function so that the loop would own the
 // whole register file: the call ABI's save / restore made it worse -- 772 B of scratch against 140.)
-template <class M, int INTEG = PCG_INT_DOPRI5>
+template <class M, int INTEG = PCG_INT_DOPRI5, int QB = QBLOCK>
 PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, double* us, const double* hs,
                                                           const uint32_t* sortbuf, int32_t* accs, int32_t* rejs,
                                                           int32_t* flag, int32_t* next, int T, int n, int refill, double dt, double dt_edge,
@@ -248,15 +248,15 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
   typename QLaneSel<NX, INTEG>::type L;
   // sorted position of the lane's current env (the sort is by decreasing cost: small = heavy).  `rot` shifts which wave
   // starts with the heaviest 64: two workgroups that share a CU put them on different SIMDs (see q_prio)
-  int pos = (tid + rot) & (QBLOCK - 1);
+  int pos = (tid + rot) & (QB - 1);
   int slot = pos < n ? (int)(sortbuf[pos] & (QSORT - 1)) : -1;  // QSORT - 1 == the QSLOT_BITS mask
   bool fresh = slot >= 0;
   bool wave_hi = false;
-  bool drained = n <= QBLOCK;  // wave-uniform: the queue has nothing (left) for this wave
+  bool drained = n <= QB;  // wave-uniform: the queue has nothing (left) for this wave
   // every spin is bounded: a lane integrates at most two envs' worth of its tile share plus the refill rounds; the
   // bound is never reached by a correct run (max_steps bounds each env) and turns a logic error into a flagged
   // PCG_ST_MAX_STEPS result instead of a hung GPU
-  const long long cap64 = ((long long)max_steps + 4) * ((T + QBLOCK - 1) / QBLOCK + 1) + 4 * T;
+  const long long cap64 = ((long long)max_steps + 4) * ((T + QB - 1) / QB + 1) + 4 * T;
   const int iter_cap = cap64 > 0x7fffff00LL ? 0x7fffff00 : (int)cap64;
   for (int iter = 0;; ++iter) {
     if (iter > iter_cap) {
@@ -369,16 +369,16 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
 #endif
 }
 
-// ---- the tile's sort: bitonic network over S = E * QBLOCK packed words, DESCENDING, E words per thread in registers ----
+// ---- the tile's sort: bitonic network over S = E * QB packed words (QB threads), DESCENDING, E words per thread in registers ----
 // Element i = tid * E + r.  A compare-exchange at distance j pairs i with i ^ j:
 //   j < E          both in the same thread's registers: no data movement
 //   E <= j < 64 E  the partner sits (j / E) lanes away in the same wave: one cross-lane read, no barrier
 //   j >= 64 E      another wave: through LDS, two barriers -- 3 of the 55 steps of a 1024-slot tile
 // Rounds 2-3 ran all 55 steps through LDS with a barrier each: 16 us of the 20-state cascade's 340 us launch, 9 of the
 // 10-state one's (tools/queue_probe.py); this form takes ~3.  Keys are unique (the slot index is in the low bits).
-template <int E>
+template <int E, int QB>
 PCG_DEV void sort_tile(uint32_t* sortbuf) {
-  constexpr int S = E * QBLOCK;
+  constexpr int S = E * QB;
   const int tid = threadIdx.x;
   uint32_t v[E];
 #pragma unroll
@@ -444,8 +444,11 @@ struct QLayout {
 // WAVES: waves per SIMD = workgroups per CU the register allocator is asked to leave room for (0 = the model's default,
 // wpe()).  The Rosenbrock loop wants ~316 registers: at two waves per SIMD it spills 34 scratch accesses per attempt, at
 // one (256 VGPRs + AGPRs) none -- the instantiation for launches that fit ONE tile per CU (me10 at B = 2^18: 0.361 -> 0.337 ms)
-template <class M, bool PER_ENV_T, bool EXTRAS, int INTEG = PCG_INT_DOPRI5, int WAVES = 0>
-__global__ __launch_bounds__(QBLOCK, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, false)) void step_kernel_queue(const StepArgs A) {
+// QB: threads per workgroup.  256 = one wave per SIMD and workgroup, as many workgroups per CU as the registers allow;
+// 512 = the two waves of every SIMD belong to ONE workgroup and share ONE tile of twice the size (see pcg_abi.hip:
+// queue launch geometry): a pool twice as deep for the same lanes, and no wave left alone behind its SIMD-mate's tile.
+template <class M, bool PER_ENV_T, bool EXTRAS, int INTEG = PCG_INT_DOPRI5, int WAVES = 0, int QB = QBLOCK>
+__global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, false)) void step_kernel_queue(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   static_assert(!M::DYNAMIC, "the work-queue kernel is built for the fixed-size models");
   CDevConst& c = *A.C;
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(QBLOCK, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPR
   const int64_t sub = (hi - lo + nsub - 1) / nsub;
   const double dt = c.dt, rtol = c.rtol, atol = c.atol;
 #ifdef PCG_QSTATS  // per-wave record of 16 words in A.g: 0-5 wall-clock stamps (100 MHz), 6-11 the loop's counts (last sub-tile)
-  unsigned long long* qst = A.g ? reinterpret_cast<unsigned long long*>(A.g) + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 16 : nullptr;
+  unsigned long long* qst = A.g ? reinterpret_cast<unsigned long long*>(A.g) + ((size_t)blockIdx.x * (QB / 64) + (tid >> 6)) * 16 : nullptr;
 #define PCG_QS(k) if (lane == 0 && qst) qst[k] = wall_clock64()
 #else
   unsigned long long* qst = nullptr;
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(QBLOCK, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPR
     const int n = (int)(min(hi, base + sub) - base);  // envs in this sub-tile
     // ---------------- phase 1: load, pre-integration half, park in LDS ----------------
     const int S = n <= QSORT / 4 ? QSORT / 4 : (n <= QSORT / 2 ? QSORT / 2 : QSORT);  // sort width
-    for (int s = tid; s < S; s += QBLOCK) {
+    for (int s = tid; s < S; s += QB) {
       uint32_t word = (uint32_t)s;  // padding: sorts behind every real slot
       if (s < n) {
         const int64_t e = base + s;
@@ -534,17 +537,17 @@ __global__ __launch_bounds__(QBLOCK, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPR
       }
       sortbuf[s] = word;
     }
-    if (tid == 0) *next = QBLOCK < n ? QBLOCK : n;
+    if (tid == 0) *next = QB < n ? QB : n;
     PCG_QS(1);
     __syncthreads();
     // ---------------- sort the slots by decreasing cost key ----------------
-    if (S == QSORT / 4) sort_tile<QSORT / 4 / QBLOCK>(sortbuf);
-    else if (S == QSORT / 2) sort_tile<QSORT / 2 / QBLOCK>(sortbuf);
-    else sort_tile<QSORT / QBLOCK>(sortbuf);
+    if (S == QSORT / 4) sort_tile<QSORT / 4 / QB, QB>(sortbuf);
+    else if (S == QSORT / 2) sort_tile<QSORT / 2 / QB, QB>(sortbuf);
+    else sort_tile<QSORT / QB, QB>(sortbuf);
 #ifdef PCG_QSTATS  // the results do not depend on the order: only a probe can tell whether the sort sorts
     {
       int bad = 0;
-      for (int i = tid; i + 1 < S; i += QBLOCK) bad += sortbuf[i] < sortbuf[i + 1] ? 1 : 0;
+      for (int i = tid; i + 1 < S; i += QB) bad += sortbuf[i] < sortbuf[i + 1] ? 1 : 0;
       const unsigned long long bb = __ballot(bad > 0);
       if (lane == 0 && qst) qst[12] = __popcll(bb);
     }
@@ -553,16 +556,16 @@ __global__ __launch_bounds__(QBLOCK, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPR
     // idle lanes that trigger a refill: with at most two envs per lane every lane refills once and waiting for company
     // only idles it (me10: 0.678 ms at 8, 0.656 at 2); with more envs per lane the refill code -- executed by the whole
     // wave -- is worth batching (configs[4] shard: 0.916 ms at 8, 0.929 at 2; profiles/r2/queue_refill_sweep.txt)
-    const int refill = refill_hi ? refill_hi : (n <= 2 * QBLOCK ? 2 : QREFILL);
+    const int refill = refill_hi ? refill_hi : (n <= 2 * QB ? 2 : QREFILL);
     PCG_QS(2);
-    queue_integrate<M, INTEG>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, A.q_prio,
+    queue_integrate<M, INTEG, QB>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, A.q_prio,
                               (A.q_prio > 0 && blockIdx.x >= gridDim.x / 2) ? 2 * 64 : 0, qst);
     if (A.q_prio > 0) __builtin_amdgcn_s_setprio(0);
     PCG_QS(3);
     __syncthreads();
     PCG_QS(4);
     // ---------------- phase 3: post-integration half, coalesced stores ----------------
-    for (int s = tid; s < n; s += QBLOCK) {
+    for (int s = tid; s < n; s += QB) {
       const int64_t e = base + s;
       const int t = PER_ENV_T ? A.t[e] : A.t_scalar;
       double x[NX];
