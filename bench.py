@@ -421,7 +421,10 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist, ranks_seen = None, 1
-    if world > 1:
+    # PCG_BENCH_FORCE_DIST=1 (TEST switch, under torch.distributed.run with one rank): take the communicator path even with
+    # one rank, so that the RCCL branch -- device-bound process group, device tensors in the reductions, barrier +
+    # synchronize brackets -- runs on a one-GPU box (RCCL refuses two ranks on one device)
+    if world > 1 or (os.environ.get("PCG_BENCH_FORCE_DIST") and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -656,7 +659,7 @@ def main():
             "dt_model_units": spec.dt,
             "x0_box": x0_box(spec),
             "parallelism": f"env-shard x{world} (no collective on the hot path)",
-            "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none (single process)",
+            "collective_backend": ("rccl" if backend == "nccl" else backend) if dist is not None else "none (single process)",
             "ranks_seen": ranks_seen,
             "clock_preheat_ms": round(preheat_ms, 1),
             "status_byte": bool(args.status),

@@ -1078,7 +1078,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       // two waves of a SIMD drain the same queue: with two workgroups a wave whose SIMD-mate's tile ran dry early finished
       // alone (per-wave stamps, tools/queue_probe.py: the 10-state cascade's waves ended between 424 and 737 us of a 737 us
       // launch).  Taken when every workgroup still gets >= 1.75 envs per lane.
-      bool wide = !r4q && k.queue_w[pe] && p->q_bpc[pe] == 2 && io->B >= (int64_t)p->num_cus * (7 * 2 * QBLOCK / 4);
+      bool wide = !r4q && k.queue_w[pe] && io->B >= (int64_t)p->num_cus * (7 * 2 * QBLOCK / 4);
       if (const char* ev = std::getenv("PCG_Q_WIDE")) wide = wide && std::atoi(ev) != 0;  // measurement switch
       const int qb = wide ? 2 * QBLOCK : QBLOCK;
       if (wide) {

@@ -1828,6 +1828,9 @@ Kernels make_kernels() {
     // integration.  The queue is the default only where a model declares a cost key, i.e. where the step count is
     // large and predictable from the input (the extraction models: 1.12-1.23x); PCG_Q_FORCE routes any model to it.
     k.queue_default = has_cost_key<M>::value;
+    // (only where the 256-thread build already runs two waves per SIMD.  The 20-state cascade was tried: at 512 threads its
+    // loop is allocated 256 registers with ~10 scratch accesses per attempt, but a second wave buys 9 % of issue rate
+    // (3.85 against 4.24 us of SIMD time per attempt) and two envs per lane instead of four cost more: 0.345 against 0.327 ms)
     if constexpr (has_cost_key<M>::value && wpe(M::NX, PCG_INT_DOPRI5, false) >= 2) {
       k.queue_w[0] = step_kernel_queue<M, false, true, PCG_INT_DOPRI5, 0, 2 * QBLOCK>;
       k.queue_w[1] = step_kernel_queue<M, true, true, PCG_INT_DOPRI5, 0, 2 * QBLOCK>;

@@ -76,6 +76,24 @@ def test_two_rank_launch_path():
     assert d["config"]["collective_backend"] == "gloo" and d["config"]["ranks_seen"] == 2
 
 
+def test_rccl_branch_with_one_rank():
+    """RCCL refuses two ranks on one device, so the multi-rank tests here share this box's GPU over gloo -- and the lines of
+    bench.py that only run under backend "nccl" (device-bound process group, the reductions' tensors on the device, the
+    barrier inside the timed brackets) would first execute on the driver's 8-GPU node.  They run here with ONE rank under
+    torch.distributed.run and the communicator path forced."""
+    env = dict(os.environ, PCG_BENCH_FORCE_DIST="1")
+    env.pop("PCG_BENCH_BACKEND", None)
+    for extra in ([], ["--workload", "mixed", "--batch", "30000"]):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                            "--gpus", "1", "--steps", "20", "--warmup", "5", "--preheat-ms", "20", "--no-cpu-baseline"] + extra,
+                           capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = _json_line(r.stdout)
+        assert d["n_gpus"] == 1 and d["config"]["ranks_seen"] == 1 and d["config"]["sane"]
+        assert d["config"]["collective_backend"] == "rccl"
+
+
 def test_two_rank_mixed_workload():
     env = dict(os.environ, PCG_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
