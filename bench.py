@@ -309,7 +309,7 @@ def committed_pmc(workload, build_id):
     """per-launch counters of this workload's dominant kernel from the committed rocprofv3 PMC passes (profiles/r4/pmc.json,
     made by tools/prof_all.sh + tools/pmc_json.py on the GPU box; FETCH_SIZE x 2 per MI355X_MICROARCH.md's gfx950 note).
     NOT measured in this run: hardware counters cannot be read from inside the process.  An entry is quoted only when it was
-    taken on THIS build of the library (pcg_build_id(): a digest of the kernel headers): -> (entry or None, reason)."""
+    taken on THIS build of the library (pcg_build_id(): a digest of the kernel headers and the .hip units): -> (entry or None, reason)."""
     global _PMC
     if _PMC is None:
         _PMC = {}

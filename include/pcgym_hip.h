@@ -356,7 +356,7 @@ typedef struct pcg_plan pcg_plan; /* opaque */
 
 /* library / ABI version (PCG_ABI_VERSION). */
 PCG_API int pcg_version(void);
-/* Build id: a digest of the kernel headers (the .hpp files of csrc) and of this header at build time (the Makefile's PCG_SRC_HASH;
+/* Build id: a digest of the library's sources (csrc: the kernel headers and the .hip units) and of this header at build time (the Makefile's PCG_SRC_HASH;
    "unknown-build" for a build made without it).  Measurements that cannot be taken in-process -- the hardware-counter
    passes under profiles/ -- record it, and bench.py reports their traffic figures only for the build they were taken on. */
 PCG_API const char* pcg_build_id(void);

@@ -123,7 +123,7 @@ extern "C" {
 
 int pcg_version(void) { return PCG_ABI_VERSION; }
 #ifndef PCG_SRC_HASH
-#define PCG_SRC_HASH "unknown-build"  // the Makefile passes a digest of csrc/*.hpp + include/pcgym_hip.h
+#define PCG_SRC_HASH "unknown-build"  // the Makefile passes a digest of csrc/*.hpp, csrc/*.hip and include/pcgym_hip.h
 #endif
 const char* pcg_build_id(void) { return PCG_SRC_HASH; }
 
@@ -478,7 +478,7 @@ static uint64_t fnv1a_seed(const std::string& s, uint64_t seed) {
   return h;
 }
 #ifndef PCG_SRC_HASH
-#define PCG_SRC_HASH "unknown-build"  // the Makefile passes a digest of csrc/*.hpp + include/pcgym_hip.h
+#define PCG_SRC_HASH "unknown-build"  // the Makefile passes a digest of csrc/*.hpp, csrc/*.hip and include/pcgym_hip.h
 #endif
 
 // digest of the headers a run-time compilation will see: every *.hpp of the include directory and the ABI header
@@ -1106,6 +1106,21 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       if (Tfit < Tq && !std::getenv("PCG_Q_TILE")) {
         Tq = Tfit;
         a.q_tile = (a.q_tile & ~0xFFFF) | Tq;
+      }
+      // A workgroup that has its CU to itself and whose tile's state does not fit in LDS walks two half tiles that do, as
+      // long as a lane still gets two envs (the 20-state cascade at B = 2^18: 1024 envs per CU, 2 x 512 with 80 KB of state
+      // each).  Scattered 8-byte accesses of a state that stays in the batch reach HBM as 32-byte sectors -- a tile's rows
+      // do not survive in L2 between a lane's pick-up and its neighbours' -- 592 MB per launch against 114 MB of algorithm;
+      // from LDS the launch moves 137 MB (1.21 x) and takes 1.7 % longer (two envs per lane instead of four for the
+      // longest-first order; profiles/r4/queue_probe/).  PCG_Q_NOXLDS=1 keeps the full tile.
+      if (q_bpc == 1 && !wide && k.queue_lds_x(Tq) + sb > (size_t)(160 * 1024 - 2048) && !std::getenv("PCG_Q_NOXLDS") &&
+          !std::getenv("PCG_Q_TILE")) {
+        const int64_t sub2 = (per + 2 * nsub - 1) / (2 * nsub);
+        const int T2 = (int)((sub2 + 63) / 64 * 64) < qb ? qb : (int)((sub2 + 63) / 64 * 64);
+        if (sub2 >= 2 * qb && k.queue_lds_x(T2) + sb <= (size_t)(160 * 1024 - 2048)) {
+          Tq = T2;
+          a.q_tile = (a.q_tile & ~0xFFFF) | Tq;
+        }
       }
       size_t qsh = k.queue_lds(Tq) + sb;
       if (k.queue_lds_x(Tq) + sb <= (size_t)(160 * 1024 - 2048) / q_bpc && !std::getenv("PCG_Q_NOXLDS")) {

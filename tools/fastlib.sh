@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../pc-gym_amd/csrc"
 OUT=$1; shift
 UNIT=${UNIT:-pcg_inst_a}
-H=$(cat *.hpp ../../include/pcgym_hip.h | sha256sum | cut -c1-32)
+H=$(cat $(ls *.hpp | sort) ../../include/pcgym_hip.h pcg_abi.hip $(ls pcg_inst_*.hip | sort) | sha256sum | cut -c1-32)
 TMP=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DPCG_SRC_HASH="\"$H\"" "$@" -c -o $TMP/a.o $UNIT.hip 2>/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -shared -o $OUT $TMP/a.o $(ls build/*.o | grep -v $UNIT.o) -lhiprtc

@@ -3,7 +3,7 @@
 per workload the dominant step kernel's mean counters per launch, HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE: the gfx950
 FETCH_SIZE correction of /opt/skills/guides/MI355X_MICROARCH.md "HBM"), and the VALU issue fraction
 4 SQ_INSTS_VALU / (1024 SIMDs x SQ_BUSY_CYCLES / 32).  Every entry carries the build id of the library the passes ran on
-(pcg_build_id(): digest of the kernel headers), and bench.py quotes an entry only for that build.
+(pcg_build_id(): digest of the kernel headers and the .hip units), and bench.py quotes an entry only for that build.
 usage: pmc_json.py <gpurun_out> <workload ...>      PMC_ROUND=r4 names the profiles/ directory in the source note"""
 import csv
 import glob
