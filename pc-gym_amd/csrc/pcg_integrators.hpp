@@ -99,6 +99,7 @@ PCG_DEV int rk4_guarded(const F& f, const K& kp, const typename M::Hold& hold, d
 // ---- stage storage policies -------------------------------------------------
 template <int NX>
 struct RegStages {
+  static constexpr bool REGS = true;
   double k[6][NX];
   PCG_DEV double get(int s, int i) const { return k[s][i]; }
   PCG_DEV void set(int s, int i, double v) { k[s][i] = v; }
@@ -108,6 +109,7 @@ struct RegStages {
 // ds_read_b64 / ds_write_b64 of a wave touches 512 contiguous bytes (conflict-free).
 template <int NX, int THREADS>
 struct LdsStages {
+  static constexpr bool REGS = false;
   double* base;  // &lds[threadIdx.x]
   PCG_DEV double get(int s, int i) const { return base[(s * NX + i) * THREADS]; }
   PCG_DEV void set(int s, int i, double v) { base[(s * NX + i) * THREADS] = v; }
@@ -309,6 +311,63 @@ PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double 
     }
     using namespace dp5;
     constexpr bool FOLD = dp5_fold(NX);
+    if constexpr (ST::REGS && NX > 10) {
+      // Stages in registers, many states: the rows in ACCUMULATOR FORM (dopri5_attempt in pcg_step_queue.hpp has the
+      // reasoning): once k4 is there the partial sums of rows 6, 7 and the error row are formed and k2..k4 are dead; the
+      // same operations on the same operands in the same order as the rows below, bit for bit, with six NX-vectors alive
+      // instead of eight -- the 20- and 24-state models otherwise shuttle their stages through the accumulation registers.
+      double k2[NX], k3[NX], s6[NX], s7[NX], se[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) y[i] = dp5_row<FOLD>(x[i], h, a21, K.get(0, i));
+      f(y, k2);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) y[i] = dp5_row<FOLD>(x[i], h, a31, K.get(0, i), a32, k2[i]);
+      f(y, k3);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) y[i] = dp5_row<FOLD>(x[i], h, a41, K.get(0, i), a42, k2[i], a43, k3[i]);
+      f(y, kk);  // k4
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const double k1 = K.get(0, i);
+        y[i] = dp5_row<FOLD>(x[i], h, a51, k1, a52, k2[i], a53, k3[i], a54, kk[i]);
+        if constexpr (FOLD) {
+          s6[i] = xlc4(x[i], h * a61, k1, h * a62, k2[i], h * a63, k3[i], h * a64, kk[i]);
+          s7[i] = xlc3(x[i], h * b1, k1, h * b3, k3[i], h * b4, kk[i]);
+          se[i] = lc3(h * e1, k1, h * e3, k3[i], h * e4, kk[i]);
+        } else {
+          s6[i] = lc4(a61, k1, a62, k2[i], a63, k3[i], a64, kk[i]);
+          s7[i] = lc3(b1, k1, b3, k3[i], b4, kk[i]);
+          se[i] = lc3(e1, k1, e3, k3[i], e4, kk[i]);
+        }
+      }
+      f(y, k2);  // k5
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        if constexpr (FOLD) {
+          y[i] = __builtin_fma(h * a65, k2[i], s6[i]);
+          s7[i] = __builtin_fma(h * b5, k2[i], s7[i]);
+          se[i] = __builtin_fma(h * e5, k2[i], se[i]);
+        } else {
+          y[i] = axpy(h, __builtin_fma(a65, k2[i], s6[i]), x[i]);
+          s7[i] = __builtin_fma(b5, k2[i], s7[i]);
+          se[i] = __builtin_fma(e5, k2[i], se[i]);
+        }
+      }
+      f(y, k3);  // k6
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        if constexpr (FOLD) {
+          y[i] = __builtin_fma(h * b6, k3[i], s7[i]);
+          se[i] = __builtin_fma(h * e6, k3[i], se[i]);
+        } else {
+          y[i] = axpy(h, __builtin_fma(b6, k3[i], s7[i]), x[i]);
+          se[i] = __builtin_fma(e6, k3[i], se[i]);
+        }
+      }
+      f(y, kk);  // k7 at the 5th-order solution (FSAL)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) w[i] = FOLD ? __builtin_fma(h * e7, kk[i], se[i]) : h * __builtin_fma(e7, kk[i], se[i]);
+    } else {
 #pragma unroll
     for (int i = 0; i < NX; ++i) y[i] = dp5_row<FOLD>(x[i], h, a21, K.get(0, i));
     f(y, kk);
@@ -345,6 +404,7 @@ PCG_DEV int dopri5(const F& f, ST& K, double (&x)[NX], int n, double dt, double 
 #pragma unroll
     for (int i = 0; i < NX; ++i)
       w[i] = dp5_err<FOLD>(h, K.get(0, i), K.get(2, i), K.get(3, i), K.get(4, i), K.get(5, i), kk[i]);
+    }
     const double E2 = ms_scaled<NX>(w, x, y, n, rtol, atol);  // accept iff E = sqrt(E2) < 1
     // one evaluation of the controller for both outcomes, the outcome applied by selects (in a wave of 64 lanes some
     // lane rejects in almost every iteration, so an if / else with the controller in both arms executed both; the
