@@ -473,6 +473,12 @@ PCG_API int pcg_graph_destroy(pcg_graph* graph);
 /* Compiler output of the most recent failed run-time compilation in this process (static storage, "" if none). */
 PCG_API const char* pcg_last_jit_log(void);
 
+/* Test hook: the work-queue kernel's tile sort on its own.  words: ntiles x S 32-bit words on the device (distinct
+ * within a tile), sorted in place, DESCENDING, one workgroup of `threads` threads per tile.  (S, threads) as the step kernels
+ * use them: S in {512, 1024, 2048}, threads in {256, 512}; anything else PCG_E_UNSUPPORTED.  The step results do not depend
+ * on the order of a tile -- this is the only way to see that the sort sorts. */
+PCG_API int pcg_test_sort_tile(uint32_t* words, int32_t S, int32_t threads, int64_t ntiles, void* stream);
+
 /* Raw Philox4x32-10 block for KAT tests: ctr[4], key[2] -> out[4]. (host) */
 PCG_API void pcg_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

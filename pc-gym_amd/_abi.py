@@ -182,6 +182,7 @@ EXPORTS = [
     "pcg_graph_destroy",
     "pcg_last_jit_log",
     "pcg_philox4x32_10",
+    "pcg_test_sort_tile",
 ]
 
 
@@ -237,6 +238,8 @@ def declare(lib):
     lib.pcg_graph_destroy.argtypes = [vp]
     lib.pcg_last_jit_log.restype = C.c_char_p
     lib.pcg_last_jit_log.argtypes = []
+    lib.pcg_test_sort_tile.restype = C.c_int
+    lib.pcg_test_sort_tile.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, vp]
     lib.pcg_philox4x32_10.restype = None
     lib.pcg_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]

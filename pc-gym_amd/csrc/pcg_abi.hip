@@ -119,6 +119,17 @@ static constexpr uint32_t PLAN_MAGIC = 0x50434731u;  // 'PCG1'
     if (_e != hipSuccess) return (int)_e;      \
   } while (0)
 
+// Test hook: the work-queue kernel's tile sort on its own (the step results do not depend on the order, so no parity test
+// can see a sort that does not sort -- only a slower launch would).
+template <int E, int QB>
+__global__ __launch_bounds__(QB) void sort_tile_test_kernel(uint32_t* w) {
+  __shared__ uint32_t buf[E * QB];
+  uint32_t* g = w + (size_t)blockIdx.x * E * QB;
+  for (int i = threadIdx.x; i < E * QB; i += QB) buf[i] = g[i];
+  __syncthreads();
+  sort_tile<E, QB>(buf);
+  for (int i = threadIdx.x; i < E * QB; i += QB) g[i] = buf[i];
+}
 extern "C" {
 
 int pcg_version(void) { return PCG_ABI_VERSION; }
@@ -162,6 +173,20 @@ int pcg_model_default_params(int model_id, double* out, int32_t n_out) {
   if (n_out < k.nraw) return PCG_E_DIM;
   for (int i = 0; i < k.nraw; ++i) out[i] = DEFAULTS[model_id][i];
   return PCG_OK;
+}
+
+int pcg_test_sort_tile(uint32_t* words, int32_t S, int32_t threads, int64_t ntiles, void* stream) {
+  if (!words || ntiles <= 0 || ntiles > 0x7fffffff) return PCG_E_VALUE;
+  const dim3 g((unsigned)ntiles);
+  hipStream_t st = (hipStream_t)stream;
+  if (threads == QBLOCK && S == QSORT / 4) hipLaunchKernelGGL((sort_tile_test_kernel<QSORT / 4 / QBLOCK, QBLOCK>), g, dim3(QBLOCK), 0, st, words);
+  else if (threads == QBLOCK && S == QSORT / 2) hipLaunchKernelGGL((sort_tile_test_kernel<QSORT / 2 / QBLOCK, QBLOCK>), g, dim3(QBLOCK), 0, st, words);
+  else if (threads == QBLOCK && S == QSORT) hipLaunchKernelGGL((sort_tile_test_kernel<QSORT / QBLOCK, QBLOCK>), g, dim3(QBLOCK), 0, st, words);
+  else if (threads == 2 * QBLOCK && S == QSORT / 4) hipLaunchKernelGGL((sort_tile_test_kernel<QSORT / 8 / QBLOCK, 2 * QBLOCK>), g, dim3(2 * QBLOCK), 0, st, words);
+  else if (threads == 2 * QBLOCK && S == QSORT / 2) hipLaunchKernelGGL((sort_tile_test_kernel<QSORT / 4 / QBLOCK, 2 * QBLOCK>), g, dim3(2 * QBLOCK), 0, st, words);
+  else if (threads == 2 * QBLOCK && S == QSORT) hipLaunchKernelGGL((sort_tile_test_kernel<QSORT / 2 / QBLOCK, 2 * QBLOCK>), g, dim3(2 * QBLOCK), 0, st, words);
+  else return PCG_E_UNSUPPORTED;
+  return (int)hipGetLastError();
 }
 
 void pcg_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {

@@ -839,3 +839,67 @@ def test_fused_rollout_with_per_env_parameters_matches_stepping(integrator):
     assert torch.allclose(out["r"][0, 1:], rew_seq.reshape(N - 1, B), rtol=1e-11, atol=1e-13)  # (the same kernel twice)
     for e in (e1, e2, e3):
         e.close()
+
+
+@pytest.mark.parametrize("name,B,kw", [("me_canonical", 1 << 18, {}), ("me_canonical", 300001, dict(per_env_t=True, auto_reset=True)),
+                                       ("me_reactive", 1 << 18, {}), ("me_reactive", 290011, {})])
+def test_work_queue_launch_shapes_of_a_full_batch(name, B, kw):
+    """The launch shapes the host only picks for well-filled CUs -- 512-thread workgroups on one tile of up to 2048 slots
+    (10-state cascade), two LDS-resident half tiles per workgroup (20-state cascade) -- against the classic kernel on the
+    same envs: identical step counts, states to round-off.  (The ragged tests above stay below the batch sizes that select
+    these shapes.)"""
+    torch = _torch()
+    from pcgym_amd import VecEnv
+
+    p = copy.deepcopy(SC.scenarios()[name]["env_params"])
+    p["integrator"] = "dopri5"
+    q = VecEnv(copy.deepcopy(p), n_envs=B, seed=5, **kw)
+    cl = VecEnv(copy.deepcopy(p), n_envs=B, seed=5, variant=1, **kw)
+    q.reset()
+    cl.reset()
+    gen = torch.Generator(device=q.device).manual_seed(8)
+    for i in range(3):
+        at = 2 * torch.rand((q.spec.na, B), generator=gen, device=q.device, dtype=torch.float64) - 1
+        o1, r1, d1, _, _ = q.step(at)
+        o2, r2, d2, _, _ = cl.step(at)
+        H.adaptive_check(q.spec.model.name, q.x.cpu().numpy(), cl.x.cpu().numpy(), q.nsteps.cpu().numpy(),
+                         cl.nsteps.cpu().numpy(), (name, i), tol=1e-12)
+        assert torch.equal(d1, d2) and torch.equal(q.status, cl.status), (name, i)
+        assert torch.allclose(o1, o2, rtol=1e-11, atol=1e-11) and torch.allclose(r1, r2, rtol=1e-9, atol=1e-11), (name, i)
+    q.close()
+    cl.close()
+
+
+@pytest.mark.parametrize("S,threads", [(512, 256), (1024, 256), (2048, 256), (512, 512), (1024, 512), (2048, 512)])
+def test_tile_sort_of_the_work_queue_kernel(S, threads):
+    """The step results do not depend on the order of a tile, so a sort that does not sort would only make launches slower:
+    the bitonic network over registers, cross-lane reads and LDS (sort_tile) on its own, every (tile width, workgroup size)
+    the step kernels instantiate, against numpy -- random keys with the slot index in the low bits as the kernel packs them,
+    sorted input, reversed input, and the padded tail of a partly filled tile."""
+    torch = _torch()
+    from pcgym_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(S + threads)
+    ntiles = 37
+    words = np.empty((ntiles, S), dtype=np.uint32)
+    for t in range(ntiles):
+        key = rng.integers(0, 1 << 21, S, dtype=np.uint32)
+        if t == 1:
+            key = np.sort(key)
+        if t == 2:
+            key = np.sort(key)[::-1].copy()
+        if t == 3:
+            key[:] = 7  # equal keys: the slot index alone decides
+        w = (key << np.uint32(11)) | np.arange(S, dtype=np.uint32)
+        if t == 4:  # a tile with n < S real slots: the padding words are the bare slot indices (key 0)
+            w[S // 3:] = np.arange(S // 3, S, dtype=np.uint32)
+        words[t] = w
+    d = torch.tensor(words.view(np.int32), device="cuda")
+    rc = lib.pcg_test_sort_tile(d.data_ptr(), S, threads, ntiles, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = d.cpu().numpy().view(np.uint32)
+    want = -np.sort(-words.astype(np.int64), axis=1)
+    assert np.array_equal(got.astype(np.int64), want)
+    assert lib.pcg_test_sort_tile(d.data_ptr(), 768, threads, ntiles, None) != 0  # not a width the kernels use
