@@ -996,7 +996,8 @@ static int warm_occupancy(pcg_plan* p) {
       p->stream_occ[e] = q;
     }
   }
-  if ((p->integrator_id == PCG_INT_DOPRI5 && k.queue[0]) || (p->integrator_id == PCG_INT_RODAS4 && k.queue_r4[0])) {
+  if (((p->integrator_id == PCG_INT_DOPRI5 || p->integrator_id == PCG_INT_RK4G || p->integrator_id == PCG_INT_T5G) && k.queue[0]) ||
+      (p->integrator_id == PCG_INT_RODAS4 && k.queue_r4[0])) {
     const int rc = queue_geometry(p, k, 0, 0);
     if (rc != PCG_OK) return rc;
   }
@@ -1068,12 +1069,15 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   const bool r4q = p->integrator_id == PCG_INT_RODAS4;
   const StepFn* qtab = r4q ? k.queue_r4 : k.queue;
   const bool q_forced = p->variant == 5 || std::getenv("PCG_Q_FORCE") != nullptr;  // PCG_OPT_VARIANT 5: any model
-  if ((p->integrator_id == PCG_INT_DOPRI5 || r4q) && !lds_st && (p->variant == 0 || p->variant == 5) && qtab[per_env_t ? 1 : 0] &&
-      (k.queue_default || q_forced)) {
+  // the launch of a work-queue kernel (geometry, tile, LDS): true = taken, rc_out is the launch's status
+  auto queue_launch = [&](StepArgs a, const StepFn* qtab, bool r4q, bool q_forced, int& rc_out) -> bool {
     const int pe = per_env_t ? 1 : 0;
     const size_t sb = (per_env_t && a.sched_in_lds) ? sizeof(double) * (size_t)(c.nsp + c.nd) * c.N : 0;
     rc = queue_geometry(p, k, pe, sb);
-    if (rc != PCG_OK) return rc;
+    if (rc != PCG_OK) {
+      rc_out = rc;
+      return true;
+    }
     if (p->q_tile[pe] > 0) {
       a.q_tile = p->q_tile[pe];
       if (const char* ev = std::getenv("PCG_Q_TILE")) {  // measurement switch: smaller tile (A/B)
@@ -1153,10 +1157,34 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
         qsh = k.queue_lds_x(Tq) + sb;
       }
       hipLaunchKernelGGL(w1 ? k.queue_r4w1[pe] : wide ? k.queue_w[pe] : qtab[pe], dim3((unsigned)nwg), dim3(qb), qsh, (hipStream_t)stream, a);
-      return (int)hipGetLastError();
+      rc_out = (int)hipGetLastError();
+      return true;
       }
     }
+      return false;
+  };
+  if ((p->integrator_id == PCG_INT_DOPRI5 || r4q) && !lds_st && (p->variant == 0 || p->variant == 5) && qtab[per_env_t ? 1 : 0] &&
+      (k.queue_default || q_forced)) {
+    int qrc = PCG_OK;
+    if (queue_launch(a, qtab, r4q, q_forced, qrc)) return qrc;
   }
+  // Guarded plans (PCG_INT_RK4G / PCG_INT_T5G) in TWO launches: the general kernel takes the guarded fixed step of every
+  // env and only MARKS the ones it does not trust (done[e] = 2, nothing else of their step stored); the work-queue kernel
+  // of the adaptive pair then integrates exactly the marked envs -- longest first, lanes pulling the next one -- and
+  // finishes their step.  In one launch the fallback ran inside the wave that met it: with a third of a batch igniting
+  // every wave waited for its slowest lane (607 us per 2^20-env step on the full x0 box of the cstr against 362 us for the
+  // adaptive pair through the queue alone).  Same arithmetic per env either way (tests: the oracle's t5g / rk4g twins).
+  // Costs the calm closed loop one nearly empty launch.  Not with a_delta (env_pre accumulates into a_save: not idempotent).
+  bool fixup = (p->integrator_id == PCG_INT_RK4G || p->integrator_id == PCG_INT_T5G) && !lds_st && p->variant == 0 &&
+               k.queue[per_env_t ? 1 : 0] && !(c.flags & PCG_F_A_DELTA) && io->B >= (int64_t)p->num_cus * QBLOCK &&
+               !std::getenv("PCG_NO_FIXUP");
+  if (fixup) {
+    const size_t sbq = (per_env_t && a.sched_in_lds) ? sizeof(double) * (size_t)(c.nsp + c.nd) * c.N : 0;
+    rc = queue_geometry(p, k, per_env_t ? 1 : 0, sbq);
+    if (rc != PCG_OK) return rc;
+    fixup = p->q_tile[per_env_t ? 1 : 0] > 0;
+  }
+  a.fixup = fixup ? 1 : 0;
   // lean variant when no noise / Gaussian disturbance / constraint work is configured
   // (the lean kernels also compile out a_delta, the terminal "batch" reward and per-env disturbances)
   const bool extras = (c.flags & (PCG_F_NOISE | PCG_F_GAUSS_DIST | PCG_F_A_DELTA | PCG_F_REWARD_BATCH | PCG_F_REWARD_TRACK)) ||
@@ -1257,7 +1285,11 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   if (shmem > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(fn, dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  rc = (int)hipGetLastError();
+  if (rc != PCG_OK || !fixup) return rc;
+  int qrc = PCG_OK;
+  if (!queue_launch(a, k.queue, false, true, qrc)) return PCG_E_UNSUPPORTED;  // (not reachable: the geometry was checked above)
+  return qrc;
 }
 
 int pcg_step(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t seed, void* stream) {

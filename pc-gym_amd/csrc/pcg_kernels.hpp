@@ -177,6 +177,9 @@ struct StepArgs {
   float q_w;             // work-queue kernel: weight of ln(scaled |f(x0)|) in the sort key (the transient's share)
   int32_t q_prio;        // work-queue kernel: waves holding one of the q_prio heaviest envs of their tile raise their issue
                          // priority (0 = off); workgroups of the upper half of the grid start their heaviest envs two waves on
+  int32_t fixup;         // guarded plans in two launches (pcg_abi.hip): 1 = the general kernel leaves an env the guard does not
+                         // trust untouched and marks it (done[e] = PCG_DONE_PENDING), the work-queue kernel then integrates
+                         // exactly the marked envs with the adaptive pair and finishes their step
 };
 
 // ---------------------------------------------------------------------------
@@ -467,12 +470,14 @@ PCG_DEV int finite_status(int status, const double (&x)[NX], int nx) {
   return (status == PCG_ST_OK && !ok) ? PCG_ST_NONFINITE : status;
 }
 
+constexpr int PCG_ST_PENDING = 64;        // internal: a guarded env left to the fix-up launch (never reaches a status buffer)
+constexpr unsigned char PCG_DONE_PENDING = 2;  // its mark in the `done` buffer between the two launches (overwritten by the second)
 // Guarded fixed-step plans on one env (PCG_INT_RK4G, PCG_INT_T5G): the fixed-step scheme under the model's guard; an env
 // that is not trusted (guard tripped; PCG_INT_T5G: or the embedded error estimate too large) is re-integrated from its start
 // state by the adaptive pair at the plan's tolerance.  Returns the pair's status (PCG_ST_OK for trusted envs).
 template <class M, int INTEG, class K, class F>
 PCG_DEV int guarded_env(const F& f, const K& kp, const typename M::Hold& hold, double (&x)[M::NX], CDevConst& c, int nx,
-                        int& nacc, int& nrej) {
+                        int& nacc, int& nrej, bool defer = false) {
   constexpr int NX = M::NX;
   int status = PCG_ST_OK;
   if constexpr (has_guard<M>::value) {
@@ -490,6 +495,7 @@ PCG_DEV int guarded_env(const F& f, const K& kp, const typename M::Hold& hold, d
     if (gc != 0) {  // the fixed step is not trusted for this env: the adaptive pair, from the start state
 #pragma unroll
       for (int i = 0; i < NX; ++i) x[i] = x0[i];
+      if (defer) return PCG_ST_PENDING;  // two-launch form: the work-queue kernel picks this env up (same pair, same tolerance)
       RegStages<NX> Kst;
       // at the PLAN's tolerance, whatever tripped (round 3 ran contracting states at 1e-7 whatever the user had asked for)
       status = dopri5<NX>(f, Kst, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
@@ -523,7 +529,8 @@ PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const do
     cv8<NX>(f, x, c.h, c.substeps);
   } else if (INTEG == PCG_INT_RK4G || INTEG == PCG_INT_T5G) {
     int nacc = 0, nrej = 0;
-    status = guarded_env<M, INTEG>(f, kp, hold, x, c, nx, nacc, nrej);
+    status = guarded_env<M, INTEG>(f, kp, hold, x, c, nx, nacc, nrej, A.fixup != 0);
+    if (status == PCG_ST_PENDING) return status;
     if (A.nsteps) {
       A.nsteps[e] = nacc;
       A.nsteps[A.B + e] = nrej;
@@ -858,6 +865,12 @@ PCG_DEV void env_step(const StepArgs& A, CDevConst& c, const double* sched_l, do
   } else {
     status = integrate_env<M, INTEG, LDS_STAGES>(A, c, kp, pre.u, x, stage_l, e, nx);
   }
+  if constexpr (INTEG == PCG_INT_RK4G || INTEG == PCG_INT_T5G) {
+    if (status == PCG_ST_PENDING) {  // nothing of this env's step has been stored: the fix-up launch redoes it from x_t
+      out.status = PCG_ST_PENDING;
+      return;
+    }
+  }
   env_post<M, PER_ENV_T, EXTRAS, UNC>(A, c, sched_l, e, t, pre, x, status, out);
 }
 
@@ -939,6 +952,12 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX, ros_structured<M>::val
   for (int i = 0; i < NA; ++i) a[i] = (i < na) ? A.a[(size_t)i * B + e] : 0.0;
   EnvOut<M> out;
   env_step<M, INTEG, PER_ENV_T, LDS_STAGES, EXTRAS, UNC>(A, c, sched_l, stage_l, e, t, a, x, out);
+  if constexpr (INTEG == PCG_INT_RK4G || INTEG == PCG_INT_T5G) {
+    if (out.status == PCG_ST_PENDING) {
+      A.done[e] = PCG_DONE_PENDING;
+      return;
+    }
+  }
   if (A.auto_reset && out.done) {
     // gymnasium "same-step" auto-reset in the same launch: reward / done / viol of the finished step are kept,
     // state, observation, step counter (and a_delta accumulator, per-env parameters) are those of the new episode

@@ -465,6 +465,8 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
   int32_t* rejs = accs + T;
   int32_t* flag = rejs + T;   // bits 0-1: PCG_ST_* of the integration, bit 2: pre-step "done"
   int32_t* next = flag + T;   // queue head (the first min(n, 256) sorted slots are handed out directly)
+  int32_t* nq = next + 1;     // fix-up launch: number of marked envs in the sub-tile
+  const bool fix = A.fixup != 0;
   const bool xlds = (A.q_tile & 0x20000) != 0;  // the tile's state lives in LDS (host: it fits)
   double* xs = reinterpret_cast<double*>(next + 4 + (T & 1));  // [NX][T] when xlds (8-byte aligned)
   double* sched_l = xs + (xlds ? (size_t)NX * T : 0);  // per-env-t schedule tables behind the tile
@@ -476,6 +478,11 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
   const int64_t per = (B + gridDim.x - 1) / gridDim.x;
   const int64_t lo = (int64_t)blockIdx.x * per, hi = min(B, lo + per);
   if (lo >= hi) return;
+  if (fix) {  // nothing marked in this workgroup's range (the calm closed loop: every launch): leave after one round of loads
+    int found = 0;
+    for (int64_t i = lo + tid; i < hi; i += QB) found |= A.done[i] == PCG_DONE_PENDING ? 1 : 0;
+    if (!__syncthreads_or(found)) return;
+  }
   const int nsub = (int)((hi - lo + T - 1) / T);
   const int64_t sub = (hi - lo + nsub - 1) / nsub;
   const double dt = c.dt, rtol = c.rtol, atol = c.atol;
@@ -492,9 +499,15 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
     const int n = (int)(min(hi, base + sub) - base);  // envs in this sub-tile
     // ---------------- phase 1: load, pre-integration half, park in LDS ----------------
     const int S = n <= QSORT / 4 ? QSORT / 4 : (n <= QSORT / 2 ? QSORT / 2 : QSORT);  // sort width
+    if (fix) {  // fix-up launch of a guarded plan: only the envs the first launch marked are integrated here
+      if (tid == 0) *nq = 0;
+      __syncthreads();
+    }
     for (int s = tid; s < S; s += QB) {
       uint32_t word = (uint32_t)s;  // padding: sorts behind every real slot
-      if (s < n) {
+      if (s < n && fix && A.done[base + s] != PCG_DONE_PENDING) {
+        flag[s] = 0;  // not this launch's env: sorts behind the marked ones (key 0), skipped by phase 3
+      } else if (s < n) {
         const int64_t e = base + s;
         const int t = PER_ENV_T ? A.t[e] : A.t_scalar;
         double x[NX], a[NA];
@@ -521,7 +534,8 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
           for (int i = 0; i < NX; ++i) xs[(size_t)i * T + s] = x[i];
         }
         hs[s] = h;
-        flag[s] = pre.done_pre ? 4 : 0;
+        flag[s] = (pre.done_pre ? 4 : 0) | (fix ? 8 : 0);
+        if (fix) atomicAdd(nq, 1);
         float key;
         // stability-limited part (the model's rate x dt) + the initial transient's share (ln of the scaled |f(x0)|,
         // already computed for the initial step size).  A least-squares fit on BASELINE configs[2] puts the weight at
@@ -537,9 +551,11 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
       }
       sortbuf[s] = word;
     }
-    if (tid == 0) *next = QB < n ? QB : n;
     PCG_QS(1);
     __syncthreads();
+    const int nqv = fix ? *nq : n;  // envs in the queue (the marked ones sort first: their key is positive)
+    if (fix && nqv == 0) continue;  // (uniform: nothing of this sub-tile is left to do; its LDS is not touched again)
+    if (tid == 0) *next = QB < nqv ? QB : nqv;  // (ordered before phase 2 by the sort's barriers)
     // ---------------- sort the slots by decreasing cost key ----------------
     if (S == QSORT / 4) sort_tile<QSORT / 4 / QB, QB>(sortbuf);
     else if (S == QSORT / 2) sort_tile<QSORT / 2 / QB, QB>(sortbuf);
@@ -556,9 +572,9 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
     // idle lanes that trigger a refill: with at most two envs per lane every lane refills once and waiting for company
     // only idles it (me10: 0.678 ms at 8, 0.656 at 2); with more envs per lane the refill code -- executed by the whole
     // wave -- is worth batching (configs[4] shard: 0.916 ms at 8, 0.929 at 2; profiles/r2/queue_refill_sweep.txt)
-    const int refill = refill_hi ? refill_hi : (n <= 2 * QB ? 2 : QREFILL);
+    const int refill = refill_hi ? refill_hi : (nqv <= 2 * QB ? 2 : QREFILL);
     PCG_QS(2);
-    queue_integrate<M, INTEG, QB>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, A.q_prio,
+    queue_integrate<M, INTEG, QB>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, nqv, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, A.q_prio,
                               (A.q_prio > 0 && blockIdx.x >= gridDim.x / 2) ? 2 * 64 : 0, qst);
     if (A.q_prio > 0) __builtin_amdgcn_s_setprio(0);
     PCG_QS(3);
@@ -566,6 +582,7 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
     PCG_QS(4);
     // ---------------- phase 3: post-integration half, coalesced stores ----------------
     for (int s = tid; s < n; s += QB) {
+      if (fix && !(flag[s] & 8)) continue;
       const int64_t e = base + s;
       const int t = PER_ENV_T ? A.t[e] : A.t_scalar;
       double x[NX];

@@ -297,3 +297,45 @@ def test_full_size_default_plans_of_four_tank_and_cryst():
         if name.startswith("four_tank"):
             assert bool((env.x > 0).all()) and bool((env.x < 5.0).all())
         env.close(), env2.close()
+
+
+@pytest.mark.parametrize("integrator", ["tsit5g", "rk4g"])
+@pytest.mark.parametrize("kw", [{}, dict(per_env_t=True, auto_reset=True), dict(auto_reset=True)])
+def test_guarded_plans_two_launch_form_is_the_single_launch_bit_for_bit(integrator, kw, monkeypatch):
+    """Batches that fill the chip run a guarded plan as two launches -- the general kernel marks the envs its guard does not
+    trust, the work-queue kernel of the adaptive pair integrates exactly those (pcg_abi.hip) -- where smaller ones keep the
+    fallback inside the first kernel (the form the oracle tests above pin).  The arithmetic of an env is the same either way:
+    on the ignition box, with observation noise and a constraint, both forms give the same bits in every output, every step,
+    through episode ends (PCG_NO_FIXUP=1 keeps the single launch at any size)."""
+    torch = _torch()
+    from pcgym_amd import VecEnv
+
+    p = copy.deepcopy(SC.scenarios()["cstr_cons_pen_norm"]["env_params"])
+    p.update(x0=np.array([0.85, 330.0, 0.85]), uncertainty_percentages={"x0": [0.15 / 0.85, 20.0 / 330.0]}, integrator=integrator,
+             noise=True, noise_percentage=0.002)
+    B = (1 << 17) + 777
+    two = VecEnv(copy.deepcopy(p), n_envs=B, seed=4, **kw)
+    one = VecEnv(copy.deepcopy(p), n_envs=B, seed=4, **kw)
+    two.reset(), one.reset()
+    assert torch.equal(two.x, one.x)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    escalated = 0
+    for i in range(two.spec.N + 3 if kw else 8):
+        a = 2 * torch.rand((two.spec.na, B), generator=gen, device="cuda", dtype=torch.float64) - 1
+        monkeypatch.delenv("PCG_NO_FIXUP", raising=False)
+        o2, r2, d2, _, _ = two.step(a)
+        monkeypatch.setenv("PCG_NO_FIXUP", "1")
+        o1, r1, d1, _, _ = one.step(a)
+        monkeypatch.delenv("PCG_NO_FIXUP", raising=False)
+        escalated += int((two.nsteps.sum(dim=0) > 0).sum())
+        for name, u, v in (("x", two.x, one.x), ("obs", o2, o1), ("rew", r2, r1), ("done", d2, d1), ("nsteps", two.nsteps, one.nsteps),
+                           ("status", two.status, one.status), ("viol", two.viol, one.viol)):
+            if u is not None:
+                assert torch.equal(u, v), (i, name)
+        assert int(d2.max()) <= 1  # no pending mark survives the second launch
+        if two.t_env is not None:
+            assert torch.equal(two.t_env, one.t_env)
+        if not kw and i == 3:
+            break
+    assert escalated > B // 20
+    two.close(), one.close()
