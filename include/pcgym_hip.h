@@ -147,8 +147,11 @@ enum pcg_integrator {
   PCG_INT_RK4G = 5,    /* GUARDED RK4: `substeps` equal RK4 sub-steps, accepted per env only while the model's guard says the
                           fixed step is accurate -- no growing mode (largest growth rate g <= 0) and a resolved fastest
                           rate (rho h <= 1) at every sub-step start and at the end state, finite result; an env that
-                          fails the guard is re-integrated from its start state by PCG_INT_DOPRI5 at rtol / atol inside
-                          the same launch (nsteps reports (0,0) for accepted envs, the pair's counts otherwise).  Models
+                          fails the guard is re-integrated from its start state by PCG_INT_DOPRI5 at rtol / atol before
+                          pcg_step returns its launches to the stream -- inside the same kernel, or, for batches that fill
+                          the chip, by a second launch of the adaptive pair's work-queue kernel over exactly the envs the
+                          first one marked (same arithmetic per env, same bits; `done` holds the mark 2 only between the
+                          two) -- (nsteps reports (0,0) for accepted envs, the pair's counts otherwise).  Models
                           with a guard hook only (cstr: the ignition branch).  The guard is the ONLY test -- RK4 carries no
                           error estimate -- and it is calibrated on the cstr's observation box and action box: an opt-in
                           for that box (the model's default plan is PCG_INT_T5G, which also checks an estimate).  General
@@ -158,7 +161,7 @@ enum pcg_integrator {
                           env while (i) the model's guard holds at EVERY stage state and at the end state (g <= 0, rho h <= 2)
                           and (ii) the pair's own embedded 5(4) error estimate of every step stays below 4e-7 |x| + 4e-9 (RMS;
                           the seventh stage it needs is the next step's first stage and the end-state guard: no extra
-                          evaluation); otherwise PCG_INT_DOPRI5 from the start state at rtol / atol inside the same launch, as
+                          evaluation); otherwise PCG_INT_DOPRI5 from the start state at rtol / atol, in one launch or two as
                           PCG_INT_RK4G (same nsteps convention).  Calibrated so that the canonical cstr loop is never
                           escalated and every trusted env of a wide state / input / step-size box lies inside 3 x the
                           reference's CVODES tolerances (1e-6 |x| + 1e-8) of the true solution.  12 + 1 evaluations per

@@ -41,7 +41,8 @@ DEFAULT_INTEGRATOR = {
     # finite garbage, while the reference's CVODES integrates it.  integrator='rk4' stays available as an explicit
     # opt-in for the canonical closed loop (T < 330 K), where 4 sub-steps reach 6e-8.
     # Round 3: 'rk4g' -- RK4 x 5 under the model's guard (no growing mode, resolved fastest rate, at every sub-step start
-    # and at the end state); an env that trips it is re-integrated by the adaptive pair at 1e-10 inside the same launch.
+    # and at the end state); an env that trips it is re-integrated by the adaptive pair at 1e-10 inside the same step call (round 4: by a
+    # second launch -- the pair's work-queue kernel over the marked envs -- when the batch fills the chip).
     # The canonical closed loop never trips it (128 -> ~37 us per 2^20-env step); the ignition and hot branches always do.
     # Later in round 3: 'tsit5g' -- the same guard at every stage state of TWO fixed Tsit5 steps: the accuracy of RK4 x 5
     # (7.5e-7 against 6.9e-7 on the accepted envs, tests/test_erk.py) with 12 right-hand sides instead of 20: 44.7 ->
