@@ -934,7 +934,8 @@ static int resident_blocks(StepFn fn) {
 static int queue_geometry(pcg_plan* p, const Kernels& k, int pe, size_t sched_bytes) {
   if (p->q_tile[pe] != 0) return PCG_OK;
   hipFuncAttributes fa;
-  const StepFn qfn = (p->integrator_id == PCG_INT_RODAS4 ? k.queue_r4 : k.queue)[pe];
+  const bool guarded = p->integrator_id == PCG_INT_RK4G || p->integrator_id == PCG_INT_T5G;  // their fix-up launch
+  const StepFn qfn = (p->integrator_id == PCG_INT_RODAS4 ? k.queue_r4 : guarded ? k.queue_fix : k.queue)[pe];
   hipError_t e = hipFuncGetAttributes(&fa, (const void*)qfn);
   if (e != hipSuccess) return (int)e;
   const int alloc = ((fa.numRegs + 7) / 8) * 8;
@@ -996,7 +997,7 @@ static int warm_occupancy(pcg_plan* p) {
       p->stream_occ[e] = q;
     }
   }
-  if (((p->integrator_id == PCG_INT_DOPRI5 || p->integrator_id == PCG_INT_RK4G || p->integrator_id == PCG_INT_T5G) && k.queue[0]) ||
+  if ((p->integrator_id == PCG_INT_DOPRI5 && k.queue[0]) || ((p->integrator_id == PCG_INT_RK4G || p->integrator_id == PCG_INT_T5G) && k.queue_fix[0]) ||
       (p->integrator_id == PCG_INT_RODAS4 && k.queue_r4[0])) {
     const int rc = queue_geometry(p, k, 0, 0);
     if (rc != PCG_OK) return rc;
@@ -1156,6 +1157,13 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
         a.q_tile |= 0x20000;
         qsh = k.queue_lds_x(Tq) + sb;
       }
+      if (a.fixup) {  // fix-up launch: a tile is a compact list of up to Tq MARKED envs (+ 4 bytes per slot: which env), the
+        // state stays in the batch
+        Tq = p->q_tile[pe];
+        while (Tq > qb && k.queue_lds(Tq) + 4 * (size_t)Tq + 8 + sb > (size_t)(160 * 1024 - 2048) / q_bpc) Tq -= 64;
+        a.q_tile = (a.q_tile & ~(0xFFFF | 0x20000)) | Tq;
+        qsh = k.queue_lds(Tq) + 4 * (size_t)Tq + 8 + sb;
+      }
       hipLaunchKernelGGL(w1 ? k.queue_r4w1[pe] : wide ? k.queue_w[pe] : qtab[pe], dim3((unsigned)nwg), dim3(qb), qsh, (hipStream_t)stream, a);
       rc_out = (int)hipGetLastError();
       return true;
@@ -1176,7 +1184,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   // adaptive pair through the queue alone).  Same arithmetic per env either way (tests: the oracle's t5g / rk4g twins).
   // Costs the calm closed loop one nearly empty launch.  Not with a_delta (env_pre accumulates into a_save: not idempotent).
   bool fixup = (p->integrator_id == PCG_INT_RK4G || p->integrator_id == PCG_INT_T5G) && !lds_st && p->variant == 0 &&
-               k.queue[per_env_t ? 1 : 0] && !(c.flags & PCG_F_A_DELTA) && io->B >= (int64_t)p->num_cus * QBLOCK &&
+               k.queue_fix[per_env_t ? 1 : 0] && !(c.flags & PCG_F_A_DELTA) && io->B >= (int64_t)p->num_cus * QBLOCK &&
                !std::getenv("PCG_NO_FIXUP");
   if (fixup) {
     const size_t sbq = (per_env_t && a.sched_in_lds) ? sizeof(double) * (size_t)(c.nsp + c.nd) * c.N : 0;
@@ -1288,7 +1296,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   rc = (int)hipGetLastError();
   if (rc != PCG_OK || !fixup) return rc;
   int qrc = PCG_OK;
-  if (!queue_launch(a, k.queue, false, true, qrc)) return PCG_E_UNSUPPORTED;  // (not reachable: the geometry was checked above)
+  if (!queue_launch(a, k.queue_fix, false, true, qrc)) return PCG_E_UNSUPPORTED;  // (not reachable: the geometry was checked above)
   return qrc;
 }
 

@@ -1759,6 +1759,7 @@ struct Kernels {
   StepFn stream[PCG_INT_COUNT][2];      // persistent streaming kernel [integrator][EPL-1] (entries may be null)
   StepFn step_unc[PCG_INT_COUNT][2]; // per-env parameter uncertainty [integrator][per_env_t] (null for affine)
   StepFn queue[2];                   // DOPRI5 with the in-workgroup work queue [per_env_t] (null for affine)
+  StepFn queue_fix[2];               // ... the fix-up launch of a guarded plan (models with a guard hook)
   StepFn queue_w[2];                 // ... 512-thread workgroups: both waves of a SIMD on ONE tile (models with a cost key, <= 256 registers)
   StepFn queue_r4[2];                // Rodas4 through the same work queue [per_env_t] (models with structured W only)
   StepFn queue_r4w1[2];              // ... compiled for ONE workgroup per CU (no register spills in the loop)
@@ -1847,6 +1848,10 @@ Kernels make_kernels() {
     // integration.  The queue is the default only where a model declares a cost key, i.e. where the step count is
     // large and predictable from the input (the extraction models: 1.12-1.23x); PCG_Q_FORCE routes any model to it.
     k.queue_default = has_cost_key<M>::value;
+    if constexpr (has_guard<M>::value) {
+      k.queue_fix[0] = step_kernel_queue<M, false, true, PCG_INT_DOPRI5, 0, QBLOCK, true>;
+      k.queue_fix[1] = step_kernel_queue<M, true, true, PCG_INT_DOPRI5, 0, QBLOCK, true>;
+    }
     // (only where the 256-thread build already runs two waves per SIMD.  The 20-state cascade was tried: at 512 threads its
     // loop is allocated 256 registers with ~10 scratch accesses per attempt, but a second wave buys 9 % of issue rate
     // (3.85 against 4.24 us of SIMD time per attempt) and two envs per lane instead of four cost more: 0.345 against 0.327 ms)

@@ -232,14 +232,20 @@ PCG_DEV int rodas4_attempt(const K& kp, const typename M::Hold& hold, const F& f
 
 // ---- phase 2: the work queue of one tile.  (Tried as a real, non-inlined function so that the loop would own the
 // whole register file: the call ABI's save / restore made it worse -- 772 B of scratch against 140.)
-template <class M, int INTEG = PCG_INT_DOPRI5, int QB = QBLOCK>
+template <class M, int INTEG = PCG_INT_DOPRI5, int QB = QBLOCK, bool COMPACT = false>
 PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, double* us, const double* hs,
                                                           const uint32_t* sortbuf, int32_t* accs, int32_t* rejs,
                                                           int32_t* flag, int32_t* next, int T, int n, int refill, double dt, double dt_edge,
                                                           double h_floor, double rtol, double atol, int max_steps,
                                                           double ep_c = 0.0, int ep_kmax = 0, int prio_h = 0, int rot = 0,
-                                                          unsigned long long* qst = nullptr) {
+                                                          unsigned long long* qst = nullptr, const int32_t* eidx = nullptr) {
   constexpr int NX = M::NX, NU = M::NA + M::NDM;
+  // COMPACT (fix-up launch of a guarded plan): the slots are a compact list of marked envs, eidx[slot] is the env's position
+  // in the state window xg; otherwise a slot is its own position
+  auto xpos = [&](int sl) -> size_t {
+    if constexpr (COMPACT) return (size_t)eidx[sl];
+    else return (size_t)sl;
+  };
 #ifdef PCG_QSTATS  // measurement build (tools/queue_probe.py): per-wave counts of what the loop below did
   unsigned long long qs_iter = 0, qs_att = 0, qs_busy = 0, qs_refill = 0, qs_refill_clk = 0, qs_pop = 0;
 #endif
@@ -262,7 +268,7 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
     if (iter > iter_cap) {
       if (slot >= 0) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + slot] = __builtin_nan("");
+        for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + xpos(slot)] = __builtin_nan("");
         accs[slot] = L.acc;
         rejs[slot] = L.rej;
         flag[slot] |= PCG_ST_MAX_STEPS;
@@ -276,7 +282,7 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
 #endif
     if (fresh) {  // (re)fill: state from the batch (xg = &x[0][base of the tile]), held input from the slot, k1 = f(x)
 #pragma unroll
-      for (int i = 0; i < NX; ++i) L.x[i] = xg[(size_t)i * xstride + slot];
+      for (int i = 0; i < NX; ++i) L.x[i] = xg[(size_t)i * xstride + xpos(slot)];
       double u[NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i) u[i] = us[(size_t)i * T + slot];
@@ -354,7 +360,7 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
       if (st >= 0) {  // finished (or gave up): park the result, free the lane
         poison_if_failed<NX>(st, L.x);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + slot] = L.x[i];
+        for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + xpos(slot)] = L.x[i];
         accs[slot] = L.acc;
         rejs[slot] = L.rej;
         flag[slot] |= st;
@@ -447,13 +453,15 @@ struct QLayout {
 // QB: threads per workgroup.  256 = one wave per SIMD and workgroup, as many workgroups per CU as the registers allow;
 // 512 = the two waves of every SIMD belong to ONE workgroup and share ONE tile of twice the size (see pcg_abi.hip:
 // queue launch geometry): a pool twice as deep for the same lanes, and no wave left alone behind its SIMD-mate's tile.
-template <class M, bool PER_ENV_T, bool EXTRAS, int INTEG = PCG_INT_DOPRI5, int WAVES = 0, int QB = QBLOCK>
+// FIX: the fix-up launch of a guarded plan (its own instantiation: the launches of the adaptive plans carry none of it)
+template <class M, bool PER_ENV_T, bool EXTRAS, int INTEG = PCG_INT_DOPRI5, int WAVES = 0, int QB = QBLOCK, bool FIX = false>
 __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, false)) void step_kernel_queue(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   static_assert(!M::DYNAMIC, "the work-queue kernel is built for the fixed-size models");
   CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA, NDM = M::NDM, NU = NA + NDM;
   const int T = A.q_tile & 0xFFFF;
+  constexpr bool fix = FIX;  // fix-up launch of a guarded plan (pcg_abi.hip): only the envs the first launch marked
   const bool nosort = (A.q_tile & 0x10000) != 0;  // measurement switch (PCG_Q_NOSORT)
   const int refill_hi = (A.q_tile >> 20) & 0x7F;  // measurement switch (PCG_Q_REFILL); 0 = the default
   // (the default depends on the tile: see where it is used)
@@ -465,11 +473,11 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
   int32_t* rejs = accs + T;
   int32_t* flag = rejs + T;   // bits 0-1: PCG_ST_* of the integration, bit 2: pre-step "done"
   int32_t* next = flag + T;   // queue head (the first min(n, 256) sorted slots are handed out directly)
-  int32_t* nq = next + 1;     // fix-up launch: number of marked envs in the sub-tile
-  const bool fix = A.fixup != 0;
+  int32_t* nq = next + 1;     // fix-up launch: number of marked envs parked in this round
   const bool xlds = (A.q_tile & 0x20000) != 0;  // the tile's state lives in LDS (host: it fits)
   double* xs = reinterpret_cast<double*>(next + 4 + (T & 1));  // [NX][T] when xlds (8-byte aligned)
-  double* sched_l = xs + (xlds ? (size_t)NX * T : 0);  // per-env-t schedule tables behind the tile
+  int32_t* eidx = reinterpret_cast<int32_t*>(xs);  // fix-up launch: env (relative to the workgroup's range) of a compact slot
+  double* sched_l = xs + (xlds ? (size_t)NX * T : fix ? (size_t)(T + 1) / 2 : 0);  // per-env-t schedule tables behind the tile
   if (PER_ENV_T) stage_schedules(A, c, sched_l);
   typename M::CKP& kp = *(typename M::CKP*)c.kp;
   const int64_t B = A.B;
@@ -493,69 +501,86 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
   unsigned long long* qst = nullptr;
 #define PCG_QS(k)
 #endif
-  for (int isub = 0; isub < nsub; ++isub) {
-    const int64_t base = lo + (int64_t)isub * sub;
+  int64_t scan = lo;  // fix-up launch: the next env of the range to look at
+  for (int isub = 0; fix ? scan < hi : isub < nsub; ++isub) {
+    const int64_t base = fix ? lo : lo + (int64_t)isub * sub;
     PCG_QS(0);
-    const int n = (int)(min(hi, base + sub) - base);  // envs in this sub-tile
     // ---------------- phase 1: load, pre-integration half, park in LDS ----------------
-    const int S = n <= QSORT / 4 ? QSORT / 4 : (n <= QSORT / 2 ? QSORT / 2 : QSORT);  // sort width
-    if (fix) {  // fix-up launch of a guarded plan: only the envs the first launch marked are integrated here
+    // one slot: the env's pre-integration half, its held input, initial step size and flags parked at slot s; returns the
+    // slot's sort word
+    auto park = [&](int s, int64_t e) -> uint32_t {
+      const int t = PER_ENV_T ? A.t[e] : A.t_scalar;
+      double x[NX], a[NA];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = A.x[(size_t)i * B + e];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a[i] = A.a[(size_t)i * B + e];
+      EnvPre<M> pre;
+      env_pre<M, PER_ENV_T, EXTRAS>(A, c, sched_l, e, t, a, x, pre);
+      const typename M::Hold hold = M::hold(kp, pre.u);
+      const RhsFn<M> f{kp, hold};
+      double k1[NX];
+      double d1, h;
+      if constexpr (INTEG == PCG_INT_RODAS4) {
+        f(x, k1);
+        h = rodas4_h_init<NX>(x, k1, NX, dt, rtol, atol, d1);
+      } else {
+        h = dopri5_h_init<NX>(f, x, k1, NX, dt, rtol, atol, d1);
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) us[(size_t)i * T + s] = pre.u[i];
+      if (xlds) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xs[(size_t)i * T + s] = x[i];
+      }
+      hs[s] = h;
+      flag[s] = pre.done_pre ? 4 : 0;
+      float key;
+      // stability-limited part (the model's rate x dt) + the initial transient's share (ln of the scaled |f(x0)|,
+      // already computed for the initial step size).  A least-squares fit on BASELINE configs[2] puts the weight at
+      // 33 (correlation with the measured step counts 0.84 -> 0.96, list-scheduling efficiency of independent lanes
+      // 0.836 -> 0.862); lock-stepped waves prefer less: measured optimum ~20 (pcg_abi.hip, profiles/r2/queue_w_sweep.txt)
+      if constexpr (INTEG == PCG_INT_RODAS4)  // fitted attempts per env step of the Rosenbrock pair (pcg_models.hpp)
+        key = M::cost_key_ros(kp, pre.u) + A.q_w * __builtin_logf(__builtin_fmaxf((float)d1, 1.0f));
+      else if constexpr (has_cost_key<M>::value)
+        key = (float)(M::cost_key(kp, pre.u) * dt) + A.q_w * __builtin_logf(__builtin_fmaxf((float)d1, 1.0f));
+      else key = (float)(dt / h);  // generic proxy: steps at the initial step size
+      key = nosort ? 1.0f : __builtin_fmaxf(key, 1e-30f);
+      return ((__float_as_uint(key) >> QSLOT_BITS) << QSLOT_BITS) | (uint32_t)s;  // positive floats order like their bit patterns
+    };
+    int n, S;
+    if (fix) {
+      // The marked envs of the range go into a COMPACT list of slots (eidx[slot] = the env), QB envs looked at per round
+      // of the scan, until the range ends or the next round might not fit: a tile holds T MARKED envs, so a workgroup whose
+      // share of the batch is several tiles long still starts its heaviest env first -- with sub-tiles of the range the
+      // second one's ignition front (~130 attempts of a lone lane) only started when the first one's had finished.
       if (tid == 0) *nq = 0;
       __syncthreads();
-    }
-    for (int s = tid; s < S; s += QB) {
-      uint32_t word = (uint32_t)s;  // padding: sorts behind every real slot
-      if (s < n && fix && A.done[base + s] != PCG_DONE_PENDING) {
-        flag[s] = 0;  // not this launch's env: sorts behind the marked ones (key 0), skipped by phase 3
-      } else if (s < n) {
-        const int64_t e = base + s;
-        const int t = PER_ENV_T ? A.t[e] : A.t_scalar;
-        double x[NX], a[NA];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = A.x[(size_t)i * B + e];
-#pragma unroll
-        for (int i = 0; i < NA; ++i) a[i] = A.a[(size_t)i * B + e];
-        EnvPre<M> pre;
-        env_pre<M, PER_ENV_T, EXTRAS>(A, c, sched_l, e, t, a, x, pre);
-        const typename M::Hold hold = M::hold(kp, pre.u);
-        const RhsFn<M> f{kp, hold};
-        double k1[NX];
-        double d1, h;
-        if constexpr (INTEG == PCG_INT_RODAS4) {
-          f(x, k1);
-          h = rodas4_h_init<NX>(x, k1, NX, dt, rtol, atol, d1);
-        } else {
-          h = dopri5_h_init<NX>(f, x, k1, NX, dt, rtol, atol, d1);
+      int parked = 0;
+      while (scan < hi && parked + QB <= T) {
+        const int64_t e = scan + tid;
+        if (e < hi && A.done[e] == PCG_DONE_PENDING) {
+          const int s = atomicAdd(nq, 1);
+          eidx[s] = (int32_t)(e - lo);
+          sortbuf[s] = park(s, e);
         }
-#pragma unroll
-        for (int i = 0; i < NU; ++i) us[(size_t)i * T + s] = pre.u[i];
-        if (xlds) {
-#pragma unroll
-          for (int i = 0; i < NX; ++i) xs[(size_t)i * T + s] = x[i];
-        }
-        hs[s] = h;
-        flag[s] = (pre.done_pre ? 4 : 0) | (fix ? 8 : 0);
-        if (fix) atomicAdd(nq, 1);
-        float key;
-        // stability-limited part (the model's rate x dt) + the initial transient's share (ln of the scaled |f(x0)|,
-        // already computed for the initial step size).  A least-squares fit on BASELINE configs[2] puts the weight at
-        // 33 (correlation with the measured step counts 0.84 -> 0.96, list-scheduling efficiency of independent lanes
-        // 0.836 -> 0.862); lock-stepped waves prefer less: measured optimum ~20 (pcg_abi.hip, profiles/r2/queue_w_sweep.txt)
-        if constexpr (INTEG == PCG_INT_RODAS4)  // fitted attempts per env step of the Rosenbrock pair (pcg_models.hpp)
-          key = M::cost_key_ros(kp, pre.u) + A.q_w * __builtin_logf(__builtin_fmaxf((float)d1, 1.0f));
-        else if constexpr (has_cost_key<M>::value)
-          key = (float)(M::cost_key(kp, pre.u) * dt) + A.q_w * __builtin_logf(__builtin_fmaxf((float)d1, 1.0f));
-        else key = (float)(dt / h);  // generic proxy: steps at the initial step size
-        key = nosort ? 1.0f : __builtin_fmaxf(key, 1e-30f);
-        word = ((__float_as_uint(key) >> QSLOT_BITS) << QSLOT_BITS) | (uint32_t)s;  // positive floats order like their bit patterns
+        __syncthreads();
+        parked = *nq;
+        __syncthreads();  // (every thread has read the count before the next round adds to it)
+        scan += QB;
       }
-      sortbuf[s] = word;
+      n = parked;
+      if (n == 0) continue;  // (uniform)
+      S = n <= QSORT / 4 ? QSORT / 4 : (n <= QSORT / 2 ? QSORT / 2 : QSORT);
+      for (int s = n + tid; s < S; s += QB) sortbuf[s] = (uint32_t)s;  // padding: sorts behind every real slot
+    } else {
+      n = (int)(min(hi, base + sub) - base);  // envs in this sub-tile
+      S = n <= QSORT / 4 ? QSORT / 4 : (n <= QSORT / 2 ? QSORT / 2 : QSORT);  // sort width
+      for (int s = tid; s < S; s += QB) sortbuf[s] = s < n ? park(s, base + s) : (uint32_t)s;
     }
     PCG_QS(1);
     __syncthreads();
-    const int nqv = fix ? *nq : n;  // envs in the queue (the marked ones sort first: their key is positive)
-    if (fix && nqv == 0) continue;  // (uniform: nothing of this sub-tile is left to do; its LDS is not touched again)
-    if (tid == 0) *next = QB < nqv ? QB : nqv;  // (ordered before phase 2 by the sort's barriers)
+    if (tid == 0) *next = QB < n ? QB : n;  // (ordered before phase 2 by the sort's barriers)
     // ---------------- sort the slots by decreasing cost key ----------------
     if (S == QSORT / 4) sort_tile<QSORT / 4 / QB, QB>(sortbuf);
     else if (S == QSORT / 2) sort_tile<QSORT / 2 / QB, QB>(sortbuf);
@@ -572,18 +597,17 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
     // idle lanes that trigger a refill: with at most two envs per lane every lane refills once and waiting for company
     // only idles it (me10: 0.678 ms at 8, 0.656 at 2); with more envs per lane the refill code -- executed by the whole
     // wave -- is worth batching (configs[4] shard: 0.916 ms at 8, 0.929 at 2; profiles/r2/queue_refill_sweep.txt)
-    const int refill = refill_hi ? refill_hi : (nqv <= 2 * QB ? 2 : QREFILL);
+    const int refill = refill_hi ? refill_hi : (n <= 2 * QB ? 2 : QREFILL);
     PCG_QS(2);
-    queue_integrate<M, INTEG, QB>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, nqv, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, A.q_prio,
-                              (A.q_prio > 0 && blockIdx.x >= gridDim.x / 2) ? 2 * 64 : 0, qst);
+    queue_integrate<M, INTEG, QB, FIX>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, A.q_prio,
+                              (A.q_prio > 0 && blockIdx.x >= gridDim.x / 2) ? 2 * 64 : 0, qst, fix ? eidx : nullptr);
     if (A.q_prio > 0) __builtin_amdgcn_s_setprio(0);
     PCG_QS(3);
     __syncthreads();
     PCG_QS(4);
     // ---------------- phase 3: post-integration half, coalesced stores ----------------
     for (int s = tid; s < n; s += QB) {
-      if (fix && !(flag[s] & 8)) continue;
-      const int64_t e = base + s;
+      const int64_t e = fix ? lo + eidx[s] : base + s;
       const int t = PER_ENV_T ? A.t[e] : A.t_scalar;
       double x[NX];
       EnvPre<M> pre;
