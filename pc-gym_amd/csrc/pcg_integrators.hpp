@@ -689,6 +689,36 @@ PCG_DEV int tsit5(const F& f, double (&x)[NX], int n, double dt, double rtol, do
 #pragma unroll
     for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc3(a41, k1[i], a42, k2[i], a43, k3[i]), x[i]);
     f(y, k4);
+    if constexpr (NX > 10) {
+      // ACCUMULATOR FORM, as dopri5() for models with many states: with k4 the partial sums of rows 6, 7 and the error row
+      // are formed (k5 / k6 hold them from here on) and k2..k4 are dead; the same operations in the same order, bit for bit
+      double (&s6)[NX] = k5;
+      double (&s7)[NX] = k6;
+      double se[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        y[i] = axpy(h, lc4(a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]), x[i]);
+        s6[i] = lc4(a61, k1[i], a62, k2[i], a63, k3[i], a64, k4[i]);
+        s7[i] = lc4(b1, k1[i], b2, k2[i], b3, k3[i], b4, k4[i]);
+        se[i] = lc4(e1, k1[i], e2, k2[i], e3, k3[i], e4, k4[i]);
+      }
+      f(y, k2);  // k5
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        y[i] = axpy(h, __builtin_fma(a65, k2[i], s6[i]), x[i]);
+        s7[i] = __builtin_fma(b5, k2[i], s7[i]);
+        se[i] = __builtin_fma(e5, k2[i], se[i]);
+      }
+      f(y, k3);  // k6
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        y[i] = axpy(h, __builtin_fma(b6, k3[i], s7[i]), x[i]);
+        se[i] = __builtin_fma(e6, k3[i], se[i]);
+      }
+      f(y, kk);  // k7 at the 5th-order solution (FSAL)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) w[i] = h * __builtin_fma(e7, kk[i], se[i]);
+    } else {
 #pragma unroll
     for (int i = 0; i < NX; ++i) y[i] = axpy(h, lc4(a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]), x[i]);
     f(y, k5);
@@ -702,6 +732,7 @@ PCG_DEV int tsit5(const F& f, double (&x)[NX], int n, double dt, double rtol, do
 #pragma unroll
     for (int i = 0; i < NX; ++i)
       w[i] = h * lc7(e1, k1[i], e2, k2[i], e3, k3[i], e4, k4[i], e5, k5[i], e6, k6[i], e7, kk[i]);
+    }
     const double E2 = ms_scaled<NX>(w, x, y, n, rtol, atol);
     const bool ok = E2 < 1.0;
     double fac = (E2 == E2) ? fmax(0.2, ctrl_pow(E2, 0.9)) : 0.2;
