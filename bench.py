@@ -395,6 +395,8 @@ def main():
     ap.add_argument("--integrator", default=None, choices=["dopri5", "rodas4", "rodas3", "rk4", "cv8", "rk4g", "tsit5g"],
                     help="me10 / me20 / mixed: integrator of the extraction envs; four_tank / cstr_safe: the plan "
                          "(default: the workload's named one)")
+    ap.add_argument("--coop-thr", type=float, default=None,
+                    help="me10_ros4 / mixed: threshold of the cooperative rule of the Rodas4 plan (0 = off; default: the plan's)")
     args = ap.parse_args()
 
     import numpy as np
@@ -456,6 +458,8 @@ def main():
             segs_global[2][0]["integrator"] = args.integrator
             if args.integrator == "dopri5":
                 segs_global[2][0].update(rtol=1e-8, atol=1e-8)
+        if args.coop_thr is not None:
+            segs_global[2][0]["cooperative"] = {"thr": args.coop_thr} if args.coop_thr > 0 else False
         K = args.steps if args.steps is not None else 118
         W = args.warmup if args.warmup is not None else 12
         menv = make_mixed_sharded_env(segs_global, rank=rank, world=world, device=dev, seed=1234, auto_reset=True,
@@ -512,6 +516,9 @@ def main():
         if args.integrator and args.workload in ("four_tank", "cstr_safe"):
             params["integrator"] = args.integrator
             wl_name = wl_name.replace("cv8x1", args.integrator).replace("default-plan(tsit5g)", "plan(" + args.integrator + ")")
+        if args.coop_thr is not None and params.get("integrator") == "rodas4":
+            params["cooperative"] = {"thr": args.coop_thr} if args.coop_thr > 0 else False
+            wl_name += f"+coop{args.coop_thr:g}"
         B = args.batch or Bd
         K = args.steps if args.steps is not None else Kd
         W = args.warmup if args.warmup is not None else Wd

@@ -49,7 +49,7 @@ typedef unsigned long uintptr_t;
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 11
+#define PCG_ABI_VERSION 12
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -319,6 +319,15 @@ typedef struct pcg_env_cfg {
    * disturbance input that is NOT configured takes the env's own (possibly uncertain) parameter value, as the
    * reference's `self.model.info()["parameters"][k]` does (pcgym.py:400-404).  d_param_index names that parameter. */
   const int32_t* d_param_index; /* [ndm] or NULL: index in `params` of each model disturbance input                  */
+  /* PCG_INT_RODAS4 on a model with a cooperative rule (multistage_extraction with eq_exponent == 2): env steps whose
+   * predicted cost -- the model's fit of the pair's attempts per env step from the held input and the scaled size of
+   * f(x0), in exact arithmetic -- reaches coop_thr are integrated by SEULEX-8 (extrapolated linearly implicit Euler, fixed
+   * column of eight, same accuracy class: pcg_seulex.hpp) instead of the pair.  In the work-queue kernel eight lanes share
+   * such an env (one row of the extrapolation tableau each), elsewhere one lane runs the eight rows: the same bits either
+   * way.  A launch is as long as its heaviest env; this is what shortens it (the reference's CVODES integrates a stiff
+   * column at a cost that does not depend on its batch-mates, integrator.py:163-182).  0 = off (every env takes the pair);
+   * nsteps then counts big steps for the heavy envs.  PCG_E_UNSUPPORTED for other models / integrators when > 0. */
+  double coop_thr;
 } pcg_env_cfg;
 
 /*

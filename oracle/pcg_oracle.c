@@ -1242,6 +1242,164 @@ static int rodas4(const orc_model* m, double* x, const double* u, double dt, dou
   return status;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * SEULEX-8: extrapolated linearly implicit Euler with a fixed column of eight (Deuflhard's SEULEX without order
+ * selection) -- the integrator of the HEAVY envs of a PCG_INT_RODAS4 plan (cfg.coop_thr > 0), twin of seulex8_serial /
+ * seulex8_lanes in pc-gym_amd/csrc/pcg_seulex.hpp.  The reference's CVODES integrates a stiff column at a cost that does
+ * not depend on its batch-mates (integrator.py:163-182); on the GPU a launch is as long as its heaviest env, and this
+ * scheme is parallel over j by construction (the kernels give row j of the tableau to lane j of eight):
+ *   big step H from x:  for j = 0..7, n_j = j + 1:  theta_j = n_j (1 / H),  W_j = theta_j I - J(x)  (J frozen at x),
+ *       y = x;  n_j times:  d = W_j^-1 f(y),  y = y + d                                  -> T_j
+ *   Aitken-Neville in h:  for c = 1..7, rows j >= c (all rows of a column read the previous column):
+ *       T_j <- fma(T_j - T_{j-1}, (n_j - c) / c, T_j)
+ *   new state T_7 (order 8), error estimate T_7 - T_7' with T_7' the last row BEFORE the last column (order 7).
+ *   Error norm: as rodas4 (mean square, end-point weights), tolerances SX_TOL x the plan's; accept iff E2 < 1;
+ *   factor Q(SX_SAFETY E2^(-1/16)) in [SX_FACMIN, SX_FACMAX] (<= 1 after a rejection or a singular W_j).
+ *   First step: min(dt, Q(SX_H0 h_r4)) with h_r4 the first step of rodas4.
+ * ------------------------------------------------------------------------------------------------------------- */
+static double g_sx_tol = 4.0, g_sx_h0 = 8.0, g_sx_safety = 0.8, g_sx_facmax = 4.0, g_sx_facmin = 0.1;
+static int g_sx_ep = 1;
+ORC_EXPORT void orc_set_seulex(double tol, double h0, double safety, double facmax, double facmin, int ep) {
+  g_sx_tol = tol; g_sx_h0 = h0; g_sx_safety = safety; g_sx_facmax = facmax; g_sx_facmin = facmin; g_sx_ep = ep;
+}
+#define SX_K 8
+static int seulex8(const orc_model* m, double* x, const double* u, double dt, double rtol, double atol, int max_steps,
+                   double ep_frac, int ep_kmax, int32_t* nacc, int32_t* nrej) {
+  const int n = m->nx;
+  double T[SX_K][MAXNX], f[MAXNX], prev[MAXNX];
+  me_ros_fac F;
+  int acc = 0, rej = 0, status = 0;
+  const double rt = g_sx_tol * rtol, at = g_sx_tol * atol;
+  double H;
+  {
+    rhs_int(m, x, u, f);
+    double d0 = rms_scaled(x, x, x, n, rtol, atol);
+    double d1 = rms_scaled(f, x, x, n, rtol, atol);
+    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    H = fmin(qtrunc6(g_sx_h0 * (5.0 * h0)), dt);
+  }
+  const double ep_c = (ep_kmax > 0 && g_sx_ep) ? ep_frac * 1.4426950408889634 : 0.0;
+  double t = 0.0;
+  int rejected_last = 0;
+  for (;;) {
+    int last = 0;
+    if (acc + rej >= max_steps) { status = 1; break; }
+    if (t + H >= dt * (1.0 - 1e-14)) { H = dt - t; last = 1; }
+    const double ih = 1.0 / H;
+    int lu_ok = 1;
+    for (int j = 0; j < SX_K; ++j) {
+      const double theta = (double)(j + 1) * ih;
+      me_ros_factor(m->p, u, x, theta, &F);
+      lu_ok = lu_ok && F.ok;
+      double* y = T[j];
+      for (int i = 0; i < n; ++i) y[i] = x[i];
+      for (int s = 0; s <= j; ++s) {
+        rhs_int(m, y, u, f);
+        me_ros_solve(&F, f);
+        for (int i = 0; i < n; ++i) y[i] = y[i] + f[i];
+      }
+    }
+    for (int c = 1; c < SX_K; ++c) {
+      if (c == SX_K - 1)
+        for (int i = 0; i < n; ++i) prev[i] = T[SX_K - 1][i];
+      for (int j = SX_K - 1; j >= c; --j) {
+        const double w = (double)(j + 1 - c) / (double)c;
+        for (int i = 0; i < n; ++i) T[j][i] = fma(T[j][i] - T[j - 1][i], w, T[j][i]);
+      }
+    }
+    const double* r = T[SX_K - 1];
+    int kg[2];
+    ep_exponents(m, u, ep_c, ep_c > 0.0 ? ep_kmax : 0, dt - (t + H), kg);
+    const double sg[2] = {ldexp(1.0, -2 * kg[0]), ldexp(1.0, -2 * kg[1])};
+    double E2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+      double a0 = fabs(x[i]), a1 = fabs(r[i]);
+      double q = (r[i] - prev[i]) / (at + rt * (a0 > a1 ? a0 : a1));
+      E2 += (q * q) * sg[ep_group(m, i)];
+    }
+    E2 = E2 * (1.0 / n);
+    if (!lu_ok) E2 = NAN;
+    double fac = (E2 == E2) ? ((E2 == 0.0) ? g_sx_facmax : fmax(g_sx_facmin, qtrunc6(g_sx_safety * pow(E2, -1.0 / 16.0)))) : g_sx_facmin;
+    if (E2 < 1.0) {
+      fac = fmin(rejected_last ? 1.0 : g_sx_facmax, fac);
+      t += H;
+      H *= fac;
+      for (int i = 0; i < n; ++i) x[i] = r[i];
+      rejected_last = 0;
+      ++acc;
+      if (last) break;
+    } else {
+      fac = fmin(1.0, fac);
+      H *= fac;
+      rejected_last = 1;
+      ++rej;
+      if (!(H > 1e-13 * dt)) { status = 2; break; }
+    }
+  }
+  if (nacc) *nacc = acc;
+  if (nrej) *nrej = rej;
+  if (status != 0)
+    for (int i = 0; i < n; ++i) x[i] = NAN;
+  return status;
+}
+/* The cooperative rule of PCG_INT_RODAS4 plans (twin of MEImpl::coop_key, pcg_models.hpp): predicted attempts of the pair
+ * for this env step, in exact arithmetic -- piecewise-linear log2 by exponent extraction, IEEE operations. */
+static double plog2(double v) {
+  int e;
+  const double m = frexp(v, &e); /* [0.5, 1) */
+  return (double)(e - 1) + (2.0 * m - 1.0);
+}
+static int me_coop_model(const orc_model* m) { return m->model_id == PCG_MODEL_ME && m->p[4] == 2.0 && g_ros4_structured; }
+static double me_coop_key(const orc_model* m, const double* u, double d1) {
+  const double iVl = 1 / m->p[0], iVg = 1 / m->p[1];
+  const double a = u[0] * iVl, c = u[1] * iVg;
+  const double mn = fmin(a, c);
+  return ((-30.0 - 10.0 * plog2(mn)) + 3.6 / mn) + 4.0 * plog2(fmax(d1, 1.0));
+}
+/* the Rosenbrock plan on one env: SEULEX-8 where the rule picks the env, the pair elsewhere (twin of seulex8_if_heavy) */
+static int rodas4_plan(const orc_model* m, double* x, const double* u, double dt, double rtol, double atol, int max_steps,
+                       double ep_frac, int ep_kmax, double coop_thr, int32_t* nacc, int32_t* nrej) {
+  if (coop_thr > 0.0 && me_coop_model(m)) {
+    double f0[MAXNX];
+    rhs_int(m, x, u, f0);
+    const double d1 = rms_scaled(f0, x, x, m->nx, rtol, atol);
+    if (me_coop_key(m, u, d1) >= coop_thr) return seulex8(m, x, u, dt, rtol, atol, max_steps, ep_frac, ep_kmax, nacc, nrej);
+  }
+  return rodas4(m, x, u, dt, rtol, atol, max_steps, ep_frac, ep_kmax, nacc, nrej);
+}
+/* test hook: the rule's key for every env of a batch (x [nx][B], u [nu][B]) */
+ORC_EXPORT int orc_coop_key(const pcg_env_cfg* c, int64_t B, const double* x, const double* u, double* key) {
+  int nx = c->nx, nu = c->na + c->ndm;
+  orc_model m = {c->model_id, nx, nu, c->params};
+  if (!me_coop_model(&m)) return PCG_E_UNSUPPORTED;
+  for (int64_t b = 0; b < B; ++b) {
+    double xi[MAXNX], ui[PCG_MAX_NU], f0[MAXNX];
+    for (int i = 0; i < nx; ++i) xi[i] = x[(size_t)i * B + b];
+    for (int i = 0; i < nu; ++i) ui[i] = u[(size_t)i * B + b];
+    rhs_int(&m, xi, ui, f0);
+    key[b] = me_coop_key(&m, ui, rms_scaled(f0, xi, xi, nx, c->rtol, c->atol));
+  }
+  return 0;
+}
+
+/* calibration / test hook: SEULEX-8 for EVERY env of the batch (the plan's rule picks the heavy ones: coop_heavy()) */
+ORC_EXPORT int orc_seulex8(const pcg_env_cfg* c, int64_t B, double* x, const double* u, int32_t* nsteps) {
+  int nx = c->nx, nu = c->na + c->ndm;
+  if (c->model_id != PCG_MODEL_ME) return PCG_E_UNSUPPORTED;
+  orc_model m = {c->model_id, nx, nu, c->params};
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t b = 0; b < B; ++b) {
+    double xi[MAXNX], ui[PCG_MAX_NU];
+    int32_t na_ = 0, nr_ = 0;
+    for (int i = 0; i < nx; ++i) xi[i] = x[(size_t)i * B + b];
+    for (int i = 0; i < nu; ++i) ui[i] = u[(size_t)i * B + b];
+    seulex8(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, &na_, &nr_);
+    for (int i = 0; i < nx; ++i) x[(size_t)i * B + b] = xi[i];
+    if (nsteps) { nsteps[b] = na_; nsteps[B + b] = nr_; }
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Counter-based RNG: Philox4x32-10 (Salmon et al., SC'11; Random123 v1.09)   */
 /* ------------------------------------------------------------------------- */
@@ -1464,7 +1622,7 @@ static void env_step(const pcg_env_cfg* c, orc_env* e, const double* action_in, 
   else if (c->integrator_id == PCG_INT_TSIT5)
     ist = tsit5(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
   else if (c->integrator_id == PCG_INT_RODAS4)
-    ist = rodas4(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, &o->nacc, &o->nrej);
+    ist = rodas4_plan(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, c->coop_thr, &o->nacc, &o->nrej);
   else ist = dopri5(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
   if (ist == 0)
     for (int i = 0; i < nx; ++i)
@@ -1624,7 +1782,7 @@ ORC_EXPORT int orc_integrate(const pcg_env_cfg* c, int64_t B, double* x, const d
     else if (c->integrator_id == PCG_INT_CV8) cv8(&m, xi, ui, c->dt, c->substeps);
     else if (c->integrator_id == PCG_INT_TSIT5) tsit5(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, &na_, &nr_);
     else if (c->integrator_id == PCG_INT_RODAS4)
-      rodas4(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, &na_, &nr_);
+      rodas4_plan(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, c->coop_thr, &na_, &nr_);
     else dopri5(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, &na_, &nr_);
     for (int i = 0; i < nx; ++i) x[(size_t)i * B + b] = xi[i];
     if (nsteps) { nsteps[b] = na_; nsteps[B + b] = nr_; }

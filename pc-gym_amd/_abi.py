@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PCG_ABI_VERSION = 11
+PCG_ABI_VERSION = 12
 PCG_MAX_NX = 24
 PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
@@ -132,6 +132,7 @@ class pcg_env_cfg(C.Structure):
         ("ep_frac", C.c_double),
         ("ep_kmax", C.c_int32),
         ("d_param_index", _pi),
+        ("coop_thr", C.c_double),
     ]
 
 

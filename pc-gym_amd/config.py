@@ -11,6 +11,9 @@ New optional keys (do not exist in the reference):
                see DEFAULT_INTEGRATOR; integration_method='jax' -> 'tsit5', the reference's own method, integrator.py:56-61)
   endpoint_control  rodas4 only: {'frac': 0.5, 'kmax': 10} | False -- end-point error control (pcgym_hip.h,
                PCG_INT_RODAS4); on by default, acts only on models with a contraction-rate hook (extraction cascades)
+  cooperative  rodas4 on multistage_extraction with eq_exponent == 2 only: {'thr': 48} | False -- env steps whose predicted
+               cost (attempts of the pair, a per-env rule) reaches thr take SEULEX-8, eight lanes per env in the work-queue
+               kernel (pcgym_hip.h: coop_thr; pcg_seulex.hpp); on by default where it applies
   substeps     RK4 sub-steps per env step
   rtol, atol   DOPRI5 tolerances (default 1e-8, integrator.py:61)
   max_steps    DOPRI5 step budget per env step
@@ -90,6 +93,7 @@ DEFAULT_TOL = {M.CSTR: 1e-10}
 # of the extraction cascade within 1e-6 of a 1e-13 solve over its whole action box (worst lanes: low liquid flow, high
 # gas flow -- 6.5e-7 at 3e-8; tests/test_rodas4.py), the class of the explicit pair at 1e-8 (5.5e-7)
 ROS4_TOL = {M.ME: 3e-8}
+DEFAULT_COOP_THR = 48.0  # cooperative rule of rodas4 plans: predicted attempts from which an env step takes SEULEX-8 (pcg_seulex.hpp)
 ROS4_DT_CAL = 1.0  # the env step (model time units) ROS4_TOL was calibrated at; larger steps tighten it (EnvSpec)
 
 
@@ -885,6 +889,23 @@ class EnvSpec:
             self.ep_frac, self.ep_kmax = float(epc.get("frac", 0.5)), int(epc.get("kmax", 10))
             if not (0.0 <= self.ep_frac <= 1.0) or not (0 <= self.ep_kmax <= 40):
                 raise ValueError("endpoint_control: frac must lie in [0, 1] and kmax in [0, 40]")
+        # cooperative rule: where the kernels carry it (the 10-state cascade with eq_exponent == 2 through the structured
+        # Rosenbrock path, registry parameters or not) it is on; asking for it elsewhere is an error, not a silent no-op
+        coop = p.get("cooperative", None)
+        pv = self.model.param_vector()
+        coop_ok = (self.integrator == "rodas4" and self.model.model_id == M.ME and self.nunc == 0
+                   and getattr(self, "user_rhs_src", None) is None and len(pv) > 4 and float(pv[4]) == 2.0)
+        self.coop_thr = 0.0
+        if coop is None or coop is True:
+            if coop is True and not coop_ok:
+                raise ValueError("cooperative: needs integrator 'rodas4' on multistage_extraction with eq_exponent == 2")
+            self.coop_thr = DEFAULT_COOP_THR if coop_ok else 0.0
+        elif coop is not False:
+            if not coop_ok:
+                raise ValueError("cooperative: needs integrator 'rodas4' on multistage_extraction with eq_exponent == 2")
+            self.coop_thr = float(dict(coop).get("thr", DEFAULT_COOP_THR))
+            if not (self.coop_thr > 0.0 and np.isfinite(self.coop_thr)):
+                raise ValueError("cooperative: thr must be a positive finite number")
         d_sub = default_substeps(self.model.model_id, self.dt)
         if self.integrator == "rk4g":  # the guard's calibration: 5 sub-steps per canonical dt = 26/60 (h <= 0.0867)
             d_sub = max(1, int(np.ceil(self.dt / (26.0 / 60.0 / 5) - 1e-9)))
@@ -1071,6 +1092,7 @@ class EnvSpec:
                              "rodas4": abi.PCG_INT_RODAS4, "tsit5": abi.PCG_INT_TSIT5, "rk4g": abi.PCG_INT_RK4G,
                              "tsit5g": abi.PCG_INT_T5G, "cv8": abi.PCG_INT_CV8}[self.integrator]
         cfg.ep_frac, cfg.ep_kmax = self.ep_frac, self.ep_kmax
+        cfg.coop_thr = self.coop_thr
         cfg.nx, cfg.na, cfg.ndm, cfg.nd = self.nx, self.na, self.ndm, self.nd
         cfg.nsp, cfg.ncon, cfg.nrew, cfg.N = self.nsp, self.ncon, self.nrew, self.N
         cfg.nsp_obs = self.nsp_obs

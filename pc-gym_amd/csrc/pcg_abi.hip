@@ -196,6 +196,7 @@ void pcg_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 }
 
 // Validates cfg and fills the host DevConst.  No HIP calls: unit-testable without a GPU.
+static int kernel_id_for(const pcg_env_cfg* c);
 static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   if (!c || !d) return PCG_E_NULL;
   if (c->model_id < 0 || c->model_id >= PCG_MODEL_COUNT) return PCG_E_MODEL;
@@ -428,6 +429,13 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
     if (c->nunc > 0) return PCG_E_UNSUPPORTED;
     d->ep_kmax = c->ep_kmax;
     d->ep_c = c->ep_kmax > 0 ? c->ep_frac * 1.4426950408889634 : 0.0;
+  }
+  // cooperative rule (pcgym_hip.h: coop_thr): only where the model's kernels carry it
+  d->coop_thr = 0.0;
+  if (c->coop_thr != 0.0) {
+    if (!(c->coop_thr > 0.0) || !std::isfinite(c->coop_thr)) return PCG_E_VALUE;
+    if (c->integrator_id != PCG_INT_RODAS4 || user || !c->params || !kernels(kernel_id_for(c)).coop) return PCG_E_UNSUPPORTED;
+    d->coop_thr = c->coop_thr;
   }
   d->atol = c->atol;
   d->nx = nx; d->na = na; d->ndm = ndm; d->nd = nd; d->nsp = nsp; d->nsp_obs = nso; d->ncon = ncon; d->nrew = nrew;

@@ -1209,11 +1209,12 @@ PCG_DEV double rodas4_factor(double E2, bool ok, bool rejected_last) {
 // transient of a freshly changed input needs h ~ 2-3 h0 -- against 0.5 out of 19.6 here, same worst-case error.)
 template <int NX>
 PCG_DEV double rodas4_h_init(const double (&x)[NX], const double (&f0)[NX], int n, double dt, double rtol, double atol,
-                             double& d1_out) {
+                             double& d1_out, double* d0_out = nullptr) {
 #pragma clang fp contract(off)
   const double d0 = rms_scaled<NX>(x, x, x, n, rtol, atol);
   const double d1 = rms_scaled<NX>(f0, x, x, n, rtol, atol);
   d1_out = d1;
+  if (d0_out) *d0_out = d0;
   const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
   return fmin(qtrunc6(5.0 * h0), dt);
 }
@@ -1270,3 +1271,5 @@ PCG_DEV int rodas4(const F& f, const LS& ls, const EP& ep, double (&x)[NX], int 
 }
 
 }  // namespace pcg
+
+#include "pcg_seulex.hpp"

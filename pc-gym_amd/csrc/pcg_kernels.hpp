@@ -125,6 +125,8 @@ struct DevConst {
   // PCG_INT_RODAS4 end-point error control: ep_c = ep_frac log2(e) (0 when off), largest tolerance exponent
   double ep_c;
   int32_t ep_kmax;
+  // ... heavy envs (M::coop_key >= coop_thr) take SEULEX-8 instead of the pair (pcg_seulex.hpp); 0 = off
+  double coop_thr;
 };
 
 using CDevConst = const PCG_CONSTANT DevConst;
@@ -547,8 +549,10 @@ PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const do
     int nacc = 0, nrej = 0;
     const EpWeights<M, K> ep{kp, u, c.ep_c, c.ep_kmax};
     if constexpr (ros_structured<M>::value) {
-      const RosStructured<M, K> ls{kp, hold, {}};
-      status = rodas4<NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+      if (!seulex8_if_heavy<M>(kp, hold, u, f, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, c.coop_thr, nacc, nrej, status)) {
+        const RosStructured<M, K> ls{kp, hold, {}};
+        status = rodas4<NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+      }
     } else {
       const RosLds<NX> Lm(stage_l);
       const RosDense<NX, RhsFn<M, double, K>> ls{f, Lm, nx, c.rtol, c.atol};
@@ -1690,8 +1694,10 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX, ros_structured<M>::val
     int nacc = 0, nrej = 0, status;
     const EpWeights<M, typename M::CKP> ep{kp, u, c.ep_c, c.ep_kmax};
     if constexpr (ros_structured<M>::value) {
-      const RosStructured<M, typename M::CKP> ls{kp, hold, {}};
-      status = rodas4<NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+      if (!seulex8_if_heavy<M>(kp, hold, u, f, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, c.coop_thr, nacc, nrej, status)) {
+        const RosStructured<M, typename M::CKP> ls{kp, hold, {}};
+        status = rodas4<NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+      }
     } else {
       const RosLds<NX> Lm(lds);
       const RosDense<NX, RhsFn<M>> ls{f, Lm, nx, c.rtol, c.atol};
@@ -1764,6 +1770,7 @@ struct Kernels {
   StepFn queue_r4[2];                // Rodas4 through the same work queue [per_env_t] (models with structured W only)
   StepFn queue_r4w1[2];              // ... compiled for ONE workgroup per CU (no register spills in the loop)
   bool ros_structured;               // Rodas4 runs in registers (launch shape of the explicit adaptive pair)
+  bool coop;                         // ... and the model has a cooperative rule (cfg.coop_thr, pcg_seulex.hpp)
   bool queue_default;                // route adaptive plans to it unless told otherwise (models with a cost key)
   size_t (*queue_lds)(int);          // LDS bytes of a tile of T slots
   size_t (*queue_lds_x)(int);        // ... with the tile's state parked in LDS as well
@@ -1807,6 +1814,7 @@ Kernels make_kernels() {
   k.step[PCG_INT_RODAS4][1][0][0] = k.step[PCG_INT_RODAS4][1][0][1] = step_kernel<M, PCG_INT_RODAS4, true, false, true>;
   k.integ[PCG_INT_RODAS4][0] = integrate_kernel<M, PCG_INT_RODAS4, false>;
   k.ros_structured = ros_structured<M>::value;
+  k.coop = ros_structured<M>::value && has_coop<M>::value;
   // guarded RK4 (models with a guard hook): general kernel, integration hook, fused rollout
   if constexpr (has_guard<M>::value) {
     k.step[PCG_INT_RK4G][0][0][0] = k.step[PCG_INT_RK4G][0][0][1] = step_kernel<M, PCG_INT_RK4G, false, false, true>;

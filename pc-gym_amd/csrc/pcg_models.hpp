@@ -44,6 +44,16 @@ PCG_DEV int ep_ilog2(double v) {
   return (v >= 1.0) ? (int)((__double_as_longlong(v) >> 52) & 0x7FF) - 1023 : 0;
 }
 
+// piecewise-linear log2 of a positive normal number: exponent + (mantissa - 1), mantissa in [1, 2).  Exponent extraction,
+// one exact subtraction and one addition: the oracle's frexp() twin gives the same bits (the cooperative rule of
+// PCG_INT_RODAS4 plans, M::coop_key, must pick the same envs on both sides)
+PCG_DEV double plog2(double v) {
+  const long long b = __double_as_longlong(v);
+  const int e = (int)((b >> 52) & 0x7FF) - 1023;
+  const double m = __longlong_as_double((b & 0x000FFFFFFFFFFFFFLL) | 0x3FF0000000000000LL);
+  return (double)e + (m - 1.0);
+}
+
 // ---------------------------------------------------------------------------
 // cstr -- model_classes.py:23-62.  raw = q,V,rho,C,deltaHr,EA_over_R,k0,UA,Ti,Caf
 // u = [Tc | Ti, Caf]
@@ -191,8 +201,15 @@ constexpr int PCG_KID_ME_SQ = PCG_MODEL_COUNT, PCG_KID_ME_REACTIVE_SQ = PCG_MODE
 // multistage_extraction -- model_classes.py:346-430.  raw = Vl,Vg,m,Kla,eq_exponent,X0,Y6
 // u = [L, G | X0, Y6];  x = X1,Y1,...,X5,Y5
 // ---------------------------------------------------------------------------
+// the cooperative phase of PCG_INT_RODAS4 plans (pcg_seulex.hpp) is calibrated for the eq_exponent == 2 cascade only
 template <bool SQ>
-struct MEImpl {
+struct MECoop {};
+template <>
+struct MECoop<true> {
+  static constexpr bool COOP = true;
+};
+template <bool SQ>
+struct MEImpl : MECoop<SQ> {
   static constexpr int NX = 10, NA = 2, NDM = 2, NRAW = 7;
   static constexpr bool DYNAMIC = false;
   static constexpr bool FULL = true;  // all kernel specialisations
@@ -267,6 +284,18 @@ struct MEImpl {
     const float a = (float)(u[0] * k.iVl), c = (float)(u[1] * k.iVg);
     const float mn = __builtin_fminf(a, c), mx = __builtin_fmaxf(a, c);
     return 40.0f - 8.65f * __builtin_logf(mn) + 1.95f * __builtin_logf(mx) + 56.3f / mn;
+  }
+  // The cooperative rule (pcg_seulex.hpp): predicted attempts of the Rosenbrock pair for this env step, from the slower
+  // through-flow rate mn and the scaled size d1 of f(x0) -- a least-squares fit over the action box of BASELINE configs[2]
+  // (tools/prototypes/seulex8_calib.py: correlation 0.90 with the measured attempts; at the default threshold 48 it picks 7 %
+  // of the envs, none below 25 attempts, and leaves none above 55), in EXACT arithmetic: IEEE operations and exponent
+  // extraction only, so that the kernels and the oracle pick the same envs.  Twin: me_coop_key() in oracle/pcg_oracle.c.
+  template <class K>
+  PCG_DEV static double coop_key(const K& k, const double (&u)[NA + NDM], double d1) {
+#pragma clang fp contract(off)
+    const double a = u[0] * k.iVl, c = u[1] * k.iVg;
+    const double mn = __builtin_fmin(a, c);
+    return ((-30.0 - 10.0 * plog2(mn)) + 3.6 / mn) + 4.0 * plog2(__builtin_fmax(d1, 1.0));
   }
   // W = theta I - J, analytic, eliminated in the natural order (X1,Y1,...,X5,Y5) without pivoting.  Rows:
   //   X_s:  DX X_s - alpha X_{s-1} - cx_s Y_s            alpha = L/Vl, Kla' = Kla, cx_s = Kla q_s, q_s = d(Y^e/m)/dY

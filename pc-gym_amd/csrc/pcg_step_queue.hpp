@@ -238,7 +238,7 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
                                                           int32_t* flag, int32_t* next, int T, int n, int refill, double dt, double dt_edge,
                                                           double h_floor, double rtol, double atol, int max_steps,
                                                           double ep_c = 0.0, int ep_kmax = 0, int prio_h = 0, int rot = 0,
-                                                          unsigned long long* qst = nullptr, const int32_t* eidx = nullptr) {
+                                                          unsigned long long* qst = nullptr, const int32_t* eidx = nullptr, int first = 0) {
   constexpr int NX = M::NX, NU = M::NA + M::NDM;
   // COMPACT (fix-up launch of a guarded plan): the slots are a compact list of marked envs, eidx[slot] is the env's position
   // in the state window xg; otherwise a slot is its own position
@@ -254,11 +254,13 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
   typename QLaneSel<NX, INTEG>::type L;
   // sorted position of the lane's current env (the sort is by decreasing cost: small = heavy).  `rot` shifts which wave
   // starts with the heaviest 64: two workgroups that share a CU put them on different SIMDs (see q_prio)
-  int pos = (tid + rot) & (QB - 1);
+  // first > 0: the first `first` sorted slots are the tile's heavy envs, integrated by the cooperative phase (coop_integrate);
+  // its waves arrive here late and at different times, so nothing is handed out directly: every lane starts idle and pops
+  int pos = first > 0 ? n : ((tid + rot) & (QB - 1));
   int slot = pos < n ? (int)(sortbuf[pos] & (QSORT - 1)) : -1;  // QSORT - 1 == the QSLOT_BITS mask
   bool fresh = slot >= 0;
   bool wave_hi = false;
-  bool drained = n <= QB;  // wave-uniform: the queue has nothing (left) for this wave
+  bool drained = first > 0 ? n <= first : n <= QB;  // wave-uniform: the queue has nothing (left) for this wave
   // every spin is bounded: a lane integrates at most two envs' worth of its tile share plus the refill rounds; the
   // bound is never reached by a correct run (max_steps bounds each env) and turns a logic error into a flagged
   // PCG_ST_MAX_STEPS result instead of a hung GPU
@@ -375,6 +377,87 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
 #endif
 }
 
+// ---- phase 2a: the cooperative phase of a Rodas4 tile (pcg_seulex.hpp).  The tile's heavy envs (the first nh sorted slots)
+// are integrated by SEULEX-8 with EIGHT LANES PER ENV: a wave carries eight envs, one per group of eight lanes, one big step
+// of every busy group per loop iteration; a group that finishes its env pops the next heavy one (one LDS atomic per wave and
+// iteration with an idle group, heaviest first).  A wave leaves when the heavy queue is empty and its groups are done, and
+// joins the pair's queue (queue_integrate).  The env's state and step size are replicated over its group's lanes.
+template <class M, int QB, bool XL = false>
+PCG_DEV void coop_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, const double* us, const double* hs,
+                            const uint32_t* sortbuf, int32_t* accs, int32_t* rejs, int32_t* flag, int32_t* cnext, int T, int nh,
+                            double dt, double dt_edge, double h_floor, double rtol, double atol, int max_steps, double ep_c,
+                            int ep_kmax) {
+  constexpr int NX = M::NX, NU = M::NA + M::NDM;
+  typename M::CKP& kp = *kpp;
+  const int lane = threadIdx.x & 63, j = lane & 7;
+  const unsigned long long below = (1ull << (lane & ~7)) - 1ull;  // the lanes of the groups before this one
+  double w[sx::K - 1];
+#pragma unroll
+  for (int c = 1; c < sx::K; ++c) w[c - 1] = seulex_w(j, c);
+  SxGroup<NX> G;
+  int slot = -1;
+  bool drained = false;  // wave-uniform
+  // bounded like the pair's queue: max_steps bounds each env, a wave carries at most nh envs one after the other
+  const long long cap64 = ((long long)max_steps + 4) * ((long long)nh + 1);
+  const int iter_cap = cap64 > 0x7fffff00LL ? 0x7fffff00 : (int)cap64;
+  for (int iter = 0;; ++iter) {
+    if (iter > iter_cap) {
+      if (slot >= 0 && j == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + slot] = __builtin_nan("");
+        accs[slot] = G.acc;
+        rejs[slot] = G.rej;
+        flag[slot] |= PCG_ST_MAX_STEPS;
+      }
+      break;
+    }
+    const unsigned long long idle = __ballot(slot < 0) & 0x0101010101010101ull;  // one bit per idle group
+    if (!drained && idle != 0ull) {
+      const int n_idle = __popcll(idle);
+      int got = 0;
+      if (lane == __ffsll((long long)idle) - 1) got = atomicAdd(cnext, n_idle);
+      got = __shfl(got, __ffsll((long long)idle) - 1);
+      drained = got + n_idle >= nh;
+      if (slot < 0) {
+        const int q = got + __popcll(idle & below);
+        if (q < nh) {  // pick up: state from the tile (LDS or the batch), first big step from the slot
+          slot = (int)(sortbuf[q] & (QSORT - 1));
+#pragma unroll
+          for (int i = 0; i < NX; ++i) G.x[i] = xg[(size_t)i * xstride + slot];
+          G.H = hs[slot];
+          G.t = 0.0;
+          G.acc = G.rej = 0;
+          G.rejected_last = false;
+        }
+      }
+    }
+    if (__ballot(slot >= 0) == 0ull) {
+      if (drained) break;
+      continue;
+    }
+    if (slot >= 0) {
+      double u[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) u[i] = us[(size_t)i * T + slot];
+      const typename M::Hold hold = M::hold(kp, u);
+      const RhsFn<M> f{kp, hold};
+      const EpWeights<M, typename M::CKP> ep{kp, u, ep_c, ep_kmax};
+      const int st = seulex8_attempt_lanes<M>(kp, hold, f, ep, G, j, w, NX, dt, dt_edge, h_floor, rtol, atol, max_steps);
+      if (st >= 0) {  // finished (or gave up): lane 0 of the group parks the result, the group is free
+        poison_if_failed<NX>(st, G.x);
+        if (j == 0) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + slot] = G.x[i];
+          accs[slot] = G.acc;
+          rejs[slot] = G.rej;
+          flag[slot] |= st;
+        }
+        slot = -1;
+      }
+    }
+  }
+}
+
 // ---- the tile's sort: bitonic network over S = E * QB packed words (QB threads), DESCENDING, E words per thread in registers ----
 // Element i = tid * E + r.  A compare-exchange at distance j pairs i with i ^ j:
 //   j < E          both in the same thread's registers: no data movement
@@ -474,6 +557,10 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
   int32_t* flag = rejs + T;   // bits 0-1: PCG_ST_* of the integration, bit 2: pre-step "done"
   int32_t* next = flag + T;   // queue head (the first min(n, 256) sorted slots are handed out directly)
   int32_t* nq = next + 1;     // fix-up launch: number of marked envs parked in this round
+  int32_t* nheavy = next + 2; // cooperative rule (Rodas4): heavy envs of the tile = its first sorted slots ...
+  int32_t* cnext = next + 3;  // ... and the head of their queue
+  constexpr bool COOP = INTEG == PCG_INT_RODAS4 && has_coop<M>::value && !FIX;
+  const bool coop = COOP && c.coop_thr > 0.0;
   const bool xlds = (A.q_tile & 0x20000) != 0;  // the tile's state lives in LDS (host: it fits)
   double* xs = reinterpret_cast<double*>(next + 4 + (T & 1));  // [NX][T] when xlds (8-byte aligned)
   int32_t* eidx = reinterpret_cast<int32_t*>(xs);  // fix-up launch: env (relative to the workgroup's range) of a compact slot
@@ -505,6 +592,11 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
   for (int isub = 0; fix ? scan < hi : isub < nsub; ++isub) {
     const int64_t base = fix ? lo : lo + (int64_t)isub * sub;
     PCG_QS(0);
+    if constexpr (COOP) {
+      if (tid == 0) *nheavy = 0, *cnext = 0;
+      __syncthreads();
+    }
+    int my_heavy = 0;
     // ---------------- phase 1: load, pre-integration half, park in LDS ----------------
     // one slot: the env's pre-integration half, its held input, initial step size and flags parked at slot s; returns the
     // slot's sort word
@@ -521,9 +613,18 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
       const RhsFn<M> f{kp, hold};
       double k1[NX];
       double d1, h;
+      bool heavy = false;
       if constexpr (INTEG == PCG_INT_RODAS4) {
         f(x, k1);
-        h = rodas4_h_init<NX>(x, k1, NX, dt, rtol, atol, d1);
+        double d0;
+        h = rodas4_h_init<NX>(x, k1, NX, dt, rtol, atol, d1, &d0);
+        if constexpr (COOP) {  // the cooperative rule (the statements of seulex8_if_heavy): SEULEX-8's first big step instead
+          if (coop && M::coop_key(kp, pre.u, d1) >= c.coop_thr) {
+            heavy = true;
+            h = seulex_h_init(d0, d1, dt);
+            ++my_heavy;
+          }
+        }
       } else {
         h = dopri5_h_init<NX>(f, x, k1, NX, dt, rtol, atol, d1);
       }
@@ -546,7 +647,8 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
         key = (float)(M::cost_key(kp, pre.u) * dt) + A.q_w * __builtin_logf(__builtin_fmaxf((float)d1, 1.0f));
       else key = (float)(dt / h);  // generic proxy: steps at the initial step size
       key = nosort ? 1.0f : __builtin_fmaxf(key, 1e-30f);
-      return ((__float_as_uint(key) >> QSLOT_BITS) << QSLOT_BITS) | (uint32_t)s;  // positive floats order like their bit patterns
+      // positive floats order like their bit patterns; the sign bit is free: heavy envs sort in front of all others
+      return ((__float_as_uint(key) >> QSLOT_BITS) << QSLOT_BITS) | (uint32_t)s | (heavy ? 0x80000000u : 0u);
     };
     int n, S;
     if (fix) {
@@ -579,8 +681,13 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
       for (int s = tid; s < S; s += QB) sortbuf[s] = s < n ? park(s, base + s) : (uint32_t)s;
     }
     PCG_QS(1);
+    if constexpr (COOP) {
+      if (my_heavy > 0) atomicAdd(nheavy, my_heavy);
+    }
     __syncthreads();
-    if (tid == 0) *next = QB < n ? QB : n;  // (ordered before phase 2 by the sort's barriers)
+    // (ordered before phase 2 by the sort's barriers).  With heavy envs in the tile the pair's queue starts behind them and
+    // hands nothing out directly (queue_integrate)
+    if (tid == 0) *next = (COOP && *nheavy > 0) ? *nheavy : (QB < n ? QB : n);
     // ---------------- sort the slots by decreasing cost key ----------------
     if (S == QSORT / 4) sort_tile<QSORT / 4 / QB, QB>(sortbuf);
     else if (S == QSORT / 2) sort_tile<QSORT / 2 / QB, QB>(sortbuf);
@@ -599,8 +706,18 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
     // wave -- is worth batching (configs[4] shard: 0.916 ms at 8, 0.929 at 2; profiles/r2/queue_refill_sweep.txt)
     const int refill = refill_hi ? refill_hi : (n <= 2 * QB ? 2 : QREFILL);
     PCG_QS(2);
+    int nh = 0;
+    if constexpr (COOP) {
+      nh = *nheavy;  // (uniform; written before the sort's barriers)
+      if (nh > 0) {
+        if (A.q_prio > 0) __builtin_amdgcn_s_setprio(3);  // the heavy envs are the launch's critical path
+        coop_integrate<M, QB>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, cnext, T, nh, dt,
+                              c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax);
+        if (A.q_prio > 0) __builtin_amdgcn_s_setprio(0);
+      }
+    }
     queue_integrate<M, INTEG, QB, FIX>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, A.q_prio,
-                              (A.q_prio > 0 && blockIdx.x >= gridDim.x / 2) ? 2 * 64 : 0, qst, fix ? eidx : nullptr);
+                              (A.q_prio > 0 && blockIdx.x >= gridDim.x / 2) ? 2 * 64 : 0, qst, fix ? eidx : nullptr, nh);
     if (A.q_prio > 0) __builtin_amdgcn_s_setprio(0);
     PCG_QS(3);
     __syncthreads();

@@ -1,0 +1,160 @@
+"""CPU: SEULEX-8 of the oracle (oracle/pcg_oracle.c: seulex8) and the cooperative rule of PCG_INT_RODAS4 plans -- pinned
+before they are trusted as the checker of the HIP kernels (tests/test_gpu_seulex.py).
+
+  * the Aitken-Neville weights turn linearly implicit Euler into an order-8 scheme: on y' = lambda y one big step of the
+    tableau reproduces the [row 8] rational approximation of exp(z) built independently here, and its error falls as z^9;
+  * the integrator reaches the LSODA(1e-13) answers on the reference RHS (tests/golden/tight_*.npz) and converges (1000 x
+    tighter tolerance: <= 3 x the big steps, >= 100 x less error: order 8 against the pair's 4);
+  * over the action box of BASELINE configs[2] the rule picks the envs the pair finds heavy (none it crosses in < 20
+    attempts, none above 60 left to it), SEULEX-8 crosses them in <= 15 big steps within the accuracy class (<= 1e-6 of
+    a 1e-13 solve), and the plan `integrator: 'rodas4'` = SEULEX-8 on the picked envs, the pair on the others;
+  * the rule's key is exact arithmetic: the oracle's value equals a NumPy restatement bit for bit;
+  * configuration errors are loud.
+"""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as H
+import scenarios as SC
+from oracle import oracle as O
+from pcgym_amd import models as M
+from pcgym_amd.config import DEFAULT_COOP_THR, EnvSpec
+from test_oracle_golden import _spec_for_integration
+from test_rodas4 import _me_box
+
+
+def _seulex_all(spec, x, u):
+    """SEULEX-8 for every env of the batch (the oracle's calibration / test hook)"""
+    cfg, keep = spec.to_cfg()
+    x = np.ascontiguousarray(x, dtype=np.float64).copy()
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    ns = np.zeros((2, x.shape[1]), dtype=np.int32)
+    fn = O.lib().orc_seulex8
+    fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert fn(C.byref(cfg), x.shape[1], O._p(x), O._p(u), O._p(ns)) == 0
+    return x, ns
+
+
+def _keys(spec, x, u):
+    cfg, keep = spec.to_cfg()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    key = np.zeros(x.shape[1])
+    fn = O.lib().orc_coop_key
+    fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert fn(C.byref(cfg), x.shape[1], O._p(x), O._p(u), O._p(key)) == 0
+    return key
+
+
+def test_tableau_is_order_eight_on_the_linear_test_equation():
+    """y' = lambda y, one big step H, z = lambda H: row j of linearly implicit Euler is (1 - z / n_j)^-n_j, and the
+    Aitken-Neville weights (n_j - c) / c of the harmonic sequence must cancel the error terms z^2 ... z^8."""
+    from decimal import Decimal, getcontext
+    from fractions import Fraction
+
+    getcontext().prec = 60
+
+    def tableau(z):  # exact rational arithmetic: the order is visible far below double round-off
+        T = [(1 - z / n) ** (-n) for n in range(1, 9)]
+        for c in range(1, 8):
+            for j in range(7, c - 1, -1):
+                T[j] = T[j] + (T[j] - T[j - 1]) * Fraction(j + 1 - c, c)
+        return T[7]
+
+    def err(z):
+        t = tableau(z)
+        return abs(Decimal(t.numerator) / Decimal(t.denominator) - (Decimal(z.numerator) / Decimal(z.denominator)).exp())
+
+    errs = [err(Fraction(-1, d)) for d in (10, 20, 40, 80)]
+    ratios = [a / b for a, b in zip(errs, errs[1:])]
+    assert all(2 ** 8.5 <= r <= 2 ** 9 for r in ratios) and ratios[0] < ratios[1] < ratios[2], ratios  # error -> C z^9
+    assert abs(tableau(Fraction(-1000))) <= Fraction(1, 1000)  # stiff limit: every row is strongly damped
+
+
+@pytest.mark.parametrize("fix", ["multistage_extraction", "multistage_extraction_d"])
+def test_seulex8_reaches_true_solution_and_converges(fix):
+    g = H.gold("tight_" + fix)
+    dt, nu = float(g["dt"]), g["u"].shape[1]
+    scale = np.maximum(np.abs(g["xf"]), 1e-6 * np.max(np.abs(g["xf"]), axis=0, keepdims=True))
+    res = []
+    for tol in (1e-6, 1e-9):
+        s = _spec_for_integration("multistage_extraction", dt, nu, integrator="rodas4", rtol=tol, atol=tol * 1e-2,
+                                  endpoint_control=False)
+        xf, ns = _seulex_all(s, g["x"].T, g["u"].T)
+        assert np.isfinite(xf).all()
+        res.append((np.max(np.abs(xf.T - g["xf"]) / scale), ns.sum(axis=0).mean()))
+    assert res[0][0] <= 1e-4 and res[1][0] <= 2e-8, res
+    assert res[1][0] <= 0.01 * res[0][0] + 1e-10 and res[1][1] <= 3.0 * res[0][1], res
+
+
+def test_rule_picks_the_heavy_envs_and_seulex8_crosses_them_in_class():
+    spec, cases, refs = _me_box(3000, 5)
+    s4 = spec(integrator="rodas4")
+    assert s4.coop_thr == DEFAULT_COOP_THR == 48.0
+    s4p = spec(integrator="rodas4", cooperative=False)
+    assert s4p.coop_thr == 0.0
+    picked_n = 0
+    for (xx, uu), ref in zip(cases, refs):
+        key = _keys(s4, xx, uu)
+        heavy = key >= s4.coop_thr
+        picked_n += int(heavy.sum())
+        y_pair, ns_pair = O.integrate(s4p, xx, uu)
+        att = ns_pair.sum(0)
+        assert att[heavy].min() >= 20, att[heavy].min()            # nothing cheap is picked
+        assert att[~heavy].max() <= 60, att[~heavy].max()          # nothing heavy is left to the pair
+        y_sx, ns_sx = _seulex_all(s4, xx[:, heavy], uu[:, heavy])
+        assert ns_sx.sum(0).max() <= 15, ns_sx.sum(0).max()
+        err = np.max(np.abs(y_sx - ref[:, heavy]) / np.abs(ref[:, heavy]), axis=0)
+        assert err.max() <= 1e-6, err.max()
+        # the plan: SEULEX-8 on the picked envs, the pair on the others -- the same bits as either alone
+        y, ns = O.integrate(s4, xx, uu)
+        assert np.array_equal(y[:, heavy], y_sx) and np.array_equal(ns[:, heavy], ns_sx)
+        assert np.array_equal(y[:, ~heavy], y_pair[:, ~heavy]) and np.array_equal(ns[:, ~heavy], ns_pair[:, ~heavy])
+        assert np.max(np.abs(y - ref) / np.abs(ref)) <= 1e-6
+        # the chain the launch waits for: the heaviest env of the plan against the heaviest of the pair alone
+        assert ns.sum(0).max() <= 60 and att.max() >= 70, (ns.sum(0).max(), att.max())
+    assert 0.03 * 6000 <= picked_n <= 0.15 * 6000, picked_n
+
+
+def test_coop_key_is_exact_arithmetic():
+    spec, cases, _ = _me_box(500, 9)
+    s4 = spec(integrator="rodas4")
+    xx, uu = cases[1]
+    key = _keys(s4, xx, uu)
+    p = np.array(s4.model.param_vector())
+    u4 = np.concatenate([uu, np.tile(p[5:7][:, None], (1, uu.shape[1]))]) if uu.shape[0] == 2 else uu
+    f0 = O.rhs(s4.model.model_id, p, xx, u4)
+    # the integrators evaluate the kernel-order twin of the right-hand side (eq_exponent == 2): d1 to a few ulp only
+    d1 = np.sqrt(np.mean((f0 / (s4.atol + s4.rtol * np.abs(xx))) ** 2, axis=0))
+
+    def plog2(v):
+        m, e = np.frexp(v)
+        return (e - 1) + (2.0 * m - 1.0)
+
+    mn = np.minimum(uu[0] / p[0], uu[1] / p[1])
+    want = ((-30.0 - 10.0 * plog2(mn)) + 3.6 / mn) + 4.0 * plog2(np.maximum(d1, 1.0))
+    assert np.max(np.abs(key - want)) <= 1e-9 and key.min() < 20 and key.max() > 60
+
+
+def test_cooperative_validation():
+    P = copy.deepcopy(SC.scenarios()["me_canonical"]["env_params"])
+    P.update(integrator="rodas4", cooperative={"thr": -1.0})
+    with pytest.raises(ValueError, match="cooperative"):
+        EnvSpec(P)
+    P.update(cooperative={"thr": 55})
+    s = EnvSpec(P)
+    cfg, _ = s.to_cfg()
+    assert s.coop_thr == 55.0 and cfg.coop_thr == 55.0
+    P.update(integrator="dopri5", cooperative=True)
+    with pytest.raises(ValueError, match="cooperative"):
+        EnvSpec(P)
+    Q = copy.deepcopy(SC.scenarios()["me_reactive"]["env_params"])
+    Q.update(integrator="rodas4")
+    assert EnvSpec(Q).coop_thr == 0.0  # off where the kernels do not carry the rule: not an error unless asked for
+    Q.update(cooperative=True)
+    with pytest.raises(ValueError, match="cooperative"):
+        EnvSpec(Q)
+    assert M.get_model("multistage_extraction").param_vector()[4] == 2.0
