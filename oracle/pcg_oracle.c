@@ -1122,6 +1122,11 @@ ORC_EXPORT int orc_me_ros_solve(const double* p, const double* u, const double* 
 }
 
 static int g_ros4_structured = 1; /* test switch: 0 = dense finite-difference path for every model */
+/* calibration hook of the pair's controller (tools/prototypes): first step x h0, safety, largest growth, smallest factor */
+static double g_r4_h0 = 5.0, g_r4_safety = 0.9, g_r4_facmax = 6.0, g_r4_facmin = 0.2;
+ORC_EXPORT void orc_set_rodas4_ctrl(double h0, double safety, double facmax, double facmin) {
+  g_r4_h0 = h0; g_r4_safety = safety; g_r4_facmax = facmax; g_r4_facmin = facmin;
+}
 ORC_EXPORT void orc_set_ros4_structured(int on) { g_ros4_structured = on; }
 
 static int rodas4(const orc_model* m, double* x, const double* u, double dt, double rtol, double atol, int max_steps,
@@ -1141,7 +1146,7 @@ static int rodas4(const orc_model* m, double* x, const double* u, double dt, dou
     double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
     /* 5 h0: measured over the action box of BASELINE configs[2], 100 h0 (Rodas3's choice) costs 3.9 rejected attempts
      * per env step out of 22.5, 5 h0 costs 0.5 out of 19.6 at the same worst-case error */
-    h = fmin(qtrunc6(5.0 * h0), dt);
+    h = fmin(qtrunc6(g_r4_h0 * h0), dt);
   }
   /* end-point error control: exponent rate per unit of contraction rate, in bits */
   const double ep_c = (ep_kmax > 0) ? ep_frac * 1.4426950408889634 : 0.0;
@@ -1216,7 +1221,7 @@ static int rodas4(const orc_model* m, double* x, const double* u, double dt, dou
     E2 = E2 * (1.0 / n);
     if (!lu_ok) E2 = NAN;
     if (E2 < 1.0) {
-      double f = (E2 == 0.0) ? 6.0 : fmin(6.0, fmax(0.2, qtrunc6(0.9 * pow(E2, -0.125))));
+      double f = (E2 == 0.0) ? g_r4_facmax : fmin(g_r4_facmax, fmax(g_r4_facmin, qtrunc6(g_r4_safety * pow(E2, -0.125))));
       if (rejected_last && f > 1.0) f = 1.0;
       t += h;
       h *= f;
@@ -1226,7 +1231,7 @@ static int rodas4(const orc_model* m, double* x, const double* u, double dt, dou
       if (last) break;
       rhs_int(m, x, u, f0);
     } else {
-      double f = (E2 == E2) ? fmax(0.2, qtrunc6(0.9 * pow(E2, -0.125))) : 0.2;
+      double f = (E2 == E2) ? fmax(g_r4_facmin, qtrunc6(g_r4_safety * pow(E2, -0.125))) : g_r4_facmin;
       if (f > 1.0) f = 1.0;
       h *= f;
       rejected_last = 1;

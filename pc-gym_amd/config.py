@@ -11,7 +11,7 @@ New optional keys (do not exist in the reference):
                see DEFAULT_INTEGRATOR; integration_method='jax' -> 'tsit5', the reference's own method, integrator.py:56-61)
   endpoint_control  rodas4 only: {'frac': 0.5, 'kmax': 10} | False -- end-point error control (pcgym_hip.h,
                PCG_INT_RODAS4); on by default, acts only on models with a contraction-rate hook (extraction cascades)
-  cooperative  rodas4 on multistage_extraction with eq_exponent == 2 only: {'thr': 48} | False -- env steps whose predicted
+  cooperative  rodas4 on multistage_extraction with eq_exponent == 2 only: {'thr': 60} | False -- env steps whose predicted
                cost (attempts of the pair, a per-env rule) reaches thr take SEULEX-8, eight lanes per env in the work-queue
                kernel (pcgym_hip.h: coop_thr; pcg_seulex.hpp); on by default where it applies
   substeps     RK4 sub-steps per env step
@@ -93,7 +93,7 @@ DEFAULT_TOL = {M.CSTR: 1e-10}
 # of the extraction cascade within 1e-6 of a 1e-13 solve over its whole action box (worst lanes: low liquid flow, high
 # gas flow -- 6.5e-7 at 3e-8; tests/test_rodas4.py), the class of the explicit pair at 1e-8 (5.5e-7)
 ROS4_TOL = {M.ME: 3e-8}
-DEFAULT_COOP_THR = 48.0  # cooperative rule of rodas4 plans: predicted attempts from which an env step takes SEULEX-8 (pcg_seulex.hpp)
+DEFAULT_COOP_THR = 60.0  # cooperative rule of rodas4 plans: predicted attempts from which an env step takes SEULEX-8 (pcg_seulex.hpp)
 ROS4_DT_CAL = 1.0  # the env step (model time units) ROS4_TOL was calibrated at; larger steps tighten it (EnvSpec)
 
 

@@ -1095,6 +1095,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       }
       if (std::getenv("PCG_Q_NOSORT")) a.q_tile |= 0x10000;  // measurement switch: FIFO order
       if (const char* ev = std::getenv("PCG_Q_REFILL")) a.q_tile |= (std::atoi(ev) & 0x7F) << 20;  // measurement switch
+
       a.q_w = r4q ? 3.56f : 20.0f;  // (Rodas4: the fit of MEImpl::cost_key_ros) tools/queue_w_sweep.sh: 0 / 10 / 20 / 33 -> me10 0.689 / 0.684 / 0.683 / 0.719 ms, configs[4] shard 0.964 / 0.938 / 0.920 / 0.924 ms
       if (const char* ev = std::getenv("PCG_Q_W")) a.q_w = (float)std::atof(ev);  // measurement switch: key weight
       // Rodas4 with two workgroups per CU: a wave that carries one of the 128 heaviest envs of its tile raises its issue
@@ -1111,12 +1112,24 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
                 io->B > (int64_t)p->num_cus * QBLOCK;
       if (const char* ev = std::getenv("PCG_Q_W1")) w1 = w1 && std::atoi(ev) != 0;  // measurement switch
       if (w1) a.q_tile = (a.q_tile & ~0xFFFF) | p->q_tile1[pe];
+      // waves of a workgroup that take part in the cooperative phase of a Rodas4 tile (pcg_step_queue.hpp): the heavy envs of
+      // a tile are few (1-2 % at the default threshold) and a wave carries eight at a time -- ONE wave with its groups busy
+      // where the workgroup has the CU to itself, two where two workgroups share it (me10_ros4 at B = 2^18: all four waves
+      // 326.8 us, two 312.9, one 311.6 at threshold 58; profiles/r5/coop_sweep.txt).  PCG_Q_COOPW: measurement switch (0 = all)
+      if (r4q) {
+        int cw = w1 ? 1 : 2;
+        if (const char* ev = std::getenv("PCG_Q_COOPW")) cw = std::atoi(ev);
+        a.q_tile |= (cw & 0xF) << 27;
+      }
       // The explicit pair at two waves per SIMD: ONE 512-thread workgroup per CU on a tile of up to 2048 slots instead of two
       // 256-thread workgroups on 1024 each.  The lanes and the envs per lane are the same, the pool is twice as deep, and the
       // two waves of a SIMD drain the same queue: with two workgroups a wave whose SIMD-mate's tile ran dry early finished
       // alone (per-wave stamps, tools/queue_probe.py: the 10-state cascade's waves ended between 424 and 737 us of a 737 us
       // launch).  Taken when every workgroup still gets >= 1.75 envs per lane.
-      bool wide = !r4q && k.queue_w[pe] && io->B >= (int64_t)p->num_cus * (7 * 2 * QBLOCK / 4);
+      bool wide = !r4q && !a.fixup && k.queue_w[pe] && io->B >= (int64_t)p->num_cus * (7 * 2 * QBLOCK / 4);
+      // (The Rosenbrock pair in this shape -- one 512-thread workgroup per CU, both waves of a SIMD on one tile of 1024 -- was
+      // built and measured in round 5: a wave that shares its SIMD takes 6.8 us per attempt, i.e. 3.4 us per wave-attempt
+      // against 3.5 alone; 320-323 us per launch against 305-326: declined, profiles/r5/r4wide_sweep.txt.)
       if (const char* ev = std::getenv("PCG_Q_WIDE")) wide = wide && std::atoi(ev) != 0;  // measurement switch
       const int qb = wide ? 2 * QBLOCK : QBLOCK;
       if (wide) {

@@ -287,8 +287,8 @@ struct MEImpl : MECoop<SQ> {
   }
   // The cooperative rule (pcg_seulex.hpp): predicted attempts of the Rosenbrock pair for this env step, from the slower
   // through-flow rate mn and the scaled size d1 of f(x0) -- a least-squares fit over the action box of BASELINE configs[2]
-  // (tools/prototypes/seulex8_calib.py: correlation 0.90 with the measured attempts; at the default threshold 48 it picks 7 %
-  // of the envs, none below 25 attempts, and leaves none above 55), in EXACT arithmetic: IEEE operations and exponent
+  // (tools/prototypes/seulex8_calib.py: correlation 0.90 with the measured attempts; at threshold 48 it picks 7 %
+  // of the envs, none below 25 attempts, and leaves none above 55; the default, 60, picks 2 %), in EXACT arithmetic: IEEE operations and exponent
   // extraction only, so that the kernels and the oracle pick the same envs.  Twin: me_coop_key() in oracle/pcg_oracle.c.
   template <class K>
   PCG_DEV static double coop_key(const K& k, const double (&u)[NA + NDM], double d1) {

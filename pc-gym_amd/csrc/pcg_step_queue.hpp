@@ -386,8 +386,11 @@ template <class M, int QB, bool XL = false>
 PCG_DEV void coop_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, const double* us, const double* hs,
                             const uint32_t* sortbuf, int32_t* accs, int32_t* rejs, int32_t* flag, int32_t* cnext, int T, int nh,
                             double dt, double dt_edge, double h_floor, double rtol, double atol, int max_steps, double ep_c,
-                            int ep_kmax) {
+                            int ep_kmax, unsigned long long* qst = nullptr) {
   constexpr int NX = M::NX, NU = M::NA + M::NDM;
+#ifdef PCG_QSTATS  // measurement build (tools/queue_probe.py): big steps this wave executed, busy groups summed over them
+  unsigned long long qs_big = 0, qs_groups = 0;
+#endif
   typename M::CKP& kp = *kpp;
   const int lane = threadIdx.x & 63, j = lane & 7;
   const unsigned long long below = (1ull << (lane & ~7)) - 1ull;  // the lanes of the groups before this one
@@ -435,6 +438,10 @@ PCG_DEV void coop_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, c
       if (drained) break;
       continue;
     }
+#ifdef PCG_QSTATS
+    ++qs_big;
+    qs_groups += __popcll(__ballot(slot >= 0) & 0x0101010101010101ull);
+#endif
     if (slot >= 0) {
       double u[NU];
 #pragma unroll
@@ -456,6 +463,9 @@ PCG_DEV void coop_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, c
       }
     }
   }
+#ifdef PCG_QSTATS
+  if (lane == 0 && qst) qst[14] = qs_big, qst[15] = qs_groups;
+#endif
 }
 
 // ---- the tile's sort: bitonic network over S = E * QB packed words (QB threads), DESCENDING, E words per thread in registers ----
@@ -709,13 +719,17 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
     int nh = 0;
     if constexpr (COOP) {
       nh = *nheavy;  // (uniform; written before the sort's barriers)
-      if (nh > 0) {
+      // how many of the workgroup's waves take part (0 = all): with few heavy envs per tile every wave would carry a mostly
+      // empty set of groups through the phase -- one wave with all eight groups busy costs the tile less
+      const int coop_waves = (A.q_tile >> 27) & 0xF;
+      if (nh > 0 && (coop_waves == 0 || (tid >> 6) < coop_waves)) {
         if (A.q_prio > 0) __builtin_amdgcn_s_setprio(3);  // the heavy envs are the launch's critical path
         coop_integrate<M, QB>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, cnext, T, nh, dt,
-                              c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax);
+                              c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, qst);
         if (A.q_prio > 0) __builtin_amdgcn_s_setprio(0);
       }
     }
+    PCG_QS(13);
     queue_integrate<M, INTEG, QB, FIX>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, A.q_prio,
                               (A.q_prio > 0 && blockIdx.x >= gridDim.x / 2) ? 2 * 64 : 0, qst, fix ? eidx : nullptr, nh);
     if (A.q_prio > 0) __builtin_amdgcn_s_setprio(0);

@@ -92,8 +92,8 @@ def test_seulex8_reaches_true_solution_and_converges(fix):
 
 def test_rule_picks_the_heavy_envs_and_seulex8_crosses_them_in_class():
     spec, cases, refs = _me_box(3000, 5)
-    s4 = spec(integrator="rodas4")
-    assert s4.coop_thr == DEFAULT_COOP_THR == 48.0
+    assert spec(integrator="rodas4").coop_thr == DEFAULT_COOP_THR == 60.0
+    s4 = spec(integrator="rodas4", cooperative={"thr": 48})  # the threshold the rule was fitted at: 7 % of the box
     s4p = spec(integrator="rodas4", cooperative=False)
     assert s4p.coop_thr == 0.0
     picked_n = 0

@@ -3,7 +3,7 @@
 through PCGYM_HIP_LIB).  Every wave records wall-clock stamps (100 MHz) at the phase boundaries and the counts of its
 phase-2 loop: iterations, attempts executed, busy lanes summed over them, refills and the time inside them.
   UNIT=pcg_inst_j tools/fastlib.sh _ab/qstats_j.so -DPCG_QSTATS
-  PCGYM_HIP_LIB=_ab/qstats_j.so python tools/queue_probe.py me20"""
+  PCGYM_HIP_LIB=_ab/qstats_j.so python tools/queue_probe.py me20 [coop_thr]"""
 import os
 import sys
 
@@ -20,6 +20,10 @@ def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "me20"
     dev = torch.device("cuda", 0)
     name, params, B, _, n_act = bench.single_workload(wl)
+    if len(sys.argv) > 2:  # threshold of the cooperative rule of a Rodas4 plan (0 = off)
+        thr = float(sys.argv[2])
+        params["cooperative"] = {"thr": thr} if thr > 0 else False
+        name += f" coop_thr {thr:g}"
     env = VecEnv(params, n_envs=B, device=dev, seed=1234, auto_reset=True)
     spec = env.spec
     gen = torch.Generator(device=dev).manual_seed(99)
@@ -50,6 +54,12 @@ def main():
         print("  phase 1 (load, pre, h_init, park)  us ", q((u[:, 1] - u[:, 0]) / 100))
         print("  sort (+ barrier)                   us ", q((u[:, 2] - u[:, 1]) / 100))
         print("  phase 2, own wave                  us ", q((u[:, 3] - u[:, 2]) / 100))
+        if (u[:, 13] > 0).any():  # cooperative phase of a Rodas4 tile (stamp 13 = its end, 14 / 15 = big steps / busy groups)
+            cp = (u[:, 13] - u[:, 2]) / 100
+            print("  ... of it the cooperative phase   us ", q(cp))
+            print("      big steps executed per wave       ", q(u[:, 14]))
+            print("      busy groups per big step (of 8)   ", q(u[:, 15] / np.maximum(u[:, 14], 1)))
+            print(f"      time per big step: {np.median(cp[u[:, 14] > 0] / u[u[:, 14] > 0, 14]):.3f} us; envs through the phase {u[:, 15].sum():.0f} group-steps")
         print("  wait for the workgroup's last wave us ", q((u[:, 4] - u[:, 3]) / 100))
         print("  phase 3                            us ", q((u[:, 5] - u[:, 4]) / 100))
         print("  end of the wave since launch start us ", q(us(u[:, 5])))
