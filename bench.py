@@ -168,6 +168,35 @@ def single_workload(name):
     raise SystemExit(f"unknown workload {name}")
 
 
+def _cgroup_cpu_quota():
+    """CPUs' worth of CPU time the container may use per period (cgroup v2 cpu.max / v1 cfs quota), None if unlimited"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+            return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+            q, per = float(fq.read()), float(fp.read())
+            return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+def _physical_cores(avail):
+    """one thread per physical core among the CPUs of the affinity mask (thread_siblings_list), `avail` if unknown"""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        seen = set()
+        for c in cpus:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as fh:
+                seen.add(fh.read().strip())
+        return max(1, len(seen))
+    except (OSError, AttributeError):
+        return avail
+
+
 def cpu_baseline(spec, seconds_target=10.0, threads=None):
     """The CPU oracle (oracle/pcg_oracle.c: same algorithm, plain C + OpenMP) on the host cores, on a bounded sample of
     the same workload, with a FIXED thread count; beside it the reference-shaped leg: one env at a time through a
@@ -189,29 +218,48 @@ def cpu_baseline(spec, seconds_target=10.0, threads=None):
     Bs, T = 1 << 18, 8
     rng = np.random.default_rng(0)
     acts = rng.uniform(-1, 1, (T, spec.na, Bs))
+    quota = _cgroup_cpu_quota()  # CPUs' worth of time the container may use (None: unlimited)
+    phys = _physical_cores(avail)
 
     def rate(nthreads, budget_s):
-        env = O.OracleEnv(spec, Bs, seed=1, n_threads=nthreads)
-        env.reset()
-        env.step(acts[0])  # warm-up (thread pool, page faults)
-        t0 = time.perf_counter()
-        env.step(acts[1])
-        per = max(time.perf_counter() - t0, 1e-6)
-        reps = int(max(2, min(4000, budget_s / per)))
-        env.reset()
-        t0 = time.perf_counter()
-        for i in range(reps):
-            if env.t == spec.N - 1:
-                env.reset()
-            env.step(acts[i % T])
-        dt = time.perf_counter() - t0
-        return reps * Bs / dt, reps, dt
+        # pinned team (thread i on the (i n_cpu / n)-th CPU of the mask: spread over the sockets); orc_reset writes every
+        # buffer first on the partition orc_step uses, so each thread's slice of every row lives on its own NUMA node
+        pinned = O.lib().orc_pin_threads(int(nthreads)) == 0
+        try:
+            env = O.OracleEnv(spec, Bs, seed=1, n_threads=nthreads)
+            env.reset()
+            env.step(acts[0])  # warm-up (thread pool, page faults)
+            t0 = time.perf_counter()
+            env.step(acts[1])
+            per = max(time.perf_counter() - t0, 1e-6)
+            reps = int(max(2, min(4000, budget_s / per)))
+            env.reset()
+            t0 = time.perf_counter()
+            for i in range(reps):
+                if env.t == spec.N - 1:
+                    env.reset()
+                env.step(acts[i % T])
+            dt = time.perf_counter() - t0
+        finally:
+            O.lib().orc_unpin_threads()
+        return reps * Bs / dt, reps, dt, pinned
 
-    one, _, _ = rate(1, 2.0)
-    value, reps, dt = rate(cores, seconds_target)
-    # the same leg on EVERY logical CPU of the host (SURVEY.md section 8(d) asks for "all host cores"): the workload is
-    # memory-bound on the CPU too, so more threads than memory channels buy little -- both numbers are on the line
-    all_value, all_reps, all_dt = (value, reps, dt) if avail == cores else rate(avail, 4.0)
+    one, _, _, _ = rate(1, 2.0)
+    value, reps, dt, pinned = rate(cores, seconds_target)
+    # SURVEY.md section 8(d) asks for "1 thread and all host cores": the same leg on one thread per physical core and on
+    # every logical CPU the process may run on.  A container's CPU-time quota (cgroup cpu.max) can be far below the CPUs
+    # its affinity mask shows: a team larger than the quota is throttled, not parallel (round 4 printed 2.2e6 env-steps/s
+    # on "256 logical CPUs" against 1.5e8 on 16 threads) -- the quota is on the line, and a leg above it says so.
+    legs = {}
+    for name, n in (("physical_cores", phys), ("all_logical_cpus", avail)):
+        if n == cores:
+            v, r, d = value, reps, dt
+        else:
+            v, r, d, _ = rate(n, 4.0)
+        legs[name] = {"value": v, "unit": "env-steps/s", "cores": n,
+                      "sample": f"{r} steps x {Bs} envs, pinned OpenMP team of {n} ({d:.1f} s)",
+                      **({"above_cgroup_cpu_quota": True} if quota is not None and n > quota + 0.5 else {})}
+    all_value, all_reps, all_dt = legs["all_logical_cpus"]["value"], 0, 0.0
     # accuracy of the workload's integrator setting vs a tight adaptive solve, same starts
     p2 = dict(spec.env_params)
     p2.update(integrator="dopri5", rtol=1e-12, atol=1e-14)
@@ -258,8 +306,11 @@ def cpu_baseline(spec, seconds_target=10.0, threads=None):
         "unit": "env-steps/s",
         "cores": cores,
         "one_thread_env_steps_per_s": one,
-        "all_host_cpus": {"value": all_value, "unit": "env-steps/s", "cores": avail,
-                          "sample": f"{all_reps} steps x {Bs} envs, OpenMP over all {avail} logical CPUs ({all_dt:.1f} s)"},
+        "all_host_cpus": legs["all_logical_cpus"],
+        "physical_cores": legs["physical_cores"],
+        "best_of_legs_env_steps_per_s": max(one, value, legs["physical_cores"]["value"], all_value),
+        "threads_pinned_first_touch_parallel": bool(pinned),
+        "cgroup_cpu_quota_cpus": quota,
         "host_cpu": cpu_model,
         "host_logical_cpus": os.cpu_count(),
         "kind": "port",
@@ -306,14 +357,14 @@ _PMC = None
 
 
 def committed_pmc(workload, build_id):
-    """per-launch counters of this workload's dominant kernel from the committed rocprofv3 PMC passes (profiles/r4/pmc.json,
+    """per-launch counters of this workload's dominant kernel from the committed rocprofv3 PMC passes (profiles/r5/pmc.json,
     made by tools/prof_all.sh + tools/pmc_json.py on the GPU box; FETCH_SIZE x 2 per MI355X_MICROARCH.md's gfx950 note).
     NOT measured in this run: hardware counters cannot be read from inside the process.  An entry is quoted only when it was
     taken on THIS build of the library (pcg_build_id(): a digest of the kernel headers and the .hip units): -> (entry or None, reason)."""
     global _PMC
     if _PMC is None:
         _PMC = {}
-        for tp in ("profiles/r4/pmc.json", "profiles/r3/pmc.json"):
+        for tp in ("profiles/r5/pmc.json", "profiles/r4/pmc.json", "profiles/r3/pmc.json"):
             tpath = os.path.join(ROOT, tp)
             if os.path.exists(tpath):
                 with open(tpath) as fh:
@@ -327,6 +378,33 @@ def committed_pmc(workload, build_id):
         return None, (f"stale profile: {_PMC.get('__file__')} was taken on build {e.get('build_id', 'unrecorded')}, "
                       f"this library is {build_id}")
     return e, None
+
+
+COPY_CEILING = {"GBps": None}  # filled by clock_preheat()
+
+
+def _pin_to_gpu_numa(torch, dev_index):
+    """N-rank runs: keep a rank's host threads on the NUMA node of its GPU (its launch loop and the runtime's helper threads
+    otherwise migrate across sockets).  Returns what was done, for the JSON line; never fails the run."""
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as fh:
+            node = int(fh.read())
+        if node < 0:
+            return {"numa_node": None, "pinned": False, "why": "the device reports no NUMA node"}
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as fh:
+            cpus = set()
+            for part in fh.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= set(os.sched_getaffinity(0))
+        if not cpus:
+            return {"numa_node": node, "pinned": False, "why": "no allowed CPU on that node"}
+        os.sched_setaffinity(0, cpus)
+        return {"numa_node": node, "pinned": True, "cpus": len(cpus)}
+    except Exception as e:  # noqa: BLE001 -- measurement hygiene, not a requirement
+        return {"numa_node": None, "pinned": False, "why": f"{type(e).__name__}: {e}"}
 
 
 def clock_preheat(torch, dev, ms):
@@ -349,6 +427,15 @@ def clock_preheat(torch, dev, ms):
             if mode != "matmul":
                 dst.copy_(src)
         torch.cuda.synchronize()
+    # the copy it has just been running, timed: the measured on-box ceiling of a streaming kernel (BASELINE.md section 3 asks
+    # for the fraction of a measured copy ceiling beside the 8 TB/s vendor peak): 256 MiB read + 256 MiB written per copy
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    COPY_CEILING["GBps"] = 20 * 2.0 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     return (time.perf_counter() - t0) * 1e3
 
 
@@ -422,6 +509,7 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a node with one GPU per rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    pin = _pin_to_gpu_numa(torch, dev_index) if world > 1 else {"pinned": False, "why": "single rank"}
     dist, ranks_seen = None, 1
     # PCG_BENCH_FORCE_DIST=1 (TEST switch, under torch.distributed.run with one rank): take the communicator path even with
     # one rank, so that the RCCL branch -- device-bound process group, device tensors in the reductions, barrier +
@@ -508,6 +596,8 @@ def main():
         spec = envs[2].spec
     else:
         wl_name, params, Bd, (Kd, Wd), n_act = single_workload(args.workload)
+        if os.environ.get("PCG_BENCH_NACT"):  # measurement switch (tools/sessions): number of rotating action slabs
+            n_act = max(1, int(os.environ["PCG_BENCH_NACT"]))
         if args.integrator and args.workload in ("me10", "me20"):
             params["integrator"] = args.integrator
             for k in ("rtol", "atol"):  # the integrator's own default tolerance for this model (config.ROS4_TOL)
@@ -617,7 +707,26 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     host_us = t_host / max(K, 1) * 1e6
+    # this rank's own figures, before the maximum over ranks replaces them: wall time per step, mean in-run kernel time (HIP
+    # events on the launch stream; the dominant segment's for the mixed shard), host cost of the launch loop per step, NUMA
+    # node -- printed per rank so that a bad 1 -> N curve can be attributed (which rank; host loop or kernel)
+    if mixed:
+        kern_local_us = max(tot_ms * 1e3 / max(n * max(graph_steps[0], 1), 1) for tot_ms, n in menv.segment_times())
+    else:
+        kern_local_us = sum(eb.elapsed_time(ee) for eb, ee, _ in brackets) * 1e3 / max(sum(m for _, _, m in brackets), 1)
+    per_rank = {"ms_per_step": [elapsed / K * 1e3], "kernel_avg_us": [kern_local_us], "host_launch_loop_us_per_step": [host_us],
+                "numa_node": [pin.get("numa_node")], "pinned_to_gpu_numa_node": [bool(pin.get("pinned"))]}
     if dist is not None:
+        pr = torch.zeros((world, 5), device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        node = pin.get("numa_node")
+        pr[rank] = torch.tensor([elapsed / K * 1e3, kern_local_us, host_us, -1.0 if node is None else float(node),
+                                 1.0 if pin.get("pinned") else 0.0], dtype=torch.float64)
+        dist.all_reduce(pr)
+        prl = pr.cpu().tolist()
+        per_rank = {"ms_per_step": [r[0] for r in prl], "kernel_avg_us": [r[1] for r in prl],
+                    "host_launch_loop_us_per_step": [r[2] for r in prl],
+                    "numa_node": [None if r[3] < 0 else int(r[3]) for r in prl],
+                    "pinned_to_gpu_numa_node": [bool(r[4]) for r in prl]}
         tt = torch.tensor([elapsed, host_us], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, host_us = float(tt[0].item()), float(tt[1].item())
@@ -673,6 +782,7 @@ def main():
             "library_build_id": build_id,
             "rank_first_env": rank_offsets,
             "host_launch_loop_us_per_step_max_over_ranks": round(host_us, 2),
+            "per_rank": per_rank,
             "sane": finite,
         },
     }
@@ -700,6 +810,7 @@ def main():
                     q = pmx.get("segments", {}).get(d["segment"])
                     if q:
                         d["traffic"] = q["traffic_bytes_per_launch"]
+                        d["traffic_over_algorithmic"] = q["traffic_bytes_per_launch"] / (float(d["algorithmic_bytes_per_env_step"]) * d["envs"])
                         if "valu_issue_frac" in q:
                             d["valu_issue_frac"] = q["valu_issue_frac"]
             dom = max(segs_out, key=lambda d: d["kernel_avg_us"])
@@ -710,7 +821,9 @@ def main():
                 "unit": "TFLOP/s" if "fp64_frac" in dom else "GB/s",
                 "frac": dom.get("fp64_frac", dom["hbm_frac"]),
                 "traffic": dom.get("traffic"),
+                "traffic_over_algorithmic": dom.get("traffic_over_algorithmic"),
                 "traffic_measured_in_run": False,
+                "copy_ceiling_GBps": COPY_CEILING["GBps"],
                 **({} if pmx else {"traffic_reason": pm_why}),
                 "kernel": f"dominant segment: {dom['segment']} ({dom['integrator']}); the three segments run concurrently "
                           "on their own streams",
@@ -736,7 +849,18 @@ def main():
                 "kernel_avg_us": kern_avg_s * 1e6,
                 "algorithmic_bytes_per_env_step": int(bpe),
                 "algorithmic_bytes_per_launch": alg_bytes,
+                # the 256 MiB device copy clock_preheat() ran just before the warm-up, timed: the measured on-box ceiling
+                "copy_ceiling_GBps": COPY_CEILING["GBps"],
+                "frac_of_copy_ceiling": (achieved / COPY_CEILING["GBps"]) if COPY_CEILING["GBps"] else None,
             }
+            if adaptive and not fp64 and env.nsteps is not None:
+                # adaptive plans of the cheap models (the cstr's guarded default on the full x0 box): neither HBM nor issue
+                # bound -- the launch waits for its heaviest env, one lane crossing an ignition front attempt by attempt
+                att_max = int(env.nsteps.sum(dim=0).max().item())
+                rl.update(bound="chain", chain={"heaviest_env_attempts_last_step": att_max,
+                                                "note": "launch time ~ guarded step + heaviest env's attempts x 1.6-2.1 us of a "
+                                                        "latency-bound lane (DESIGN.md section 3); the hbm figures beside it are the "
+                                                        "algorithmic bytes over that time, not what limits it"})
             if fp64:
                 # fp64-issue-bound kernels: algorithmic flops = RHS evaluations x (flop per RHS + RK stage combination)
                 att = 0.0
@@ -767,8 +891,13 @@ def main():
                     # 1024 SIMDs, cycles = GRBM_GUI_ACTIVE of the dispatch -- independent of any flop weighting
                     rl["valu_issue_frac"] = pm["valu_issue_frac"]
                     rl["valu_insts_per_launch"] = pm["SQ_INSTS_VALU_per_launch"]
-                    if "valu_issue_time_frac_at_2p4ns" in pm:
-                        # the same count priced at the measured 2.4 ns per fp64 wave-instruction per SIMD (tools/issuebench.hip)
+                    if "valu_issue_time_frac_by_class" in pm:
+                        # the same launch priced by instruction class at the measured issue costs (tools/issuebench.hip: fp64
+                        # add / mul / fma 2.4 ns, fp64 estimates 7.3 ns, fp32 transcendentals 3.65 ns, the rest 1.35 ns per
+                        # wave-instruction and SIMD): the share of the launch its SIMDs spend issuing vector work
+                        rl["valu_issue_time_frac_by_class"] = pm["valu_issue_time_frac_by_class"]
+                        rl["valu_insts_by_class_per_launch"] = pm["valu_insts_by_class_per_launch"]
+                    elif "valu_issue_time_frac_at_2p4ns" in pm:
                         rl["valu_issue_time_frac_at_2p4ns"] = pm["valu_issue_time_frac_at_2p4ns"]
             if fp64:
                 f_survey = {"crystallization": 80 + 2 + 3 + 1 + 6}.get(spec.model.name)  # "~80 flop + 2 exp + 3 pow + 1 sqrt + ~6 div" counted as one flop each

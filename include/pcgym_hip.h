@@ -151,14 +151,17 @@ enum pcg_integrator {
                           pcg_step returns its launches to the stream -- inside the same kernel, or, for batches that fill
                           the chip, by a second launch of the adaptive pair's work-queue kernel over exactly the envs the
                           first one marked (same arithmetic per env, same bits; `done` holds the mark 2 only between the
-                          two) -- (nsteps reports (0,0) for accepted envs, the pair's counts otherwise).  Models
+                          two: a consumer of `done` on ANOTHER stream must order itself behind the whole pcg_step, as for any
+                          output; should the second launch fail to start, pcg_step returns its error and the marked envs keep
+                          done == 2 with their state, observation and counters of the step not advanced) -- (nsteps reports (0,0) for accepted envs, the pair's counts otherwise).  Models
                           with a guard hook only (cstr: the ignition branch).  The guard is the ONLY test -- RK4 carries no
                           error estimate -- and it is calibrated on the cstr's observation box and action box: an opt-in
                           for that box (the model's default plan is PCG_INT_T5G, which also checks an estimate).  General
                           kernel, pcg_step_autoreset, pcg_graph_*, pcg_integrate, pcg_rollout; not with per-env uncertain
                           parameters */
   PCG_INT_T5G = 6,     /* GUARDED FIXED-STEP TSIT5: `substeps` equal steps of Tsit5's fifth-order solution weights, TRUSTED per
-                          env while (i) the model's guard holds at EVERY stage state and at the end state (g <= 0, rho h <= 2)
+                          env while (i) the model's guard holds at the START and END state of every step (g <= 0, rho h <= 2; the five
+                          inner stage states change no decision once the estimate of (ii) is checked)
                           and (ii) the pair's own embedded 5(4) error estimate of every step stays below 4e-7 |x| + 4e-9 (RMS;
                           the seventh stage it needs is the next step's first stage and the end-state guard: no extra
                           evaluation); otherwise PCG_INT_DOPRI5 from the start state at rtol / atol, in one launch or two as

@@ -43,6 +43,12 @@ def lib():
         l.orc_reset.restype = C.c_int
         l.orc_reset.argtypes = [C.POINTER(abi.pcg_env_cfg), C.POINTER(abi.pcg_buffers), vp, vp, C.c_uint64,
                                 C.c_int64]
+        l.orc_set_reset_threads.restype = None
+        l.orc_set_reset_threads.argtypes = [C.c_int]
+        l.orc_pin_threads.restype = C.c_int
+        l.orc_pin_threads.argtypes = [C.c_int]
+        l.orc_unpin_threads.restype = C.c_int
+        l.orc_unpin_threads.argtypes = []
         l.orc_philox4x32_10.restype = None
         l.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
         l.orc_rng_normal.restype = C.c_double
@@ -149,6 +155,7 @@ class OracleEnv:
             self.t = 0
             self.status[:] = 0
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().orc_set_reset_threads(int(self.n_threads))  # the partition of orc_step: first touch places each thread's slice
         lib().orc_reset(C.byref(self.cfg), C.byref(self.buf), _p(self.slots), _p(m), self._seed(), self.env_offset)
         return self.obs
 

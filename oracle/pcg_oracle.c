@@ -32,10 +32,16 @@
  *
  * Build: make -C oracle   (gcc -O2 -fopenmp -shared -fPIC) -> oracle/libpcg_oracle.so
  */
+#define _GNU_SOURCE /* sched_setaffinity: the timed CPU baseline pins its OpenMP team (orc_pin_threads) */
 #include <math.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../include/pcgym_hip.h"
 
@@ -1855,10 +1861,50 @@ ORC_EXPORT int orc_step(const pcg_env_cfg* c, const pcg_buffers* io, double* slo
   return 0;
 }
 
+/* The timed CPU baseline (bench.py: cpu_baseline) on a many-core host: (1) orc_reset writes every SoA buffer first, so it
+ * runs on the SAME static partition of the envs as orc_step -- each thread's slice of every row is first touched, hence
+ * placed, on that thread's NUMA node; (2) the team is pinned, thread i on the (i n_cpu / n)-th CPU of the process's mask
+ * (spread over the sockets; OMP_PROC_BIND cannot be relied on: another OpenMP runtime is already initialised in the process);
+ * orc_unpin_threads() gives the calling thread its mask back. */
+static int g_reset_threads = 1;
+ORC_EXPORT void orc_set_reset_threads(int n) { g_reset_threads = n > 0 ? n : 1; }
+static cpu_set_t g_mask0;
+static int g_mask0_valid = 0;
+ORC_EXPORT int orc_pin_threads(int n) {
+  if (n < 1) return -1;
+  if (!g_mask0_valid) {
+    if (sched_getaffinity(0, sizeof g_mask0, &g_mask0) != 0) return -2;
+    g_mask0_valid = 1;
+  }
+  int cpus[CPU_SETSIZE], nc = 0;
+  for (int i = 0; i < CPU_SETSIZE; ++i)
+    if (CPU_ISSET(i, &g_mask0)) cpus[nc++] = i;
+  if (nc == 0) return -3;
+  int bad = 0;
+  (void)cpus;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n) reduction(+ : bad)
+  {
+    const int i = omp_get_thread_num();
+    cpu_set_t m;
+    CPU_ZERO(&m);
+    CPU_SET(cpus[(int)(((int64_t)i * nc) / n) % nc], &m);
+    if (sched_setaffinity(0, sizeof m, &m) != 0) ++bad;
+  }
+#endif
+  return bad;
+}
+ORC_EXPORT int orc_unpin_threads(void) {
+  return g_mask0_valid ? sched_setaffinity(0, sizeof g_mask0, &g_mask0) : 0;
+}
+
 ORC_EXPORT int orc_reset(const pcg_env_cfg* c, const pcg_buffers* io, double* slots, const uint8_t* mask,
                          uint64_t seed, int64_t env_offset) {
   int nx = c->nx, na = c->na, nsp = c->nsp_obs, nd = c->nd, nobs = cfg_nobs(c);
   int64_t B = io->B;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_reset_threads)
+#endif
   for (int64_t b = 0; b < B; ++b) {
     if (mask && !mask[b]) continue;
     double state[PCG_MAX_NOBS], asave[PCG_MAX_NA], obs[PCG_MAX_NOBS];

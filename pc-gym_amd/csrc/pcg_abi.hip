@@ -1182,6 +1182,10 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
         // state stays in the batch
         Tq = p->q_tile[pe];
         while (Tq > qb && k.queue_lds(Tq) + 4 * (size_t)Tq + 8 + sb > (size_t)(160 * 1024 - 2048) / q_bpc) Tq -= 64;
+        if (Tq < qb) {  // (the scan of the fix-up kernel parks QB envs per round: a tile smaller than that never advances)
+          rc_out = PCG_E_UNSUPPORTED;
+          return true;
+        }
         a.q_tile = (a.q_tile & ~(0xFFFF | 0x20000)) | Tq;
         qsh = k.queue_lds(Tq) + 4 * (size_t)Tq + 8 + sb;
       }
@@ -1338,7 +1342,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   int rc = fill_args(p, io, &a);
   if (rc != PCG_OK) return rc;
   if (io->t) return PCG_E_UNSUPPORTED;  // lock-stepped only
-  if (T < 1) return PCG_E_VALUE;
+  if (T < 1 || t0 < 0 || (int64_t)t0 + (int64_t)T > 0x7fffffffLL) return PCG_E_VALUE;  // (t0 indexes the per-step tables)
   if (io->B == 0) return PCG_OK;
   if (!io->x || !a_seq || !io->obs || !io->rew || !io->done) return PCG_E_NULL;
   const DevConst& c = p->hc;

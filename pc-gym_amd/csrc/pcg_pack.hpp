@@ -254,8 +254,11 @@ PCG_PK void sincospi_unit(double x, double& s, double& c) {
 
 // sqrt(x) for x >= 0 in the normal range (exact 0 -> 0; negative -> NaN like the library): hardware reciprocal-
 // square-root estimate y (relative error <= 2^-24), g = x y, then ONE Newton step of the square root with the unrefined
-// half-estimate, g + (y/2)(x - g^2): relative error (2^-24)^2 / 2 = 2^-49 (measured against sqrt(): tests/test_gpu_parity.py
-// RHS parity at 1e-12 holds with two decades to spare).  6 VALU instructions -- one of them the 7.3-ns estimate
+// half-estimate, g + (y/2)(x - g^2): with y = (1 + e) / sqrt(x) the result is sqrt(x) (1 - 3 e^2 / 2 - e^3 / 2), i.e. a relative
+// error of 1.5 e^2 <= 1.5 x 2^-48 = 5.3e-15 (~24 ulp; rounds 2-3 were within 1 ulp) for the measured |e| <= 2^-24 of v_rsq_f64 /
+// v_rcp_f64 on gfx950 (tools/issuebench.hip over 4M arguments: 2^-24.4 -- a measurement of this ASIC, not an architectural
+// guarantee: tests/test_gpu_parity.py::test_hardware_estimates_are_as_accurate_as_the_fast_math_assumes pins it).  RHS parity
+// with the host sqrt() at 1e-12 holds with two decades to spare; last-bit agreement with it is given up.  6 VALU instructions -- one of them the 7.3-ns estimate
 // (profiles/r4/issuebench.txt) -- against ~25 for the library sqrt(), whose extra work is the 2^+-256 rescaling for huge /
 // denormal arguments.  Rounds 2-3 spent 9: a coupled Goldschmidt refinement of BOTH g and y/2 before the same correction,
 // for a last-bit result nothing downstream of a 1e-7-accurate integrator needs; four_tank spends half of its instructions

@@ -47,7 +47,12 @@ def test_other_workloads_line(wl, batch, steps):
     assert KEYS <= set(d) and d["config"]["sane"] and d["steps"] == steps and d["warmup"] == 2
     assert abs(d["value"] - d["config"]["global_envs"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     rf = d["roofline"]
-    assert rf["bound"] in ("hbm", "fp64_valu") and 0 < rf["frac"] < 1.0
+    assert rf["bound"] in ("hbm", "fp64_valu", "chain") and 0 < rf["frac"] < 1.0
+    assert (rf["bound"] == "chain") == (wl == "cstr_safe")  # the adaptive plan of a cheap model waits for its heaviest env
+    if wl == "cstr_safe":
+        assert rf["chain"]["heaviest_env_attempts_last_step"] >= 1
+    if wl != "mixed":
+        assert rf["copy_ceiling_GBps"] > 500 and rf["frac_of_copy_ceiling"] > 0  # the preheat's device copy, timed
     if wl == "mixed":
         assert [s["segment"] for s in rf["segments"]] == ["cstr", "four_tank", "multistage_extraction"]
         assert d["config"]["envs_per_gpu"] == 3 * ((batch // 3) & ~1)
@@ -118,7 +123,9 @@ def test_gpus_n_as_typed_starts_its_own_ranks():
     assert d["config"]["global_envs"] == 2 * d["config"]["envs_per_gpu"] and d["config"]["sane"]
 
 
-@pytest.mark.parametrize("wl,batch,steps", [("cstr", 65536, 70), ("mixed", 30000, 8)])
+@pytest.mark.parametrize("wl,batch,steps", [("cstr", 65536, 70), ("mixed", 30000, 8), ("cstr_safe", 65536, 20),
+                                            ("four_tank", 65536, 20), ("me10_ros4", 16384, 6), ("me20", 16384, 4),
+                                            ("cryst_cv8", 16384, 10)])
 def test_eight_rank_launch_path_on_one_device(wl, batch, steps):
     """No 8-GPU node is available to the builder: the EIGHT-rank code path of the command the driver types
     (`python bench.py --gpus 8`: bench.py starts its own ranks) runs here with the ranks sharing this box's GPU over gloo,
@@ -139,9 +146,17 @@ def test_eight_rank_launch_path_on_one_device(wl, batch, steps):
     assert abs(d["value"] - c["global_envs"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     offs = c["rank_first_env"]
     assert len(offs) == 8 and offs[0] == 0 and offs == sorted(offs) and len(set(offs)) == 8
-    if wl == "cstr":
+    if wl != "mixed":
         assert offs == [r_ * c["envs_per_gpu"] for r_ in range(8)]
     else:  # global layout [cstr x 8 | four_tank x 8 | ME x 8]: a rank's first env is its slice of the first segment
         n = c["envs_per_gpu"] // 3
         assert offs == [r_ * n for r_ in range(8)]
     assert 0 < c["host_launch_loop_us_per_step_max_over_ranks"] < 5000
+    # attribution of a 1 -> N curve: every rank's own wall time per step, in-run kernel time and host-loop cost are on the line
+    # (the maximum over ranks is what `value` is computed from), with the NUMA node each rank was pinned to
+    pr = c["per_rank"]
+    for k in ("ms_per_step", "kernel_avg_us", "host_launch_loop_us_per_step", "numa_node", "pinned_to_gpu_numa_node"):
+        assert len(pr[k]) == 8, k
+    assert all(v > 0 for v in pr["ms_per_step"]) and all(v > 0 for v in pr["kernel_avg_us"])
+    assert abs(max(pr["ms_per_step"]) - d["ms_per_step"]) <= 1e-9 * d["ms_per_step"]
+    assert abs(max(pr["host_launch_loop_us_per_step"]) - c["host_launch_loop_us_per_step_max_over_ranks"]) <= 0.011

@@ -199,7 +199,8 @@ def test_registry_shaped_custom_model_reuses_kernel_with_its_parameters():
 def test_integrator_selection():
     # cstr: the guarded fixed step by default (the ignition branch inside the canonical o_space is beyond fixed-step RK4:
     # those envs fall back to the adaptive pair); plain rk4 is an explicit opt-in and then gets the tuned sub-step count
-    sc_ = EnvSpec(P("cstr_canonical"))  # guarded Tsit5 x 2; the adaptive pair at 1e-10 for the envs the guard refuses
+    sc_ = EnvSpec(P("cstr_canonical"))  # guarded Tsit5 x 2; the adaptive pair for the envs the guard refuses, at the tolerance
+    # that holds an igniting env within 3 x the reference's CVODES tolerances: 1e-9 (1/60) / dt, floor 1e-10 (here dt = 26/60)
     assert sc_.integrator == "tsit5g" and sc_.substeps == 2 and sc_.rtol == 1e-10 and sc_.to_cfg()[0].integrator_id == abi.PCG_INT_T5G
     pg = P("cstr_canonical")
     pg["integrator"] = "rk4g"            # the first guarded plan of round 3 stays available

@@ -60,7 +60,8 @@ def _spec(name, **kw):
 
 def test_default_plans():
     s = _spec("cstr_canonical")
-    assert s.integrator == "tsit5g" and s.substeps == 2 and s.rtol == 1e-10 and s.atol == 1e-10
+    assert s.integrator == "tsit5g" and s.substeps == 2 and s.rtol == 1e-10 and s.atol == s.rtol
+    assert _spec("cstr_canonical", tsim=1.0).rtol == 1e-9 and abs(_spec("cstr_canonical", tsim=5.0).rtol - 2e-10) <= 1e-24
     assert _spec("cstr_canonical", integrator="tsit5g", tsim=13.0).substeps == 1
     assert _spec("cstr_canonical", integrator="tsit5g", tsim=52.0).substeps == 4
     f = _spec("four_tank_canonical")
@@ -144,13 +145,16 @@ def test_t5g_accepts_only_accurate_steps_and_escalates_the_rest(tsim):
         want, _ = O.integrate(ref, x, u)
         got, ns = O.integrate(plan, x, u)
         err = np.max(np.abs(got - want) / np.abs(want), axis=0)
+        scaled = np.max(np.abs(got - want) / (1e-6 * np.abs(want) + 1e-8), axis=0)  # in units of the reference's CVODES tolerances
         esc = ns.sum(axis=0) > 0
         frac.append(esc.mean())
         worst_acc = max(worst_acc, err[~esc].max())
-        worst_esc = max(worst_esc, err[esc].max() if esc.any() else 0.0)
+        worst_esc = max(worst_esc, scaled[esc].max() if esc.any() else 0.0)
         hot = max(hot, float((want[1] > 400).mean()))
         x = want
-    assert worst_acc <= 1e-6 and worst_esc <= 1e-6, (worst_acc, worst_esc)
+    # trusted envs: the 1e-6 class; escalated envs -- the ones that ignite inside the step -- within 3 x the reference's own
+    # tolerances of the 1e-13 solve (config.cstr_default_tol: what is owed through the front; the reference itself is ~1e-4 off)
+    assert worst_acc <= 1e-6 and worst_esc <= 3.0, (worst_acc, worst_esc)
     assert 0.25 < frac[0] < 0.7 and hot > 0.02  # the ignition branch really is in the sample
     if tsim < 2:
         return
@@ -184,7 +188,7 @@ def test_t5g_trusts_nothing_outside_the_reference_tolerance_class_on_a_wide_box(
         ok = np.isfinite(scaled)
         assert 0.01 < trusted.mean() < 0.5, (tsim, trusted.mean())
         assert scaled[trusted & ok].max() <= 3.0, (tsim, scaled[trusted & ok].max())
-        assert scaled[~trusted & ok].max() <= 3.0, (tsim, scaled[~trusted & ok].max())  # (the escalated ones: 1e-10 pair)
+        assert scaled[~trusted & ok].max() <= 3.0, (tsim, scaled[~trusted & ok].max())  # (the escalated ones: the pair at config.cstr_default_tol(dt))
     for ca, T, Tc, tsim in ((0.0036, 375.5, 285.7, 26.0), (0.005, 380.0, 300.0, 5.0)):
         plan = _spec("cstr_canonical", integrator="tsit5g", tsim=tsim)
         _, ns = O.integrate(plan, np.array([[ca], [T]]), np.array([[Tc]]))

@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 root, wls = sys.argv[1], sys.argv[2:]
-RND = os.environ.get("PMC_ROUND", "r4")
+RND = os.environ.get("PMC_ROUND", "r5")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 try:
     from pcgym_amd import _lib
@@ -73,6 +73,15 @@ def entry(kname, c, dur, wl):
             # the same instruction count priced at the MEASURED issue cost of an fp64 wave-instruction (tools/issuebench.hip:
             # 2.1-2.5 ns per SIMD, i.e. ~5 cycles, not 4): the share of the launch its SIMDs spend issuing vector work
             e["valu_issue_time_frac_at_2p4ns"] = c["SQ_INSTS_VALU"] * 2.4 / 1024.0 / dur[kname][1]
+            # ... and priced BY CLASS (round 5: the flat 2.4 ns read 1.07 for me10 and cryst -- a third of their instructions are
+            # 32-bit moves / selects / integer work at 1.35 ns): fp64 add / mul / fma 2.4 ns, fp64 transcendental estimates 7.3 ns,
+            # fp32 transcendentals 3.65 ns, everything else 1.35 ns per wave-instruction and SIMD (profiles/r4/issuebench.txt)
+            if all(k in c for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")):
+                f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"]
+                t64, t32 = c["SQ_INSTS_VALU_TRANS_F64"], c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+                rest = max(0.0, c["SQ_INSTS_VALU"] - f64 - t64 - t32)
+                e["valu_insts_by_class_per_launch"] = {"fp64_add_mul_fma": f64, "fp64_trans": t64, "fp32_trans": t32, "other": rest}
+                e["valu_issue_time_frac_by_class"] = (f64 * 2.4 + t64 * 7.3 + t32 * 3.65 + rest * 1.35) / 1024.0 / dur[kname][1]
     e["build_id"] = BUILD_ID
     e["source"] = (f"profiles/{RND}/{wl}/rocprofv3_summary.txt (tools/prof_all.sh: FETCH_SIZE, WRITE_SIZE, SQ and GRBM counters in "
                    "separate --pmc passes with --kernel-trace only; FETCH_SIZE x 2 per MI355X_MICROARCH.md HBM section); NOT "
@@ -93,6 +102,22 @@ for wl in wls:
             if name and (name not in segs or c["_n"] > segs[name]["launches_in_pmc_pass"]):
                 segs[name] = entry(k, c, dur, wl)
         res[wl] = {"segments": segs, "build_id": BUILD_ID}
+    elif wl == "cstr_safe":
+        # a guarded plan's step is TWO launches (the guarded step of every env + the work-queue fix-up of the envs it marked):
+        # per-step counters = the sum over both kernels' per-launch means; the duration is the sum of the two averages
+        ks = [q for q in cs if cs[q]["_n"] >= 0.5 * max(v["_n"] for v in cs.values())]
+        tot = defaultdict(float)
+        for q in ks:
+            for cn, v in cs[q].items():
+                if cn != "_n":
+                    tot[cn] += v
+        tot["_n"] = min(cs[q]["_n"] for q in ks)
+        name = " + ".join(q[:60] for q in ks)
+        d2 = dict(dur)
+        if all(q in dur for q in ks):
+            d2[name] = (min(dur[q][0] for q in ks), sum(dur[q][1] for q in ks))
+        res[wl] = entry(name, dict(tot), d2, wl)
+        res[wl]["kernels_per_step"] = len(ks)
     else:
         k = max(cs, key=lambda q: cs[q]["_n"])  # the kernel of (almost) every launch of the workload
         res[wl] = entry(k, cs[k], dur, wl)
