@@ -109,7 +109,7 @@ static void rhs_me(const double* p, const double* x, const double* u, int nu, do
  * reference's vectors -- at 4e-16 relative (tests/test_oracle_golden.py); orc_rhs() keeps reporting rhs_me(). */
 static void rhs_me_kernel_order(const double* p, const double* x, const double* u, int nu, double* dx) {
   double iVl = 1 / p[0], iVg = 1 / p[1], inv_m = 1 / p[2], KlaVl = p[3] * p[0], X0 = p[5], Y6 = p[6];
-  double L = u[0], G = u[1];
+  const double alpha = u[0] * iVl, beta = u[1] * iVg, klap = iVl * KlaVl, eK = iVg * KlaVl; /* folded as the kernel folds them */
   if (nu != 2) {
     X0 = u[2];
     Y6 = u[3];
@@ -118,9 +118,9 @@ static void rhs_me_kernel_order(const double* p, const double* x, const double* 
     double X = x[2 * s], Y = x[2 * s + 1];
     double Xp = (s == 0) ? X0 : x[2 * s - 2];
     double Yn = (s == 4) ? Y6 : x[2 * s + 3];
-    double Q = KlaVl * fma(-(Y * Y), inv_m, X);
-    dx[2 * s] = iVl * fma(L, Xp - X, -Q);
-    dx[2 * s + 1] = iVg * fma(G, Yn - Y, Q);
+    double q = fma(-(Y * Y), inv_m, X);
+    dx[2 * s] = fma(alpha, Xp - X, -(klap * q));
+    dx[2 * s + 1] = fma(beta, Yn - Y, eK * q);
   }
 }
 
@@ -1082,7 +1082,7 @@ typedef struct {
 } me_ros_fac;
 static void me_ros_factor(const double* p, const double* u, const double* x, double theta, me_ros_fac* F) {
   const double iVl = 1 / p[0], iVg = 1 / p[1], inv_m = 1 / p[2], KlaVl = p[3] * p[0], ex = p[4];
-  const double alpha = iVl * u[0], beta = iVg * u[1], klap = iVl * KlaVl, e = iVg * KlaVl;
+  const double alpha = u[0] * iVl, beta = u[1] * iVg, klap = iVl * KlaVl, e = iVg * KlaVl;
   const double DX = theta + (alpha + klap);
   const double thb = theta + beta;
   F->iDX = 1.0 / DX;

@@ -215,11 +215,13 @@ struct MEImpl : MECoop<SQ> {
   static constexpr bool FULL = true;  // all kernel specialisations
   struct KP {
     double iVl, iVg, inv_m, KlaVl, e;
+    double klap, eK;  // Kla Vl / Vl and Kla Vl / Vg, folded for rhs() and ros_factor()
   };
   using CKP = const PCG_CONSTANT KP;
   template <class R>
   struct HoldT {
     R L, G, X0, Y6;
+    R a, c;  // through-flow rates L / Vl, G / Vg: held over the env step, so the divisions by the volumes are too
   };
   using Hold = HoldT<double>;
   PCG_HD static void prep(const double* r, int, int, double* kp_out, double* ddef) {
@@ -229,13 +231,15 @@ struct MEImpl : MECoop<SQ> {
     k.inv_m = 1 / r[2];
     k.KlaVl = r[3] * r[0];
     k.e = r[4];
+    k.klap = k.iVl * k.KlaVl;
+    k.eK = k.iVg * k.KlaVl;
     __builtin_memcpy(kp_out, &k, sizeof(k));
     ddef[0] = r[5];
     ddef[1] = r[6];
   }
   template <class R, class K>
-  PCG_DEV static HoldT<R> hold(const K&, const R (&u)[NA + NDM]) {
-    return HoldT<R>{u[0], u[1], u[2], u[3]};
+  PCG_DEV static HoldT<R> hold(const K& k, const R (&u)[NA + NDM]) {
+    return HoldT<R>{u[0], u[1], u[2], u[3], u[0] * k.iVl, u[1] * k.iVg};
   }
   // sort key of the work-queue kernel: the faster of the two through-flow rates sets the stiffness, and with it the
   // number of (stability-limited) RK steps of an env step -- correlation with the measured step counts 0.83
@@ -312,7 +316,7 @@ struct MEImpl : MECoop<SQ> {
   template <class K>
   PCG_DEV static void ros_factor(const K& k, const HoldT<double>& h, const double (&x)[NX], double theta, RosFac& F) {
 #pragma clang fp contract(off)
-    const double alpha = k.iVl * h.L, beta = k.iVg * h.G, klap = k.iVl * k.KlaVl, e = k.iVg * k.KlaVl;
+    const double alpha = h.a, beta = h.c, klap = k.klap, e = k.eK;
     const double DX = theta + (alpha + klap);
     const double thb = theta + beta;
     F.iDX = rcp_ieee(DX);  // (== 1.0 / DX bit for bit: DX is finite and positive or the step is rejected)
@@ -372,9 +376,19 @@ struct MEImpl : MECoop<SQ> {
       const R Xp = (s == 0) ? h.X0 : x[2 * s - 2];
       const R Yn = (s == 4) ? h.Y6 : x[2 * s + 3];
       if constexpr (SQ) {
-        const R Q = k.KlaVl * pk_fma(-(Y * Y), k.inv_m, X);     // Kla Vl (X - Y^2 / m)
+        // the reference's expressions (model_classes.py:370-412) with the constant factors folded (round 5): per stage
+        //   q = X - Y^2 / m,   dX = (L / Vl) (X' - X) - Kla q,   dY = (G / Vg) (Y" - Y) + (Kla Vl / Vg) q
+        // 8 fp64 operations against 9 (Q = Kla Vl q, then 1 / Vl and 1 / Vg over each sum): the explicit pair's attempt is
+        // 7 of these evaluations.  Twin: rhs_me_kernel_order() in oracle/pcg_oracle.c, operation for operation.
+#ifdef PCG_ME_RHS_UNFOLDED  // the form of rounds 1-4 (A/B builds: tools/fastlib.sh ... -DPCG_ME_RHS_UNFOLDED; not the oracle's twin)
+        const R Q = k.KlaVl * pk_fma(-(Y * Y), k.inv_m, X);
         dx[2 * s] = k.iVl * pk_fma(h.L, Xp - X, -Q);
         dx[2 * s + 1] = k.iVg * pk_fma(h.G, Yn - Y, Q);
+#else
+        const R q = pk_fma(-(Y * Y), k.inv_m, X);
+        dx[2 * s] = pk_fma(h.a, Xp - X, -(k.klap * q));
+        dx[2 * s + 1] = pk_fma(h.c, Yn - Y, k.eK * q);
+#endif
       } else {
         const R Q = k.KlaVl * (X - eq_curve<SQ>(Y, k.e, k.inv_m));
         dx[2 * s] = k.iVl * (h.L * (Xp - X) - Q);
