@@ -73,15 +73,19 @@ def entry(kname, c, dur, wl):
             # the same instruction count priced at the MEASURED issue cost of an fp64 wave-instruction (tools/issuebench.hip:
             # 2.1-2.5 ns per SIMD, i.e. ~5 cycles, not 4): the share of the launch its SIMDs spend issuing vector work
             e["valu_issue_time_frac_at_2p4ns"] = c["SQ_INSTS_VALU"] * 2.4 / 1024.0 / dur[kname][1]
-            # ... and priced BY CLASS (round 5: the flat 2.4 ns read 1.07 for me10 and cryst -- a third of their instructions are
-            # 32-bit moves / selects / integer work at 1.35 ns): fp64 add / mul / fma 2.4 ns, fp64 transcendental estimates 7.3 ns,
-            # fp32 transcendentals 3.65 ns, everything else 1.35 ns per wave-instruction and SIMD (profiles/r4/issuebench.txt)
+            # ... and priced BY CLASS in CYCLES against the launch's own busy cycles (round 5).  The flat 2.4 ns of round 4 read
+            # 1.07 for me10 and 1.09 for cryst: tools/issuebench.hip's 2.4 ns (~5 cycles at its ~2.0 GHz) is the cost of an fp64
+            # instruction in a DEPENDENT chain of one wave, not its issue slot -- a SIMD issues an fp64 wave-instruction in 4 cycles
+            # (16 lanes x 4), and these kernels run at 2.1-2.25 GHz.  Costs: fp64 add / mul / fma 4 cycles (architectural), fp64
+            # estimates (rcp / rsq) 16 (quarter rate; measured 17), fp32 transcendentals 8 (measured 8.6), everything else
+            # (32-bit moves, selects, integer, conversions) 3 (measured: v_mov_b32 / v_and_b32 1.35 ns at 2.26 GHz).
             if all(k in c for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")):
                 f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"]
                 t64, t32 = c["SQ_INSTS_VALU_TRANS_F64"], c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
                 rest = max(0.0, c["SQ_INSTS_VALU"] - f64 - t64 - t32)
                 e["valu_insts_by_class_per_launch"] = {"fp64_add_mul_fma": f64, "fp64_trans": t64, "fp32_trans": t32, "other": rest}
-                e["valu_issue_time_frac_by_class"] = (f64 * 2.4 + t64 * 7.3 + t32 * 3.65 + rest * 1.35) / 1024.0 / dur[kname][1]
+                e["valu_issue_cycles_by_class"] = {"fp64_add_mul_fma": 4, "fp64_trans": 16, "fp32_trans": 8, "other": 3}
+                e["valu_issue_time_frac_by_class"] = (f64 * 4.0 + t64 * 16.0 + t32 * 8.0 + rest * 3.0) / (1024.0 * cyc)
     e["build_id"] = BUILD_ID
     e["source"] = (f"profiles/{RND}/{wl}/rocprofv3_summary.txt (tools/prof_all.sh: FETCH_SIZE, WRITE_SIZE, SQ and GRBM counters in "
                    "separate --pmc passes with --kernel-trace only; FETCH_SIZE x 2 per MI355X_MICROARCH.md HBM section); NOT "
