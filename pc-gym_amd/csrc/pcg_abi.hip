@@ -1108,7 +1108,9 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       // Rodas4, launches of at most ~one full tile per CU (measured: 1024 envs per CU 0.361 -> 0.337 ms; 1366 per CU no
       // difference; 4096 per CU 1.47 -> 1.71 ms): ONE workgroup per CU on the instantiation that keeps the whole loop in
       // registers, every wave alone on its SIMD
-      bool w1 = r4q && k.queue_r4w1[pe] && p->q_tile1[pe] >= QBLOCK && io->B <= (int64_t)p->num_cus * 1200 &&
+      int w1_cap = 1200;  // envs per CU up to which the one-workgroup-per-CU shape is taken
+      if (const char* ev = std::getenv("PCG_Q_W1CAP")) w1_cap = std::atoi(ev);  // measurement switch
+      bool w1 = r4q && k.queue_r4w1[pe] && p->q_tile1[pe] >= QBLOCK && io->B <= (int64_t)p->num_cus * w1_cap &&
                 io->B > (int64_t)p->num_cus * QBLOCK;
       if (const char* ev = std::getenv("PCG_Q_W1")) w1 = w1 && std::atoi(ev) != 0;  // measurement switch
       if (w1) a.q_tile = (a.q_tile & ~0xFFFF) | p->q_tile1[pe];
@@ -1164,7 +1166,10 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       // do not survive in L2 between a lane's pick-up and its neighbours' -- 592 MB per launch against 114 MB of algorithm;
       // from LDS the launch moves 137 MB (1.21 x) and takes 1.7 % longer (two envs per lane instead of four for the
       // longest-first order; profiles/r4/queue_probe/).  PCG_Q_NOXLDS=1 keeps the full tile.
-      if (q_bpc == 1 && !wide && k.queue_lds_x(Tq) + sb > (size_t)(160 * 1024 - 2048) && !std::getenv("PCG_Q_NOXLDS") &&
+      // (a full tile whose state fits in the LEAN layout -- below -- is preferred to two half tiles)
+      const bool lean_fits = !a.fixup && k.queue_lds_x_lean && !std::getenv("PCG_Q_NOXLDS") && !std::getenv("PCG_Q_NOLEAN") &&
+                             k.queue_lds_x_lean(Tq, c.na + c.nd) + sb <= (size_t)(160 * 1024 - 2048) / q_bpc;
+      if (!lean_fits && q_bpc == 1 && !wide && k.queue_lds_x(Tq) + sb > (size_t)(160 * 1024 - 2048) && !std::getenv("PCG_Q_NOXLDS") &&
           !std::getenv("PCG_Q_TILE")) {
         const int64_t sub2 = (per + 2 * nsub - 1) / (2 * nsub);
         const int T2 = (int)((sub2 + 63) / 64 * 64) < qb ? qb : (int)((sub2 + 63) / 64 * 64);
@@ -1174,9 +1179,17 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
         }
       }
       size_t qsh = k.queue_lds(Tq) + sb;
-      if (k.queue_lds_x(Tq) + sb <= (size_t)(160 * 1024 - 2048) / q_bpc && !std::getenv("PCG_Q_NOXLDS")) {
+      const bool force_lean = std::getenv("PCG_Q_FORCE_LEAN") != nullptr;  // test switch: the lean layout wherever it fits
+      if (!force_lean && k.queue_lds_x(Tq) + sb <= (size_t)(160 * 1024 - 2048) / q_bpc && !std::getenv("PCG_Q_NOXLDS")) {
         a.q_tile |= 0x20000;
         qsh = k.queue_lds_x(Tq) + sb;
+      } else if (lean_fits && k.queue_lds_x_lean(Tq, c.na + c.nd) + sb <= (size_t)(160 * 1024 - 2048) / q_bpc) {  // (Tq may have changed)
+        // the LEAN tile layout (pcg_step_queue.hpp, QTile; round 5) where it is what lets the state in: no first-step and
+        // step-count arrays, only the configured disturbance values of the held input.  configs[4]'s extraction segment
+        // (349,524 envs = 683 per workgroup, two workgroups per CU: 98.8 KB each in the full layout, 76.2 in this one) moved
+        // 5.1 x its algorithmic bytes with its state in the batch (profiles/r5/pmc.json)
+        a.q_tile |= 0x20000 | 0x40000;
+        qsh = k.queue_lds_x_lean(Tq, c.na + c.nd) + sb;
       }
       if (a.fixup) {  // fix-up launch: a tile is a compact list of up to Tq MARKED envs (+ 4 bytes per slot: which env), the
         // state stays in the batch

@@ -1774,6 +1774,7 @@ struct Kernels {
   bool queue_default;                // route adaptive plans to it unless told otherwise (models with a cost key)
   size_t (*queue_lds)(int);          // LDS bytes of a tile of T slots
   size_t (*queue_lds_x)(int);        // ... with the tile's state parked in LDS as well
+  size_t (*queue_lds_x_lean)(int, int);  // ... in the lean layout (tile size, stored input rows: pcg_step_queue.hpp QTile)
   StepFn pipe[2][2];                 // software-pipelined lean kernel [lean_scheme(integrator)][EPL-1] (may be null)
   StepFn pipe_ar[2][2];              // the same with the same-launch auto-reset path compiled in
   StepFn roll_lean[2];               // RK4 lean fused rollout [EPL-1] (may be null)
@@ -1851,6 +1852,7 @@ Kernels make_kernels() {
     k.queue[1] = step_kernel_queue<M, true, true>;
     k.queue_lds = QLayout<M>::bytes;
     k.queue_lds_x = QLayout<M>::bytes_x;
+    k.queue_lds_x_lean = QLayout<M>::bytes_x_lean;
     // Measured (tools/user_model_probe.py, cstr B = 2^20 at 1e-8: ~4 attempts per env step): 90 us through the queue
     // against 38 us for the classic kernel -- sorting, parking and refilling cost more than a cheap env's whole
     // integration.  The queue is the default only where a model declares a cost key, i.e. where the step count is

@@ -49,6 +49,63 @@ struct has_cost_key : tt::false_type {};
 template <class M>
 struct has_cost_key<M, tt::void_t<decltype(M::COST_KEY)>> : tt::true_type {};
 
+// ---- what phase 2 knows about its tile (LDS arrays of the layout below) ------------------------------------------------
+// LEAN layout (round 5; the host picks it where it is what lets the tile's STATE live in LDS too, QLayout::bytes_x): no
+// first-step array (the step size is recomputed where an env is picked up: the same statements on the same values as where it
+// was parked), the two step counts packed into one word (17 + 15 bits, saturating: exact up to max_steps = 131,071 -- the
+// default budget is 100,000; writing them straight to the nsteps buffer from phase 2 was measured first: 4-byte scattered
+// stores cost a 64-byte read-modify-write each, 90 MB per launch of configs[4]'s segment), and of the held input only the
+// action and the CONFIGURED disturbance values (the model's other disturbance inputs are plan constants).
+template <class M>
+struct QTile {
+  const double* us;       // [nus][T]
+  const double* hs;       // [T] first step size, or null (lean)
+  int32_t *accs, *rejs;   // [T]; lean: accs holds both counts packed, rejs is null
+  uint8_t* flag;          // [T] bits 0-1: PCG_ST_* of the integration, bit 2: pre-step "done"
+  int T;
+  bool lean;
+  int nd;                          // configured disturbances (lean: rows NA .. NA + nd - 1 of us)
+  const PCG_CONSTANT int32_t* d_slot;    // which model input each of them drives
+  const PCG_CONSTANT double* d_default;  // the model's disturbance inputs when not configured
+  static constexpr int ACC_BITS = 17, ACC_MAX = (1 << 17) - 1, REJ_MAX = (1 << 15) - 1;
+  // the held input of a slot
+  PCG_DEV void load_u(int slot, double (&u)[M::NA + M::NDM]) const {
+    constexpr int NA = M::NA, NDM = M::NDM, NU = NA + NDM;
+    if (!lean) {
+#pragma unroll
+      for (int i = 0; i < NU; ++i) u[i] = us[(size_t)i * T + slot];
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) u[i] = us[(size_t)i * T + slot];
+#pragma unroll
+    for (int j = 0; j < NDM; ++j) u[NA + j] = d_default[j];
+#pragma unroll
+    for (int k = 0; k < NDM; ++k)
+      if (k < nd) {
+        const double v = us[(size_t)(NA + k) * T + slot];
+        const int sl = d_slot[k];
+#pragma unroll
+        for (int j = 0; j < NDM; ++j) u[NA + j] = (j == sl) ? v : u[NA + j];
+      }
+  }
+  // a finished env's result bookkeeping
+  PCG_DEV void finish(int slot, int acc, int rej, int st) const {
+    if (lean) {
+      accs[slot] = (acc < ACC_MAX ? acc : ACC_MAX) | ((rej < REJ_MAX ? rej : REJ_MAX) << ACC_BITS);
+    } else {
+      accs[slot] = acc;
+      rejs[slot] = rej;
+    }
+    flag[slot] |= (uint8_t)st;
+  }
+  PCG_DEV void counts(int slot, int& acc, int& rej) const {
+    const int v = accs[slot];
+    acc = lean ? (v & ACC_MAX) : v;
+    rej = lean ? (int)((unsigned)v >> ACC_BITS) : rejs[slot];
+  }
+};
+
 // ---- DOPRI5 in resumable form: the state one lane carries for the env it is integrating -------------------------
 template <int NX>
 struct DpLane {
@@ -233,12 +290,13 @@ PCG_DEV int rodas4_attempt(const K& kp, const typename M::Hold& hold, const F& f
 // ---- phase 2: the work queue of one tile.  (Tried as a real, non-inlined function so that the loop would own the
 // whole register file: the call ABI's save / restore made it worse -- 772 B of scratch against 140.)
 template <class M, int INTEG = PCG_INT_DOPRI5, int QB = QBLOCK, bool COMPACT = false>
-PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, double* us, const double* hs,
-                                                          const uint32_t* sortbuf, int32_t* accs, int32_t* rejs,
-                                                          int32_t* flag, int32_t* next, int T, int n, int refill, double dt, double dt_edge,
+PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, const QTile<M>& Q,
+                                                          const uint32_t* sortbuf,
+                                                          int32_t* next, int n, int refill, double dt, double dt_edge,
                                                           double h_floor, double rtol, double atol, int max_steps,
                                                           double ep_c = 0.0, int ep_kmax = 0, int prio_h = 0, int rot = 0,
                                                           unsigned long long* qst = nullptr, const int32_t* eidx = nullptr, int first = 0) {
+  const int T = Q.T;
   constexpr int NX = M::NX, NU = M::NA + M::NDM;
   // COMPACT (fix-up launch of a guarded plan): the slots are a compact list of marked envs, eidx[slot] is the env's position
   // in the state window xg; otherwise a slot is its own position
@@ -271,9 +329,7 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
       if (slot >= 0) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + xpos(slot)] = __builtin_nan("");
-        accs[slot] = L.acc;
-        rejs[slot] = L.rej;
-        flag[slot] |= PCG_ST_MAX_STEPS;
+        Q.finish(slot, L.acc, L.rej, PCG_ST_MAX_STEPS);
       }
       break;
     }
@@ -286,16 +342,28 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
 #pragma unroll
       for (int i = 0; i < NX; ++i) L.x[i] = xg[(size_t)i * xstride + xpos(slot)];
       double u[NU];
-#pragma unroll
-      for (int i = 0; i < NU; ++i) u[i] = us[(size_t)i * T + slot];
-      L.h = hs[slot];
+      Q.load_u(slot, u);
       L.t = 0.0;
       L.acc = L.rej = 0;
       L.rejected_last = false;
+      const typename M::Hold hold = M::hold(kp, u);
+      const RhsFn<M> f{kp, hold};
       if constexpr (INTEG == PCG_INT_DOPRI5) {
-        const typename M::Hold hold = M::hold(kp, u);
-        const RhsFn<M> f{kp, hold};
-        f(L.x, L.k1);
+        if (Q.lean) {  // (the statements of park(): k1 = f(x) and the first step size)
+          double d1;
+          L.h = dopri5_h_init<NX>(f, L.x, L.k1, NX, dt, rtol, atol, d1);
+        } else {
+          L.h = Q.hs[slot];
+          f(L.x, L.k1);
+        }
+      } else {
+        if (Q.lean) {
+          double f0[NX], d1;
+          f(L.x, f0);
+          L.h = rodas4_h_init<NX>(L.x, f0, NX, dt, rtol, atol, d1);
+        } else {
+          L.h = Q.hs[slot];
+        }
       }
       fresh = false;
     }
@@ -348,8 +416,7 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
       // the held input stays in LDS between attempts (a few ds_read per ~1000-instruction attempt) instead of in
       // registers: the resumable loop sits right at the 256-register budget
       double u[NU];
-#pragma unroll
-      for (int i = 0; i < NU; ++i) u[i] = us[(size_t)i * T + slot];
+      Q.load_u(slot, u);
       const typename M::Hold hold = M::hold(kp, u);
       const RhsFn<M> f{kp, hold};
       int st;
@@ -363,9 +430,7 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
         poison_if_failed<NX>(st, L.x);
 #pragma unroll
         for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + xpos(slot)] = L.x[i];
-        accs[slot] = L.acc;
-        rejs[slot] = L.rej;
-        flag[slot] |= st;
+        Q.finish(slot, L.acc, L.rej, st);
         slot = -1;
       }
     }
@@ -383,10 +448,12 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
 // iteration with an idle group, heaviest first).  A wave leaves when the heavy queue is empty and its groups are done, and
 // joins the pair's queue (queue_integrate).  The env's state and step size are replicated over its group's lanes.
 template <class M, int QB, bool XL = false>
-PCG_DEV void coop_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, const double* us, const double* hs,
-                            const uint32_t* sortbuf, int32_t* accs, int32_t* rejs, int32_t* flag, int32_t* cnext, int T, int nh,
+PCG_DEV void coop_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, const QTile<M>& Q,
+                            const uint32_t* sortbuf, int32_t* cnext, int nh,
                             double dt, double dt_edge, double h_floor, double rtol, double atol, int max_steps, double ep_c,
                             int ep_kmax, unsigned long long* qst = nullptr) {
+  const int T = Q.T;
+  (void)T;
   constexpr int NX = M::NX, NU = M::NA + M::NDM;
 #ifdef PCG_QSTATS  // measurement build (tools/queue_probe.py): big steps this wave executed, busy groups summed over them
   unsigned long long qs_big = 0, qs_groups = 0;
@@ -408,9 +475,7 @@ PCG_DEV void coop_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, c
       if (slot >= 0 && j == 0) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + slot] = __builtin_nan("");
-        accs[slot] = G.acc;
-        rejs[slot] = G.rej;
-        flag[slot] |= PCG_ST_MAX_STEPS;
+        Q.finish(slot, G.acc, G.rej, PCG_ST_MAX_STEPS);
       }
       break;
     }
@@ -427,7 +492,18 @@ PCG_DEV void coop_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, c
           slot = (int)(sortbuf[q] & (QSORT - 1));
 #pragma unroll
           for (int i = 0; i < NX; ++i) G.x[i] = xg[(size_t)i * xstride + slot];
-          G.H = hs[slot];
+          if (Q.lean) {  // (the statements of park() for a heavy env)
+            double u0[NU], f0[NX];
+            Q.load_u(slot, u0);
+            const typename M::Hold hold0 = M::hold(kp, u0);
+            const RhsFn<M> ff{kp, hold0};
+            ff(G.x, f0);
+            const double d0 = rms_scaled<NX>(G.x, G.x, G.x, NX, rtol, atol);
+            const double d1 = rms_scaled<NX>(f0, G.x, G.x, NX, rtol, atol);
+            G.H = seulex_h_init(d0, d1, dt);
+          } else {
+            G.H = Q.hs[slot];
+          }
           G.t = 0.0;
           G.acc = G.rej = 0;
           G.rejected_last = false;
@@ -444,8 +520,7 @@ PCG_DEV void coop_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, c
 #endif
     if (slot >= 0) {
       double u[NU];
-#pragma unroll
-      for (int i = 0; i < NU; ++i) u[i] = us[(size_t)i * T + slot];
+      Q.load_u(slot, u);
       const typename M::Hold hold = M::hold(kp, u);
       const RhsFn<M> f{kp, hold};
       const EpWeights<M, typename M::CKP> ep{kp, u, ep_c, ep_kmax};
@@ -455,9 +530,7 @@ PCG_DEV void coop_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, c
         if (j == 0) {
 #pragma unroll
           for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + slot] = G.x[i];
-          accs[slot] = G.acc;
-          rejs[slot] = G.rej;
-          flag[slot] |= st;
+          Q.finish(slot, G.acc, G.rej, st);
         }
         slot = -1;
       }
@@ -527,17 +600,23 @@ PCG_DEV void sort_tile(uint32_t* sortbuf) {
   __syncthreads();
 }
 
-// LDS layout of one tile (T slots): us[NU][T] | hs[T] | sortbuf[QSORT] u32 | acc[T] rej[T] flag[T] i32 | next
+// LDS layout of one tile (T slots):
+//   us[nus][T] | hs[T] (-) | sortbuf[sort_words(T)] u32 | acc[T] i32 | rej[T] i32 (-) | flag[T] u8 (padded to 8) | 4 counters | xs ...
+// (-) not in the LEAN layout (QTile), where nus = NA + configured disturbances instead of NA + NDM and acc holds both counts.
 template <class M>
 struct QLayout {
   static constexpr int NU = M::NA + M::NDM;
-  PCG_HD static size_t bytes(int T) {
-    return sizeof(double) * (size_t)(NU + 1) * T + sizeof(uint32_t) * QSORT + sizeof(int32_t) * 3 * (size_t)T + 16;
+  PCG_HD static int sort_words(int T) { return T <= QSORT / 4 ? QSORT / 4 : (T <= QSORT / 2 ? QSORT / 2 : QSORT); }
+  PCG_HD static size_t bytes_l(int T, bool lean, int nus) {
+    return sizeof(double) * (size_t)(lean ? nus : NU + 1) * T + sizeof(uint32_t) * (size_t)sort_words(T) +
+           sizeof(int32_t) * (lean ? 1 : 2) * (size_t)((T + 1) & ~1) + (size_t)((T + 7) & ~7) + 16;
   }
+  PCG_HD static size_t bytes(int T) { return bytes_l(T, false, NU); }
   // with the tile's STATE parked in LDS too (xs[NX][T], round 3): every access of the batch stays coalesced -- phase 1
   // reads x once, phase 3 writes it once -- instead of NX scattered 8-byte loads / stores per env whenever a lane picks
   // up / finishes one (PMC, round 2: 2.3-4.3x the algorithmic bytes).  Used when it fits beside the other workgroups.
   PCG_HD static size_t bytes_x(int T) { return bytes(T) + sizeof(double) * (size_t)M::NX * T; }
+  PCG_HD static size_t bytes_x_lean(int T, int nus) { return bytes_l(T, true, nus) + sizeof(double) * (size_t)M::NX * T; }
 };
 
 // WAVES: waves per SIMD = workgroups per CU the register allocator is asked to leave room for (0 = the model's default,
@@ -559,20 +638,23 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
   const int refill_hi = (A.q_tile >> 20) & 0x7F;  // measurement switch (PCG_Q_REFILL); 0 = the default
   // (the default depends on the tile: see where it is used)
   static_assert(QSORT == (1 << QSLOT_BITS), "slot index field");
+  const bool lean = (A.q_tile & 0x40000) != 0;  // the lean LDS layout (QTile; host: it is what lets the state fit)
+  const int nus = lean ? NA + c.nd : NU;
   double* us = lds;
-  double* hs = us + (size_t)NU * T;
-  uint32_t* sortbuf = reinterpret_cast<uint32_t*>(hs + T);
-  int32_t* accs = reinterpret_cast<int32_t*>(sortbuf + QSORT);
-  int32_t* rejs = accs + T;
-  int32_t* flag = rejs + T;   // bits 0-1: PCG_ST_* of the integration, bit 2: pre-step "done"
-  int32_t* next = flag + T;   // queue head (the first min(n, 256) sorted slots are handed out directly)
+  double* hs = us + (size_t)nus * T;           // (not in the lean layout)
+  uint32_t* sortbuf = reinterpret_cast<uint32_t*>(hs + (lean ? 0 : T));
+  const int Te = (T + 1) & ~1;  // (8-byte alignment of what follows)
+  int32_t* accs = reinterpret_cast<int32_t*>(sortbuf + QLayout<M>::sort_words(T));  // (lean layout: both counts packed)
+  int32_t* rejs = accs + Te;                                                        // (not in the lean layout)
+  uint8_t* flag = reinterpret_cast<uint8_t*>(lean ? rejs : rejs + Te);   // bits 0-1: PCG_ST_* of the integration, bit 2: pre-step "done"
+  int32_t* next = reinterpret_cast<int32_t*>(flag + ((T + 7) & ~7));   // queue head (the first min(n, 256) sorted slots are handed out directly)
   int32_t* nq = next + 1;     // fix-up launch: number of marked envs parked in this round
   int32_t* nheavy = next + 2; // cooperative rule (Rodas4): heavy envs of the tile = its first sorted slots ...
   int32_t* cnext = next + 3;  // ... and the head of their queue
   constexpr bool COOP = INTEG == PCG_INT_RODAS4 && has_coop<M>::value && !FIX;
   const bool coop = COOP && c.coop_thr > 0.0;
   const bool xlds = (A.q_tile & 0x20000) != 0;  // the tile's state lives in LDS (host: it fits)
-  double* xs = reinterpret_cast<double*>(next + 4 + (T & 1));  // [NX][T] when xlds (8-byte aligned)
+  double* xs = reinterpret_cast<double*>(next + 4);  // [NX][T] when xlds (8-byte aligned: every array before it is)
   int32_t* eidx = reinterpret_cast<int32_t*>(xs);  // fix-up launch: env (relative to the workgroup's range) of a compact slot
   double* sched_l = xs + (xlds ? (size_t)NX * T : fix ? (size_t)(T + 1) / 2 : 0);  // per-env-t schedule tables behind the tile
   if (PER_ENV_T) stage_schedules(A, c, sched_l);
@@ -638,13 +720,21 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
       } else {
         h = dopri5_h_init<NX>(f, x, k1, NX, dt, rtol, atol, d1);
       }
+      if (lean) {  // the action and the configured disturbance values (pre.dv); the first step is recomputed at pick-up
 #pragma unroll
-      for (int i = 0; i < NU; ++i) us[(size_t)i * T + s] = pre.u[i];
+        for (int i = 0; i < NA; ++i) us[(size_t)i * T + s] = pre.u[i];
+#pragma unroll
+        for (int k = 0; k < NDM; ++k)
+          if (k < c.nd) us[(size_t)(NA + k) * T + s] = pre.dv[k];
+      } else {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) us[(size_t)i * T + s] = pre.u[i];
+        hs[s] = h;
+      }
       if (xlds) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xs[(size_t)i * T + s] = x[i];
       }
-      hs[s] = h;
       flag[s] = pre.done_pre ? 4 : 0;
       float key;
       // stability-limited part (the model's rate x dt) + the initial transient's share (ln of the scaled |f(x0)|,
@@ -716,6 +806,7 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
     // wave -- is worth batching (configs[4] shard: 0.916 ms at 8, 0.929 at 2; profiles/r2/queue_refill_sweep.txt)
     const int refill = refill_hi ? refill_hi : (n <= 2 * QB ? 2 : QREFILL);
     PCG_QS(2);
+    const QTile<M> Q{us, lean ? nullptr : hs, accs, lean ? nullptr : rejs, flag, T, lean, c.nd, c.d_slot, c.d_default};
     int nh = 0;
     if constexpr (COOP) {
       nh = *nheavy;  // (uniform; written before the sort's barriers)
@@ -724,13 +815,13 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
       const int coop_waves = (A.q_tile >> 27) & 0xF;
       if (nh > 0 && (coop_waves == 0 || (tid >> 6) < coop_waves)) {
         if (A.q_prio > 0) __builtin_amdgcn_s_setprio(3);  // the heavy envs are the launch's critical path
-        coop_integrate<M, QB>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, cnext, T, nh, dt,
+        coop_integrate<M, QB>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, Q, sortbuf, cnext, nh, dt,
                               c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, qst);
         if (A.q_prio > 0) __builtin_amdgcn_s_setprio(0);
       }
     }
     PCG_QS(13);
-    queue_integrate<M, INTEG, QB, FIX>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, us, hs, sortbuf, accs, rejs, flag, next, T, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, A.q_prio,
+    queue_integrate<M, INTEG, QB, FIX>(&kp, xlds ? xs : A.x + base, xlds ? (int64_t)T : B, Q, sortbuf, next, n, refill, dt, c.dt_edge, c.h_floor, rtol, atol, c.max_steps, c.ep_c, c.ep_kmax, A.q_prio,
                               (A.q_prio > 0 && blockIdx.x >= gridDim.x / 2) ? 2 * 64 : 0, qst, fix ? eidx : nullptr, nh);
     if (A.q_prio > 0) __builtin_amdgcn_s_setprio(0);
     PCG_QS(3);
@@ -744,8 +835,7 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
       EnvPre<M> pre;
 #pragma unroll
       for (int i = 0; i < NX; ++i) x[i] = xlds ? xs[(size_t)i * T + s] : A.x[(size_t)i * B + e];  // written by phase 2 (same workgroup, behind a barrier)
-#pragma unroll
-      for (int i = 0; i < NU; ++i) pre.u[i] = us[(size_t)i * T + s];
+      Q.load_u(s, pre.u);
 #pragma unroll
       for (int k = 0; k < PCG_MAX_NDM; ++k) pre.dv[k] = 0.0;
 #pragma unroll
@@ -760,8 +850,10 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
       const int fl = flag[s];
       pre.done_pre = (fl & 4) != 0;
       if (A.nsteps) {
-        A.nsteps[e] = accs[s];
-        A.nsteps[B + e] = rejs[s];
+        int na_, nr_;
+        Q.counts(s, na_, nr_);
+        A.nsteps[e] = na_;
+        A.nsteps[B + e] = nr_;
       }
       EnvOut<M> out;
       env_post<M, PER_ENV_T, EXTRAS>(A, c, sched_l, e, t, pre, x, finite_status<NX>(fl & 3, x, NX), out);

@@ -126,3 +126,49 @@ def test_rule_on_and_off_are_both_in_class_and_the_rule_shortens_the_chain():
         att_on, att_off = on.nsteps.sum(dim=0), off.nsteps.sum(dim=0)
         assert att_on.max().item() < att_off.max().item() and att_on.max().item() <= 80, (att_on.max().item(), att_off.max().item())
     on.close(), off.close()
+
+
+@pytest.mark.parametrize("integrator", ["rodas4", "dopri5"])
+@pytest.mark.parametrize("per_env_t", [False, True])
+def test_lean_tile_layout_is_the_full_one_bit_for_bit(integrator, per_env_t, monkeypatch):
+    """The work-queue kernel's LEAN tile layout (round 5: no first-step and step-count arrays in LDS, only the configured
+    disturbance values of the held input -- what lets the tile's state live in LDS where two workgroups share a CU, e.g. the
+    extraction segment of BASELINE configs[4]) against the full layout and the classic kernel: every output bitwise equal,
+    step counts included (written from phase 2 in the lean layout), with a configured disturbance and a constraint, and
+    against the oracle."""
+    torch = _torch()
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    monkeypatch.setenv("PCG_Q_FORCE", "1")
+    p = copy.deepcopy(SC.scenarios()["me_dist_cons"]["env_params"])
+    p.update(integrator=integrator)
+    if integrator == "rodas4":
+        p.update(cooperative={"thr": 48})
+    B = 2100
+    full = VecEnv(p, n_envs=B, seed=6, per_env_t=per_env_t)
+    cl = VecEnv(p, n_envs=B, seed=6, per_env_t=per_env_t, variant=1)
+    monkeypatch.setenv("PCG_Q_FORCE_LEAN", "1")
+    lean = VecEnv(p, n_envs=B, seed=6, per_env_t=per_env_t)
+    orc = O.OracleEnv(full.spec, B, seed=6, per_env_t=per_env_t)
+    for e in (full, cl, lean, orc):
+        e.reset()
+    rng = np.random.default_rng(12)
+    for i in range(6):
+        a = _heavy_actions(rng, 2, B, 0.2)
+        if not full.spec.normalise_a:
+            a = (a + 1) * (full.spec.a_high - full.spec.a_low)[:, None] / 2 + full.spec.a_low[:, None]
+        at = torch.tensor(a, device=full.device)
+        monkeypatch.delenv("PCG_Q_FORCE_LEAN")
+        full.step(at), cl.step(at)
+        monkeypatch.setenv("PCG_Q_FORCE_LEAN", "1")
+        lean.step(at)
+        orc.step(a)
+        for other in (full, cl):
+            assert torch.equal(lean.x, other.x) and torch.equal(lean.nsteps, other.nsteps) and torch.equal(lean.rew, other.rew), i
+            assert torch.equal(lean.obs_soa, other.obs_soa) and torch.equal(lean.viol, other.viol) and torch.equal(lean.done, other.done), i
+        tol = 1e-11 if integrator == "rodas4" else 1e-10
+        H.adaptive_check("multistage_extraction", lean.x.cpu().numpy(), orc.x, lean.nsteps.cpu().numpy(), orc.nsteps,
+                         ("lean", integrator, per_env_t, i), tol=tol)
+    for e in (full, cl, lean):
+        e.close()
