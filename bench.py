@@ -64,6 +64,8 @@ def flops_per_env_step(model, nx, integrator, attempts, substeps=1):
         return substeps * (11 * f + 2 * (49 + 11) * nx)
     if integrator == "rodas4":
         return attempts * (6 * f + 25 * 2 * nx + 60 + 6 * 66 + 4 * nx)
+    if integrator == "rodas5":  # 8 stages: 7 RHS after f(x) + f(x) itself, 17 + 28 stage axpys, 8 solves
+        return attempts * (8 * f + 45 * 2 * nx + 60 + 8 * 66 + 4 * nx)
     return (2 + 6 * attempts) * (f + 2 * 6 * nx)
 
 
@@ -479,7 +481,7 @@ def main():
     ap.add_argument("--substeps", type=int, default=None,
                     help="cstr workload: RK4 sub-steps per env step (1 = the headline; other values are probes)")
     ap.add_argument("--status", type=int, default=1, help="write the per-env status byte (0 = off, A/B)")
-    ap.add_argument("--integrator", default=None, choices=["dopri5", "rodas4", "rodas3", "rk4", "cv8", "rk4g", "tsit5g"],
+    ap.add_argument("--integrator", default=None, choices=["dopri5", "rodas4", "rodas5", "rodas3", "rk4", "cv8", "rk4g", "tsit5g"],
                     help="me10 / me20 / mixed: integrator of the extraction envs; four_tank / cstr_safe: the plan "
                          "(default: the workload's named one)")
     ap.add_argument("--coop-thr", type=float, default=None,
@@ -548,6 +550,8 @@ def main():
                 segs_global[2][0].update(rtol=1e-8, atol=1e-8)
         if args.coop_thr is not None:
             segs_global[2][0]["cooperative"] = {"thr": args.coop_thr} if args.coop_thr > 0 else False
+        if os.environ.get("PCG_BENCH_ME_TOL"):  # measurement switch (tools/sessions): tolerance of the extraction envs' plan
+            segs_global[2][0].update(rtol=float(os.environ["PCG_BENCH_ME_TOL"]), atol=float(os.environ["PCG_BENCH_ME_TOL"]))
         K = args.steps if args.steps is not None else 118
         W = args.warmup if args.warmup is not None else 12
         menv = make_mixed_sharded_env(segs_global, rank=rank, world=world, device=dev, seed=1234, auto_reset=True,
@@ -606,9 +610,12 @@ def main():
         if args.integrator and args.workload in ("four_tank", "cstr_safe"):
             params["integrator"] = args.integrator
             wl_name = wl_name.replace("cv8x1", args.integrator).replace("default-plan(tsit5g)", "plan(" + args.integrator + ")")
-        if args.coop_thr is not None and params.get("integrator") == "rodas4":
+        if args.coop_thr is not None and params.get("integrator") in ("rodas4", "rodas5"):
             params["cooperative"] = {"thr": args.coop_thr} if args.coop_thr > 0 else False
             wl_name += f"+coop{args.coop_thr:g}"
+        if os.environ.get("PCG_BENCH_ME_TOL") and args.workload in ("me10", "me10_ros4", "me20"):  # measurement switch
+            params.update(rtol=float(os.environ["PCG_BENCH_ME_TOL"]), atol=float(os.environ["PCG_BENCH_ME_TOL"]))
+            wl_name += "+tol" + os.environ["PCG_BENCH_ME_TOL"]
         B = args.batch or Bd
         K = args.steps if args.steps is not None else Kd
         W = args.warmup if args.warmup is not None else Wd

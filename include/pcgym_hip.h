@@ -49,7 +49,7 @@ typedef unsigned long uintptr_t;
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 12
+#define PCG_ABI_VERSION 13
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -176,7 +176,16 @@ enum pcg_integrator {
                           plan: 11 evaluations instead of 20 at a smaller error).  Kernels of PCG_INT_RK4: lean pipelined
                           kernel (small models), general kernel, pcg_step_autoreset, pcg_graph_*, pcg_integrate,
                           pcg_rollout; not with per-env uncertain parameters */
-  PCG_INT_COUNT = 8
+  PCG_INT_RODAS5 = 8,  /* stiff-capable, fifth order (ABI 13): adaptive Rodas5 (Di Marzo's coefficient set, the one of Hairer &
+                          Wanner's RODAS5 code: 8-stage linearly implicit Rosenbrock 5(4) pair, gamma = 0.19, L-stable, stiffly
+                          accurate).  Everything but the tableau and the controller's exponent (quantised factor 0.9 E^-1/5 in
+                          [0.2, 6]) is PCG_INT_RODAS4's: linear-algebra policy (structured W in registers / dense W in LDS),
+                          error norm, END-POINT ERROR CONTROL (cfg.ep_frac / ep_kmax), cooperative rule (cfg.coop_thr), first
+                          step, failure semantics, entry points.  The extraction cascade is accuracy-bound under the fourth-
+                          order pair (17.6 attempts per env step for 1e-6 of a 1e-13 solve); this pair reaches the same class in
+                          0.6 x the attempts at 8 stages against 6: the default plan of multistage_extraction.  The reference
+                          integrates with CVODES BDF, variable order up to 5 (integrator.py:163-182) */
+  PCG_INT_COUNT = 9
 };
 
 /* cfg.flags */

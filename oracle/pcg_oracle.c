@@ -1254,6 +1254,160 @@ static int rodas4(const orc_model* m, double* x, const double* u, double dt, dou
 }
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Rodas5 (Di Marzo's coefficient set, the METH of Hairer & Wanner's RODAS5 code): 8-stage linearly implicit Rosenbrock
+ * 5(4) pair, gamma = 0.19, L-stable, stiffly accurate, in the same transformed form as Rodas4 above:
+ *     (I/(gamma h) - J) U_i = f(x + sum_j a_ij U_j) + sum_j (c_ij / h) U_j,
+ *     y_7 = y_6 + U_6,  y_8 = y_7 + U_7,  x_new = y_8 + U_8,  error estimate = U_8 (against the embedded order-4 solution y_8).
+ * The 17 order-5 conditions are checked by tests/test_rodas5.py (convergence order on a nonlinear problem, row sums,
+ * quadrature conditions, stiff accuracy re-derived from (a, C)).  Linear algebra, error norm, end-point weights,
+ * first step and failure semantics: rodas4's; factor = clip(Q(safety E^-1/5), facmin, facmax).
+ * Twin of rodas5() in pc-gym_amd/csrc/pcg_integrators.hpp.
+ * ------------------------------------------------------------------------------------------------------------- */
+#define R5_S 8
+static const double R5_GAM = 0.19;
+static const double R5_A[6][5] = {
+    {0, 0, 0, 0, 0},
+    {2.0, 0, 0, 0, 0},
+    {3.040894194418781, 1.041747909077569, 0, 0, 0},
+    {2.576417536461461, 1.622083060776640, -0.9089668560264532, 0, 0},
+    {2.760842080225597, 1.446624659844071, -0.3036980084553738, 0.2877498600325443, 0},
+    {-14.09640773051259, 6.925207756232704, -41.47510893210728, 2.343771018586405, 24.13215229196062}};
+static const double R5_C[8][7] = {
+    {0, 0, 0, 0, 0, 0, 0},
+    {-10.31323885133993, 0, 0, 0, 0, 0, 0},
+    {-21.04823117650003, -7.234992135176716, 0, 0, 0, 0, 0},
+    {32.22751541853323, -4.943732386540191, 19.44922031041879, 0, 0, 0, 0},
+    {-20.69865579590063, -8.816374604402768, 1.260436877740897, -0.7495647613787146, 0, 0, 0},
+    {-46.22004352711257, -17.49534862857472, -289.6389582892057, 93.60855400400906, 318.3822534212147, 0, 0},
+    {34.20013733472935, -14.15535402717690, 57.82335640988400, 25.83362985412365, 1.408950972071624, -6.551835421242162, 0},
+    {42.57076742291101, -13.80770672017997, 93.98938432427124, 18.77919633714503, -31.58359187223370, -6.685968952921985,
+     -5.810979938412932}};
+ORC_EXPORT void orc_rodas5_tableau(double* a15, double* c28, double* gam) {
+  int k = 0;
+  for (int i = 1; i < 6; ++i)
+    for (int j = 0; j < i; ++j) a15[k++] = R5_A[i][j];
+  k = 0;
+  for (int i = 1; i < 8; ++i)
+    for (int j = 0; j < i; ++j) c28[k++] = R5_C[i][j];
+  *gam = R5_GAM;
+}
+static double g_r5_h0 = 10.0, g_r5_safety = 0.9, g_r5_facmax = 6.0, g_r5_facmin = 0.2; /* (calibration hook below; r5::H0 of the kernels) */
+static double g_r5_hcap = 2.0;
+ORC_EXPORT void orc_set_rodas5_hcap(double kb) { g_r5_hcap = kb; }
+ORC_EXPORT void orc_set_rodas5_ctrl(double h0, double safety, double facmax, double facmin) {
+  g_r5_h0 = h0; g_r5_safety = safety; g_r5_facmax = facmax; g_r5_facmin = facmin;
+}
+static int rodas5(const orc_model* m, double* x, const double* u, double dt, double rtol, double atol, int max_steps,
+                  double ep_frac, int ep_kmax, int32_t* nacc, int32_t* nrej) {
+  int n = m->nx;
+  const int structured = g_ros4_structured && m->model_id == PCG_MODEL_ME;
+  double f0[MAXNX], U[R5_S][MAXNX], y[MAXNX], fy[MAXNX], r[MAXNX];
+  double* W = structured ? 0 : (double*)malloc(sizeof(double) * (size_t)n * n);
+  int piv[MAXNX];
+  me_ros_fac F;
+  int acc = 0, rej = 0, status = 0;
+  rhs_int(m, x, u, f0);
+  double h;
+  {
+    double d0 = rms_scaled(x, x, x, n, rtol, atol);
+    double d1 = rms_scaled(f0, x, x, n, rtol, atol);
+    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    h = fmin(qtrunc6(g_r5_h0 * h0), dt);
+  }
+  const double ep_c = (ep_kmax > 0) ? ep_frac * 1.4426950408889634 : 0.0;
+  double t = 0.0;
+  int rejected_last = 0;
+  for (;;) {
+    int last = 0;
+    if (acc + rej >= max_steps) { status = 1; break; }
+    if (t + h >= dt * (1.0 - 1e-14)) { h = dt - t; last = 1; }
+    const double ih = 1.0 / h, igh = ih * (1.0 / R5_GAM);
+    int lu_ok;
+    if (structured) {
+      me_ros_factor(m->p, u, x, igh, &F);
+      lu_ok = F.ok;
+    } else {
+      double xmax = 0.0;
+      for (int i = 0; i < n; ++i) xmax = fmax(xmax, fabs(x[i]));
+      const double wfloor = atol / rtol + 1e-12 * xmax + 1e-100;
+      for (int j = 0; j < n; ++j) {
+        double xj = x[j];
+        double del = 1.4901161193847656e-8 * (fabs(xj) + wfloor);
+        for (int i = 0; i < n; ++i) y[i] = x[i];
+        y[j] = xj + del;
+        rhs_int(m, y, u, fy);
+        double idel = 1.0 / ((xj + del) - xj);
+        for (int i = 0; i < n; ++i) W[i * n + j] = -(fy[i] - f0[i]) * idel;
+      }
+      for (int i = 0; i < n; ++i) W[i * n + i] = W[i * n + i] + igh;
+      lu_ok = ros_lu(W, piv, n);
+    }
+    for (int s = 0; s < R5_S; ++s) {
+      if (s == 0) {
+        for (int i = 0; i < n; ++i) U[0][i] = f0[i];
+      } else {
+        if (s < 6) { /* y = x + sum_j a_sj U_j, innermost term j = 0 */
+          for (int i = 0; i < n; ++i) {
+            double v = x[i];
+            for (int j = 0; j < s; ++j) v = fma(R5_A[s][j], U[j][i], v);
+            y[i] = v;
+          }
+        } else {
+          for (int i = 0; i < n; ++i) y[i] = y[i] + U[s - 1][i];
+        }
+        rhs_int(m, y, u, fy);
+        for (int i = 0; i < n; ++i) {
+          double v = fy[i];
+          for (int j = 0; j < s; ++j) v = fma(R5_C[s][j] * ih, U[j][i], v);
+          U[s][i] = v;
+        }
+      }
+      if (structured) me_ros_solve(&F, U[s]); else ros_solve(W, piv, n, U[s]);
+    }
+    for (int i = 0; i < n; ++i) r[i] = y[i] + U[7][i]; /* the new solution; error = U8 */
+    int kg[2];
+    ep_exponents(m, u, ep_c, ep_kmax, dt - (t + h), kg);
+    if (g_r5_hcap > 0.0) { /* see ros_pair() in pcg_integrators.hpp */
+      const int kc = ep_trunc(g_r5_hcap * ((dt - (t + h)) * ih), 1000);
+      if (kg[0] > kc) kg[0] = kc;
+      if (kg[1] > kc) kg[1] = kc;
+    }
+    const double sg[2] = {ldexp(1.0, -2 * kg[0]), ldexp(1.0, -2 * kg[1])};
+    double E2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+      double a0 = fabs(x[i]), a1 = fabs(r[i]);
+      double q = U[7][i] / (atol + rtol * (a0 > a1 ? a0 : a1));
+      E2 += (q * q) * sg[ep_group(m, i)];
+    }
+    E2 = E2 * (1.0 / n);
+    if (!lu_ok) E2 = NAN;
+    if (E2 < 1.0) {
+      double f = (E2 == 0.0) ? g_r5_facmax : fmin(g_r5_facmax, fmax(g_r5_facmin, qtrunc6(g_r5_safety * pow(E2, -0.1))));
+      if (rejected_last && f > 1.0) f = 1.0;
+      t += h;
+      h *= f;
+      for (int i = 0; i < n; ++i) x[i] = r[i];
+      rejected_last = 0;
+      ++acc;
+      if (last) break;
+      rhs_int(m, x, u, f0);
+    } else {
+      double f = (E2 == E2) ? fmax(g_r5_facmin, qtrunc6(g_r5_safety * pow(E2, -0.1))) : g_r5_facmin;
+      if (f > 1.0) f = 1.0;
+      h *= f;
+      rejected_last = 1;
+      ++rej;
+      if (!(h > 1e-13 * dt)) { status = 2; break; }
+    }
+  }
+  if (W) free(W);
+  if (nacc) *nacc = acc;
+  if (nrej) *nrej = rej;
+  if (status != 0)
+    for (int i = 0; i < n; ++i) x[i] = NAN;
+  return status;
+}
+/* ---------------------------------------------------------------------------------------------------------------
  * SEULEX-8: extrapolated linearly implicit Euler with a fixed column of eight (Deuflhard's SEULEX without order
  * selection) -- the integrator of the HEAVY envs of a PCG_INT_RODAS4 plan (cfg.coop_thr > 0), twin of seulex8_serial /
  * seulex8_lanes in pc-gym_amd/csrc/pcg_seulex.hpp.  The reference's CVODES integrates a stiff column at a cost that does
@@ -1368,7 +1522,7 @@ static double me_coop_key(const orc_model* m, const double* u, double d1) {
   return ((-30.0 - 10.0 * plog2(mn)) + 3.6 / mn) + 4.0 * plog2(fmax(d1, 1.0));
 }
 /* the Rosenbrock plan on one env: SEULEX-8 where the rule picks the env, the pair elsewhere (twin of seulex8_if_heavy) */
-static int rodas4_plan(const orc_model* m, double* x, const double* u, double dt, double rtol, double atol, int max_steps,
+static int rodas4_plan(int integ, const orc_model* m, double* x, const double* u, double dt, double rtol, double atol, int max_steps,
                        double ep_frac, int ep_kmax, double coop_thr, int32_t* nacc, int32_t* nrej) {
   if (coop_thr > 0.0 && me_coop_model(m)) {
     double f0[MAXNX];
@@ -1376,6 +1530,7 @@ static int rodas4_plan(const orc_model* m, double* x, const double* u, double dt
     const double d1 = rms_scaled(f0, x, x, m->nx, rtol, atol);
     if (me_coop_key(m, u, d1) >= coop_thr) return seulex8(m, x, u, dt, rtol, atol, max_steps, ep_frac, ep_kmax, nacc, nrej);
   }
+  if (integ == PCG_INT_RODAS5) return rodas5(m, x, u, dt, rtol, atol, max_steps, ep_frac, ep_kmax, nacc, nrej);
   return rodas4(m, x, u, dt, rtol, atol, max_steps, ep_frac, ep_kmax, nacc, nrej);
 }
 /* test hook: the rule's key for every env of a batch (x [nx][B], u [nu][B]) */
@@ -1632,8 +1787,8 @@ static void env_step(const pcg_env_cfg* c, orc_env* e, const double* action_in, 
   else if (c->integrator_id == PCG_INT_CV8) cv8(&m, e->state, uk, c->dt, c->substeps);
   else if (c->integrator_id == PCG_INT_TSIT5)
     ist = tsit5(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
-  else if (c->integrator_id == PCG_INT_RODAS4)
-    ist = rodas4_plan(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, c->coop_thr, &o->nacc, &o->nrej);
+  else if (c->integrator_id == PCG_INT_RODAS4 || c->integrator_id == PCG_INT_RODAS5)
+    ist = rodas4_plan(c->integrator_id, &m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, c->coop_thr, &o->nacc, &o->nrej);
   else ist = dopri5(&m, e->state, uk, c->dt, c->rtol, c->atol, c->max_steps, &o->nacc, &o->nrej);
   if (ist == 0)
     for (int i = 0; i < nx; ++i)
@@ -1792,8 +1947,8 @@ ORC_EXPORT int orc_integrate(const pcg_env_cfg* c, int64_t B, double* x, const d
     else if (c->integrator_id == PCG_INT_T5G) t5g(&m, xi, ui, c->dt, c->substeps, c->rtol, c->atol, c->max_steps, &na_, &nr_);
     else if (c->integrator_id == PCG_INT_CV8) cv8(&m, xi, ui, c->dt, c->substeps);
     else if (c->integrator_id == PCG_INT_TSIT5) tsit5(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, &na_, &nr_);
-    else if (c->integrator_id == PCG_INT_RODAS4)
-      rodas4_plan(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, c->coop_thr, &na_, &nr_);
+    else if (c->integrator_id == PCG_INT_RODAS4 || c->integrator_id == PCG_INT_RODAS5)
+      rodas4_plan(c->integrator_id, &m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, c->ep_frac, c->ep_kmax, c->coop_thr, &na_, &nr_);
     else dopri5(&m, xi, ui, c->dt, c->rtol, c->atol, c->max_steps, &na_, &nr_);
     for (int i = 0; i < nx; ++i) x[(size_t)i * B + b] = xi[i];
     if (nsteps) { nsteps[b] = na_; nsteps[B + b] = nr_; }

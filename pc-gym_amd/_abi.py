@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PCG_ABI_VERSION = 12
+PCG_ABI_VERSION = 13
 PCG_MAX_NX = 24
 PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
@@ -47,6 +47,7 @@ PCG_INT_TSIT5 = 4
 PCG_INT_RK4G = 5
 PCG_INT_T5G = 6
 PCG_INT_CV8 = 7
+PCG_INT_RODAS5 = 8
 
 PCG_F_NORMALISE_A = 0x0001
 PCG_F_NORMALISE_O = 0x0002

@@ -107,6 +107,9 @@ def cstr_default_tol(dt):
 # of the extraction cascade within 1e-6 of a 1e-13 solve over its whole action box (worst lanes: low liquid flow, high
 # gas flow -- 6.5e-7 at 3e-8; tests/test_rodas4.py), the class of the explicit pair at 1e-8 (5.5e-7)
 ROS4_TOL = {M.ME: 3e-8}
+# integrator = 'rodas5' (fifth-order pair, same hooks): worst 6.0e-7 over the action box at 8e-8 with end-point exponents up
+# to 12 under the step cap, at 0.56 x the attempts of the fourth-order pair (tests/test_rodas5.py, profiles/r5/rodas5_calib.txt)
+ROS5_TOL = {M.ME: 8e-8}
 DEFAULT_COOP_THR = 60.0  # cooperative rule of rodas4 plans: predicted attempts from which an env step takes SEULEX-8 (pcg_seulex.hpp)
 ROS4_DT_CAL = 1.0  # the env step (model time units) ROS4_TOL was calibrated at; larger steps tighten it (EnvSpec)
 
@@ -115,7 +118,8 @@ ROS4_DT_CAL = 1.0  # the env step (model time units) ROS4_TOL was calibrated at;
 # (7.2e-7 of a 1e-13 solve against 1.8e-6 for RK4 x 5 on the same sample, tools/prototypes/erk_fixed.py); crystallization:
 # four per model time unit (tests/test_erk.py)
 DEFAULT_CV8_H = {M.FOUR_TANK: 1000.0 / 60.0, M.CRYST: 1.0 / 4}
-INTEGRATOR_IDS = ("rk4", "rk4g", "tsit5g", "cv8", "dopri5", "tsit5", "rodas3", "rodas4")
+INTEGRATOR_IDS = ("rk4", "rk4g", "tsit5g", "cv8", "dopri5", "tsit5", "rodas3", "rodas4", "rodas5")
+ROS_PAIRS = ("rodas4", "rodas5")  # the two Rosenbrock pairs: one set of hooks (end-point control, cooperative rule, structured W)
 
 
 def default_substeps(model_id, dt):
@@ -884,39 +888,46 @@ class EnvSpec:
             # diffrax.Tsit5 + PIDController(rtol = atol = 1e-8): the same tableau, tolerances and step-size controller
             # family here; plans it has no kernel for (per-env parameters) use the Dormand-Prince pair of the same class
             d_int = "tsit5" if self.nunc == 0 else "dopri5"
-        elif d_int in ("rodas4", "rk4g", "tsit5g") and self.nunc > 0:
+        elif d_int in ("rodas4", "rodas5", "rk4g", "tsit5g") and self.nunc > 0:
             d_int = "dopri5"
         elif d_int == "cv8" and self.nunc > 0:
             d_int = "rk4"
         self.integrator = p.get("integrator", d_int)
         if self.integrator not in INTEGRATOR_IDS:
             raise ValueError("integrator must be one of " + ", ".join(repr(k) for k in INTEGRATOR_IDS))
-        if self.nunc > 0 and self.integrator in ("rodas4", "rodas3", "rk4g", "tsit5g", "cv8", "tsit5"):
+        if self.nunc > 0 and self.integrator in ("rodas4", "rodas5", "rodas3", "rk4g", "tsit5g", "cv8", "tsit5"):
             raise ValueError(f"integrator '{self.integrator}' has no kernel for per-env uncertain parameters "
                              "(uncertainty_percentages on model parameters): use 'rk4' or 'dopri5'")
         if self.integrator in ("rk4g", "tsit5g") and self.model.model_id != M.CSTR:
             raise ValueError(f"integrator '{self.integrator}' (guarded fixed step) needs a model with a guard hook: cstr")
         epc = p.get("endpoint_control", True)
         self.ep_frac, self.ep_kmax = 0.0, 0
-        if self.integrator == "rodas4" and epc is not False and epc is not None:
+        if self.integrator in ROS_PAIRS and epc is not False and epc is not None:
             epc = {} if epc is True else dict(epc)
-            self.ep_frac, self.ep_kmax = float(epc.get("frac", 0.5)), int(epc.get("kmax", 10))
+            # kmax: the largest relaxation 2^kmax of an early attempt's tolerance.  The fifth-order pair caps the exponent of
+            # an attempt at two bits per remaining step of its size (pcg_integrators.hpp: ros_ep_cap -- the steps' own damping
+            # |R(h lambda)| is what an early error really meets), and with that cap the exponents can grow to 12: 11.3 attempts
+            # per env step over the action box, worst 6.0e-7; without it, 2^10 and 2^9 leave single fast envs at 1.0e-6 -
+            # 1.8e-6 and 2^8 costs 13.3 attempts (profiles/r5/rodas5_calib.txt)
+            self.ep_frac, self.ep_kmax = float(epc.get("frac", 0.5)), int(epc.get("kmax", 10 if self.integrator == "rodas4" else 12))
             if not (0.0 <= self.ep_frac <= 1.0) or not (0 <= self.ep_kmax <= 40):
                 raise ValueError("endpoint_control: frac must lie in [0, 1] and kmax in [0, 40]")
         # cooperative rule: where the kernels carry it (the 10-state cascade with eq_exponent == 2 through the structured
         # Rosenbrock path, registry parameters or not) it is on; asking for it elsewhere is an error, not a silent no-op
         coop = p.get("cooperative", None)
         pv = self.model.param_vector()
-        coop_ok = (self.integrator == "rodas4" and self.model.model_id == M.ME and self.nunc == 0
+        coop_ok = (self.integrator in ROS_PAIRS and self.model.model_id == M.ME and self.nunc == 0
                    and getattr(self, "user_rhs_src", None) is None and len(pv) > 4 and float(pv[4]) == 2.0)
         self.coop_thr = 0.0
         if coop is None or coop is True:
             if coop is True and not coop_ok:
-                raise ValueError("cooperative: needs integrator 'rodas4' on multistage_extraction with eq_exponent == 2")
-            self.coop_thr = DEFAULT_COOP_THR if coop_ok else 0.0
+                raise ValueError("cooperative: needs integrator 'rodas4' / 'rodas5' on multistage_extraction with eq_exponent == 2")
+            # on by default under the fourth-order pair, whose heaviest envs take ~100 attempts; the fifth-order pair's take
+            # ~45 and the launch does not wait for them (DEFAULT_COOP_THR counts attempts of the FOURTH-order pair)
+            self.coop_thr = DEFAULT_COOP_THR if (coop_ok and (self.integrator == "rodas4" or coop is True)) else 0.0
         elif coop is not False:
             if not coop_ok:
-                raise ValueError("cooperative: needs integrator 'rodas4' on multistage_extraction with eq_exponent == 2")
+                raise ValueError("cooperative: needs integrator 'rodas4' / 'rodas5' on multistage_extraction with eq_exponent == 2")
             self.coop_thr = float(dict(coop).get("thr", DEFAULT_COOP_THR))
             if not (self.coop_thr > 0.0 and np.isfinite(self.coop_thr)):
                 raise ValueError("cooperative: thr must be a positive finite number")
@@ -935,9 +946,10 @@ class EnvSpec:
         d_tol = 1e-8 if self.integration_method == "jax" else DEFAULT_TOL.get(self.model.model_id, 1e-8)
         if self.model.model_id == M.CSTR and self.integration_method != "jax":
             d_tol = cstr_default_tol(self.dt)
-        if self.integrator == "rodas4":
-            d_tol = ROS4_TOL.get(self.model.model_id, d_tol)
-            if self.model.model_id in ROS4_TOL:
+        if self.integrator in ROS_PAIRS:
+            tab = ROS4_TOL if self.integrator == "rodas4" else ROS5_TOL
+            d_tol = tab.get(self.model.model_id, d_tol)
+            if self.model.model_id in tab:
                 # the global error of an env step is the SUM of the per-attempt budgets (~ attempts x tolerance), and the
                 # attempts grow with dt: calibrated at dt = 1 (<= 7e-7 there and at 0.2), the same tolerance gave 1.5e-6
                 # at dt = 2 and 3.9e-6 at dt = 5.  Scaled by the calibrated dt it stays at 7.0-7.4e-7 for dt =
@@ -1105,7 +1117,7 @@ class EnvSpec:
         cfg = abi.pcg_env_cfg()
         cfg.model_id = self.model.model_id
         cfg.integrator_id = {"rk4": abi.PCG_INT_RK4, "dopri5": abi.PCG_INT_DOPRI5, "rodas3": abi.PCG_INT_RODAS3,
-                             "rodas4": abi.PCG_INT_RODAS4, "tsit5": abi.PCG_INT_TSIT5, "rk4g": abi.PCG_INT_RK4G,
+                             "rodas4": abi.PCG_INT_RODAS4, "rodas5": abi.PCG_INT_RODAS5, "tsit5": abi.PCG_INT_TSIT5, "rk4g": abi.PCG_INT_RK4G,
                              "tsit5g": abi.PCG_INT_T5G, "cv8": abi.PCG_INT_CV8}[self.integrator]
         cfg.ep_frac, cfg.ep_kmax = self.ep_frac, self.ep_kmax
         cfg.coop_thr = self.coop_thr

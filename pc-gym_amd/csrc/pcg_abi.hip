@@ -423,8 +423,9 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   d->rtol = c->rtol;
   d->dt_edge = c->dt * (1.0 - 1e-14);
   d->h_floor = 1e-13 * c->dt;
-  // end-point error control of PCG_INT_RODAS4 (pcgym_hip.h): exponent rate = ep_c x the model's contraction rate
-  if (c->integrator_id == PCG_INT_RODAS4) {
+  // end-point error control of the Rosenbrock pairs (PCG_INT_RODAS4 / PCG_INT_RODAS5, pcgym_hip.h): exponent rate = ep_c x the
+  // model's contraction rate
+  if (is_ros_pair(c->integrator_id)) {
     if (!(c->ep_frac >= 0.0 && c->ep_frac <= 1.0) || c->ep_kmax < 0 || c->ep_kmax > 40) return PCG_E_VALUE;
     if (c->nunc > 0) return PCG_E_UNSUPPORTED;
     d->ep_kmax = c->ep_kmax;
@@ -434,7 +435,7 @@ static int build_devconst(const pcg_env_cfg* c, DevConst* d, int* cfg_nu_out) {
   d->coop_thr = 0.0;
   if (c->coop_thr != 0.0) {
     if (!(c->coop_thr > 0.0) || !std::isfinite(c->coop_thr)) return PCG_E_VALUE;
-    if (c->integrator_id != PCG_INT_RODAS4 || user || !c->params || !kernels(kernel_id_for(c)).coop) return PCG_E_UNSUPPORTED;
+    if (!is_ros_pair(c->integrator_id) || user || !c->params || !kernels(kernel_id_for(c)).coop) return PCG_E_UNSUPPORTED;
     d->coop_thr = c->coop_thr;
   }
   d->atol = c->atol;
@@ -645,7 +646,7 @@ static int jit_kernels(const pcg_env_cfg* cfg, int kid, int device, JitModule* o
     src << "__device__ double pcg_user_reward(const double* o, const double* x, const double* u, const double* sp, "
            "int violated, int t, int N) {\n  return (double)(" << cfg->user_reward_src << ");\n}\n";
   src << "}\n";
-  const bool roll = cfg->integrator_id != PCG_INT_RODAS3 && cfg->integrator_id != PCG_INT_RODAS4;
+  const bool roll = cfg->integrator_id != PCG_INT_RODAS3 && !is_ros_pair(cfg->integrator_id);
   const int iroll = user ? 4 : 2;
   const int nfn = iroll + (roll ? 1 : 0);
   std::string names[5];
@@ -943,7 +944,9 @@ static int queue_geometry(pcg_plan* p, const Kernels& k, int pe, size_t sched_by
   if (p->q_tile[pe] != 0) return PCG_OK;
   hipFuncAttributes fa;
   const bool guarded = p->integrator_id == PCG_INT_RK4G || p->integrator_id == PCG_INT_T5G;  // their fix-up launch
-  const StepFn qfn = (p->integrator_id == PCG_INT_RODAS4 ? k.queue_r4 : guarded ? k.queue_fix : k.queue)[pe];
+  const bool ros = is_ros_pair(p->integrator_id);
+  const StepFn* q_w1 = p->integrator_id == PCG_INT_RODAS5 ? k.queue_r5w1 : k.queue_r4w1;
+  const StepFn qfn = (p->integrator_id == PCG_INT_RODAS5 ? k.queue_r5 : ros ? k.queue_r4 : guarded ? k.queue_fix : k.queue)[pe];
   hipError_t e = hipFuncGetAttributes(&fa, (const void*)qfn);
   if (e != hipSuccess) return (int)e;
   const int alloc = ((fa.numRegs + 7) / 8) * 8;
@@ -956,7 +959,7 @@ static int queue_geometry(pcg_plan* p, const Kernels& k, int pe, size_t sched_by
   const size_t lds_cu = 160 * 1024 - 2048;
   // tile cap: four envs per lane for the explicit pair (tuned in round 2); the Rosenbrock pair's attempts per env are
   // heavy-tailed (median 17, 1 % above 70, maximum ~100 on BASELINE configs[2]) and want the largest pool
-  const int tcap = p->integrator_id == PCG_INT_RODAS4 ? QSORT : QSORT / 2;
+  const int tcap = ros ? QSORT : QSORT / 2;
   int best_t = 0, best_b = 1, t1 = 0;
   for (int b = bpc; b >= 1; --b) {
     int T = tcap;
@@ -967,7 +970,7 @@ static int queue_geometry(pcg_plan* p, const Kernels& k, int pe, size_t sched_by
       best_t = T;
       best_b = b;
     }
-    if (T == tcap && p->integrator_id != PCG_INT_RODAS4) break;  // the full tile at the highest occupancy that allows it
+    if (T == tcap && !ros) break;  // the full tile at the highest occupancy that allows it
   }
   p->q_tile[pe] = best_t > 0 ? best_t : -1;
   p->q_bpc[pe] = best_b;
@@ -976,8 +979,8 @@ static int queue_geometry(pcg_plan* p, const Kernels& k, int pe, size_t sched_by
     // (the whole CU's LDS: a launch may also park its tile's state there when that fits, see step_impl)
     e = hipFuncSetAttribute((const void*)qfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
     if (e != hipSuccess) return (int)e;
-    if (p->integrator_id == PCG_INT_RODAS4 && k.queue_r4w1[pe]) {
-      e = hipFuncSetAttribute((const void*)k.queue_r4w1[pe], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
+    if (ros && q_w1[pe]) {
+      e = hipFuncSetAttribute((const void*)q_w1[pe], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
       if (e != hipSuccess) return (int)e;
     }
     if (p->integrator_id == PCG_INT_DOPRI5 && k.queue_w[pe]) {
@@ -1006,7 +1009,7 @@ static int warm_occupancy(pcg_plan* p) {
     }
   }
   if ((p->integrator_id == PCG_INT_DOPRI5 && k.queue[0]) || ((p->integrator_id == PCG_INT_RK4G || p->integrator_id == PCG_INT_T5G) && k.queue_fix[0]) ||
-      (p->integrator_id == PCG_INT_RODAS4 && k.queue_r4[0])) {
+      (is_ros_pair(p->integrator_id) && k.queue_r4[0])) {
     const int rc = queue_geometry(p, k, 0, 0);
     if (rc != PCG_OK) return rc;
   }
@@ -1075,8 +1078,9 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   }
   // Adaptive plans: the work-queue kernel (lanes that finish early pull the next env from an LDS tile).
   // PCG_OPT_VARIANT 1 keeps the classic one-env-per-lane kernel (A/B measurement), PCG_OPT_LDS_STAGES too.
-  const bool r4q = p->integrator_id == PCG_INT_RODAS4;
-  const StepFn* qtab = r4q ? k.queue_r4 : k.queue;
+  const bool r4q = is_ros_pair(p->integrator_id);  // either Rosenbrock pair
+  const StepFn* qtab = p->integrator_id == PCG_INT_RODAS5 ? k.queue_r5 : r4q ? k.queue_r4 : k.queue;
+  const StepFn* q_w1 = p->integrator_id == PCG_INT_RODAS5 ? k.queue_r5w1 : k.queue_r4w1;
   const bool q_forced = p->variant == 5 || std::getenv("PCG_Q_FORCE") != nullptr;  // PCG_OPT_VARIANT 5: any model
   // the launch of a work-queue kernel (geometry, tile, LDS): true = taken, rc_out is the launch's status
   auto queue_launch = [&](StepArgs a, const StepFn* qtab, bool r4q, bool q_forced, int& rc_out) -> bool {
@@ -1110,7 +1114,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       // registers, every wave alone on its SIMD
       int w1_cap = 1200;  // envs per CU up to which the one-workgroup-per-CU shape is taken
       if (const char* ev = std::getenv("PCG_Q_W1CAP")) w1_cap = std::atoi(ev);  // measurement switch
-      bool w1 = r4q && k.queue_r4w1[pe] && p->q_tile1[pe] >= QBLOCK && io->B <= (int64_t)p->num_cus * w1_cap &&
+      bool w1 = r4q && q_w1[pe] && p->q_tile1[pe] >= QBLOCK && io->B <= (int64_t)p->num_cus * w1_cap &&
                 io->B > (int64_t)p->num_cus * QBLOCK;
       if (const char* ev = std::getenv("PCG_Q_W1")) w1 = w1 && std::atoi(ev) != 0;  // measurement switch
       if (w1) a.q_tile = (a.q_tile & ~0xFFFF) | p->q_tile1[pe];
@@ -1202,7 +1206,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
         a.q_tile = (a.q_tile & ~(0xFFFF | 0x20000)) | Tq;
         qsh = k.queue_lds(Tq) + 4 * (size_t)Tq + 8 + sb;
       }
-      hipLaunchKernelGGL(w1 ? k.queue_r4w1[pe] : wide ? k.queue_w[pe] : qtab[pe], dim3((unsigned)nwg), dim3(qb), qsh, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(w1 ? q_w1[pe] : wide ? k.queue_w[pe] : qtab[pe], dim3((unsigned)nwg), dim3(qb), qsh, (hipStream_t)stream, a);
       rc_out = (int)hipGetLastError();
       return true;
       }

@@ -1102,12 +1102,15 @@ struct EpWeights {
   }
 };
 // mean square of err_i / (atol + rtol max(|y0_i|, |y1_i|)), term i weighted by 4^-kg[group(i)]
+// kcap: an upper bound of both exponents (the fifth-order pair's step cap, ros_ep_cap())
 template <int NX, class EP>
 PCG_DEV double ms_scaled_ep(const EP& ep, double tau, const double (&v)[NX], const double (&y0)[NX],
-                            const double (&y1)[NX], int n, double rtol, double atol) {
+                            const double (&y1)[NX], int n, double rtol, double atol, int kcap = 1 << 20) {
 #pragma clang fp contract(off)
   int kg[2];
   ep(tau, kg);
+  kg[0] = kg[0] < kcap ? kg[0] : kcap;
+  kg[1] = kg[1] < kcap ? kg[1] : kcap;
   const double sg[2] = {ldexp(1.0, -2 * kg[0]), ldexp(1.0, -2 * kg[1])};
   double s = 0.0;
 #pragma unroll
@@ -1118,6 +1121,92 @@ PCG_DEV double ms_scaled_ep(const EP& ep, double tau, const double (&v)[NX], con
     s += (i < n) ? (r * r) * w : 0.0;
   }
   return s * (1.0 / n);  // (the oracle multiplies by the same reciprocal: a division less per attempt)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rodas5 -- the fifth-order stiff pair (PCG_INT_RODAS5).  Di Marzo's coefficient set, the one of Hairer & Wanner's RODAS5
+// code: 8 stages, order 5 with an embedded order-4 solution, gamma = 0.19, L-stable, stiffly accurate; the transformed form of
+// Rodas4 above with two more stages:
+//     W U_i = f(x + sum_j a_ij U_j) + sum_j (c_ij / h) U_j  (i <= 6),   y_7 = y_6 + U_6,  y_8 = y_7 + U_7,
+//     x_new = y_8 + U_8,   error estimate = U_8.
+// Why: on the extraction cascade the fourth-order pair is accuracy-bound, not stability-bound (17.6 attempts per env step
+// at 3e-8 for 1e-6 of a 1e-13 solve); the fifth-order pair reaches the same class in 0.59 x the attempts at 8 stages
+// against 6 (tools/prototypes/rodas5_me.py, tests/test_rodas5.py).  Linear-algebra policy, error norm, end-point weights,
+// first step and failure semantics are rodas4()'s; factor Q(0.9 E^-1/5) in [0.2, 6].  Twin: rodas5() in oracle/pcg_oracle.c.
+// ---------------------------------------------------------------------------------------------------------------
+namespace r5 {
+constexpr double GAM = 0.19, IGAM = 1.0 / 0.19;
+constexpr double EP_KB = 2.0;  // end-point exponents: bits per remaining step (ros_ep_cap)
+constexpr double H0 = 10.0;  // first step = min(Q(H0 h0), dt): scanned on the oracle over BASELINE configs[2]'s action box (5: 12.42 attempts
+                            // per env step, 8: 12.22, 10: 12.16, 15: 12.17; profiles/r5/rodas5_calib.txt)
+constexpr double A[6][5] = {
+    {0, 0, 0, 0, 0},
+    {2.0, 0, 0, 0, 0},
+    {3.040894194418781, 1.041747909077569, 0, 0, 0},
+    {2.576417536461461, 1.622083060776640, -0.9089668560264532, 0, 0},
+    {2.760842080225597, 1.446624659844071, -0.3036980084553738, 0.2877498600325443, 0},
+    {-14.09640773051259, 6.925207756232704, -41.47510893210728, 2.343771018586405, 24.13215229196062}};
+constexpr double C[8][7] = {
+    {0, 0, 0, 0, 0, 0, 0},
+    {-10.31323885133993, 0, 0, 0, 0, 0, 0},
+    {-21.04823117650003, -7.234992135176716, 0, 0, 0, 0, 0},
+    {32.22751541853323, -4.943732386540191, 19.44922031041879, 0, 0, 0, 0},
+    {-20.69865579590063, -8.816374604402768, 1.260436877740897, -0.7495647613787146, 0, 0, 0},
+    {-46.22004352711257, -17.49534862857472, -289.6389582892057, 93.60855400400906, 318.3822534212147, 0, 0},
+    {34.20013733472935, -14.15535402717690, 57.82335640988400, 25.83362985412365, 1.408950972071624, -6.551835421242162, 0},
+    {42.57076742291101, -13.80770672017997, 93.98938432427124, 18.77919633714503, -31.58359187223370, -6.685968952921985,
+     -5.810979938412932}};
+}  // namespace r5
+
+// One attempted step of size h from x (f0 = f(x)): as rodas4_try.
+template <int NX, class F, class LS>
+PCG_DEV bool rodas5_try(const F& f, const LS& ls, const double (&x)[NX], const double (&f0)[NX], double h,
+                        double (&xn)[NX], double (&err)[NX]) {
+#pragma clang fp contract(off)
+  const double ih = rcp_ieee(h), igh = ih * r5::IGAM;  // (h is a positive normal number: == 1.0 / h)
+  const bool lu_ok = ls.factor(x, f0, igh);
+  double U[8][NX], y[NX], fy[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) U[0][i] = f0[i];
+  ls.solve(U[0]);
+#pragma unroll
+  for (int s = 1; s < 8; ++s) {
+    if (s < 6) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        double v = x[i];
+#pragma unroll
+        for (int j = 0; j < s; ++j) v = __builtin_fma(r5::A[s][j], U[j][i], v);
+        y[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) y[i] = y[i] + U[s - 1][i];
+    }
+    f(y, fy);
+    double cs[7];
+#pragma unroll
+    for (int j = 0; j < s; ++j) cs[j] = r5::C[s][j] * ih;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      double v = fy[i];
+#pragma unroll
+      for (int j = 0; j < s; ++j) v = __builtin_fma(cs[j], U[j][i], v);
+      U[s][i] = v;
+    }
+    ls.solve(U[s]);
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    xn[i] = y[i] + U[7][i];
+    err[i] = U[7][i];
+  }
+  return lu_ok;
+}
+PCG_DEV double rodas5_factor(double E2, bool ok, bool rejected_last) {
+  double fac = (E2 == E2) ? fmax(0.2, ctrl_pow(E2, 0.9)) : 0.2;  // Q(0.9 E^-1/5); NaN -> hardest shrink
+  const double cap = ok ? (rejected_last ? 1.0 : 6.0) : 1.0;
+  return fmin(cap, fac);
 }
 
 // One attempted step of size h from x (f0 = f(x)): the candidate solution in xn, the error estimate in err; returns
@@ -1207,7 +1296,8 @@ PCG_DEV double rodas4_factor(double E2, bool ok, bool rejected_last) {
 // first step size: h0 of Hairer, Norsett & Wanner II.4 (first stage) x 5, quantised.  (rodas3() starts at 100 h0; measured
 // over the action box of BASELINE configs[2] that costs this pair 3.9 rejected attempts per env step out of 22.5 -- the
 // transient of a freshly changed input needs h ~ 2-3 h0 -- against 0.5 out of 19.6 here, same worst-case error.)
-template <int NX>
+// (the fifth-order pair starts at r5::H0 h0: INTEG selects the multiple)
+template <int NX, int INTEG = PCG_INT_RODAS4>
 PCG_DEV double rodas4_h_init(const double (&x)[NX], const double (&f0)[NX], int n, double dt, double rtol, double atol,
                              double& d1_out, double* d0_out = nullptr) {
 #pragma clang fp contract(off)
@@ -1216,19 +1306,50 @@ PCG_DEV double rodas4_h_init(const double (&x)[NX], const double (&f0)[NX], int 
   d1_out = d1;
   if (d0_out) *d0_out = d0;
   const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-  return fmin(qtrunc6(5.0 * h0), dt);
+  return fmin(qtrunc6((INTEG == PCG_INT_RODAS5 ? r5::H0 : 5.0) * h0), dt);
+}
+// the two Rosenbrock pairs behind one name: attempt and controller verdict of PCG_INT_RODAS4 / PCG_INT_RODAS5
+constexpr bool is_ros_pair(int integ) { return integ == PCG_INT_RODAS4 || integ == PCG_INT_RODAS5; }
+template <int INTEG, int NX, class F, class LS>
+PCG_DEV bool ros_pair_try(const F& f, const LS& ls, const double (&x)[NX], const double (&f0)[NX], double h,
+                          double (&xn)[NX], double (&err)[NX]) {
+  // (instantiated, and dead, for every INTEG at the kernels' run-time-free `if (INTEG == ...)` chains: anything but
+  // PCG_INT_RODAS5 is the fourth-order pair)
+  if constexpr (INTEG == PCG_INT_RODAS5) return rodas5_try<NX>(f, ls, x, f0, h, xn, err);
+  else return rodas4_try<NX>(f, ls, x, f0, h, xn, err);
+}
+// STEP CAP of the end-point exponents (PCG_INT_RODAS5).  The weights assume that an error committed at time-to-go tau arrives
+// damped by exp(-mu tau).  That is the exact flow's damping; the remaining STEPS damp a stiff component by |R(h lambda)| each,
+// and for both pairs |R(z)| = 0.10 ... 0.16 for z in [-100, -10] (2.6 - 3.3 bits per step, tests/test_rodas5.py) however small
+// exp(z) is.  The fifth-order pair crosses a fast env's step in 6 - 9 attempts, the last two or three of them at h lambda ~ 30:
+// relaxed by 2^10 they left single envs of the action box at 1.0e-6 - 1.8e-6 (profiles/r5/rodas5_calib.txt).  So the
+// exponent of an attempt of size h is capped at r5::EP_KB bits per remaining step of that size:
+//     k <= trunc(EP_KB tau / h),   EP_KB = 2
+// (scanned: 3 and 4 leave outliers again, 1 and 0.5 cost attempts; with the cap the largest exponent can grow to 12: 11.3
+// attempts per env step against 13.3 at exponents up to 8 without it, same worst case).  Exact arithmetic: tau (1/h), a
+// scaling by two, a truncation -- the kernels and the oracle cap alike.  The fourth-order pair keeps its calibration.
+template <int INTEG>
+PCG_DEV int ros_ep_cap(double tau, double h) {
+#pragma clang fp contract(off)
+  if constexpr (INTEG == PCG_INT_RODAS5) return ep_trunc(r5::EP_KB * (tau * rcp_ieee(h)), 1000);
+  else return 1 << 20;
+}
+template <int INTEG>
+PCG_DEV double ros_pair_factor(double E2, bool ok, bool rejected_last) {
+  if constexpr (INTEG == PCG_INT_RODAS5) return rodas5_factor(E2, ok, rejected_last);
+  else return rodas4_factor(E2, ok, rejected_last);
 }
 
 // returns PCG_ST_OK, PCG_ST_MAX_STEPS or PCG_ST_UNDERFLOW (the caller poisons the state on failure)
-template <int NX, class F, class LS, class EP>
-PCG_DEV int rodas4(const F& f, const LS& ls, const EP& ep, double (&x)[NX], int n, double dt, double rtol, double atol,
-                   int max_steps, int& nacc, int& nrej) {
+template <int INTEG, int NX, class F, class LS, class EP>
+PCG_DEV int ros_pair(const F& f, const LS& ls, const EP& ep, double (&x)[NX], int n, double dt, double rtol, double atol,
+                     int max_steps, int& nacc, int& nrej) {
 #pragma clang fp contract(off)
   double f0[NX], xn[NX], err[NX];
   int acc = 0, rej = 0, status = 0;
   f(x, f0);
   double d1;
-  double h = rodas4_h_init<NX>(x, f0, n, dt, rtol, atol, d1);
+  double h = rodas4_h_init<NX, INTEG>(x, f0, n, dt, rtol, atol, d1);
   double t = 0.0;
   bool rejected_last = false;
   for (;;) {
@@ -1241,11 +1362,11 @@ PCG_DEV int rodas4(const F& f, const LS& ls, const EP& ep, double (&x)[NX], int 
       h = dt - t;
       last = true;
     }
-    const bool lu_ok = rodas4_try<NX>(f, ls, x, f0, h, xn, err);
-    double E2 = ms_scaled_ep<NX>(ep, dt - (t + h), err, x, xn, n, rtol, atol);
+    const bool lu_ok = ros_pair_try<INTEG, NX>(f, ls, x, f0, h, xn, err);
+    double E2 = ms_scaled_ep<NX>(ep, dt - (t + h), err, x, xn, n, rtol, atol, ros_ep_cap<INTEG>(dt - (t + h), h));
     if (!lu_ok) E2 = __builtin_nan("");
     const bool ok = E2 < 1.0;
-    const double fac = rodas4_factor(E2, ok, rejected_last);
+    const double fac = ros_pair_factor<INTEG>(E2, ok, rejected_last);
     if (ok) {
       t += h;
       h *= fac;
@@ -1268,6 +1389,11 @@ PCG_DEV int rodas4(const F& f, const LS& ls, const EP& ep, double (&x)[NX], int 
   nacc = acc;
   nrej = rej;
   return status;
+}
+template <int NX, class F, class LS, class EP>
+PCG_DEV int rodas4(const F& f, const LS& ls, const EP& ep, double (&x)[NX], int n, double dt, double rtol, double atol,
+                   int max_steps, int& nacc, int& nrej) {
+  return ros_pair<PCG_INT_RODAS4, NX>(f, ls, ep, x, n, dt, rtol, atol, max_steps, nacc, nrej);
 }
 
 }  // namespace pcg

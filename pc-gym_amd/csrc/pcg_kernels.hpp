@@ -54,13 +54,13 @@ constexpr int BLOCK_LDS = 64;   // LDS-staged DOPRI5: 6*NX*8 B of stage storage 
 // Rosenbrock integrators with the dense per-lane LU in LDS: Rodas3 always, Rodas4 unless the model brings its own
 // structured linear algebra (M::ROS_STRUCTURED -> registers only, launched like the explicit adaptive pair)
 constexpr bool ros_dense(int integ, bool structured) {
-  return integ == PCG_INT_RODAS3 || (integ == PCG_INT_RODAS4 && !structured);
+  return integ == PCG_INT_RODAS3 || (is_ros_pair(integ) && !structured);
 }
 // the fixed-step schemes the lean pipelined kernel is instantiated for: index into Kernels::pipe (-1: none)
 constexpr int lean_scheme(int integ) { return integ == PCG_INT_RK4 ? 0 : integ == PCG_INT_CV8 ? 1 : -1; }
 constexpr int tb(bool lds_stages, int integ, int nx = 0, bool structured = false) {
   return ros_dense(integ, structured) ? ros_threads(nx)
-         : (lds_stages || integ == PCG_INT_DOPRI5 || integ == PCG_INT_RODAS4 || integ == PCG_INT_TSIT5) ? BLOCK_LDS : BLOCK;
+         : (lds_stages || integ == PCG_INT_DOPRI5 || is_ros_pair(integ) || integ == PCG_INT_TSIT5) ? BLOCK_LDS : BLOCK;
 }
 // doubles of dynamic LDS the integrator itself needs per workgroup (the schedules follow them)
 constexpr size_t integ_lds_doubles(int nx, int integ, bool lds_stages, bool structured = false) {
@@ -71,7 +71,7 @@ constexpr size_t integ_lds_doubles(int nx, int integ, bool lds_stages, bool stru
 // issue); capping it at 256 costs a few spills and doubles the resident waves.
 constexpr int wpe(int nx, int integ, bool lds_stages, bool structured = false) {
   return (((integ == PCG_INT_DOPRI5 || integ == PCG_INT_TSIT5) && !lds_stages && nx <= 10) ||
-          (integ == PCG_INT_RODAS4 && structured && nx <= 10)) ? 2 : 1;
+          (is_ros_pair(integ) && structured && nx <= 10)) ? 2 : 1;
 }
 constexpr int KNU = PCG_MAX_NA + PCG_MAX_NDM;                      // kernel-side u width
 constexpr int CON_W = PCG_MAX_NX + PCG_MAX_NSP + PCG_MAX_NDM + KNU; // padded constraint row
@@ -545,18 +545,18 @@ PCG_DEV int integrate_env(const StepArgs& A, CDevConst& c, const K& kp, const do
       A.nsteps[A.B + e] = nrej;
     }
     poison_if_failed<NX>(status, x);
-  } else if (INTEG == PCG_INT_RODAS4) {
+  } else if (is_ros_pair(INTEG)) {
     int nacc = 0, nrej = 0;
     const EpWeights<M, K> ep{kp, u, c.ep_c, c.ep_kmax};
     if constexpr (ros_structured<M>::value) {
       if (!seulex8_if_heavy<M>(kp, hold, u, f, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, c.coop_thr, nacc, nrej, status)) {
         const RosStructured<M, K> ls{kp, hold, {}};
-        status = rodas4<NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+        status = ros_pair<INTEG, NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
       }
     } else {
       const RosLds<NX> Lm(stage_l);
       const RosDense<NX, RhsFn<M, double, K>> ls{f, Lm, nx, c.rtol, c.atol};
-      status = rodas4<NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+      status = ros_pair<INTEG, NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
     }
     if (A.nsteps) {
       A.nsteps[e] = nacc;
@@ -1690,18 +1690,18 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX, ros_structured<M>::val
       nsteps[e] = nacc;
       nsteps[B + e] = nrej;
     }
-  } else if (INTEG == PCG_INT_RODAS4) {
+  } else if (is_ros_pair(INTEG)) {
     int nacc = 0, nrej = 0, status;
     const EpWeights<M, typename M::CKP> ep{kp, u, c.ep_c, c.ep_kmax};
     if constexpr (ros_structured<M>::value) {
       if (!seulex8_if_heavy<M>(kp, hold, u, f, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, c.coop_thr, nacc, nrej, status)) {
         const RosStructured<M, typename M::CKP> ls{kp, hold, {}};
-        status = rodas4<NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+        status = ros_pair<INTEG, NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
       }
     } else {
       const RosLds<NX> Lm(lds);
       const RosDense<NX, RhsFn<M>> ls{f, Lm, nx, c.rtol, c.atol};
-      status = rodas4<NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
+      status = ros_pair<INTEG, NX>(f, ls, ep, x, nx, c.dt, c.rtol, c.atol, c.max_steps, nacc, nrej);
     }
     poison_if_failed<NX>(status, x);
     if (nsteps) {
@@ -1769,6 +1769,7 @@ struct Kernels {
   StepFn queue_w[2];                 // ... 512-thread workgroups: both waves of a SIMD on ONE tile (models with a cost key, <= 256 registers)
   StepFn queue_r4[2];                // Rodas4 through the same work queue [per_env_t] (models with structured W only)
   StepFn queue_r4w1[2];              // ... compiled for ONE workgroup per CU (no register spills in the loop)
+  StepFn queue_r5[2], queue_r5w1[2]; // the same two for the fifth-order pair (PCG_INT_RODAS5)
   bool ros_structured;               // Rodas4 runs in registers (launch shape of the explicit adaptive pair)
   bool coop;                         // ... and the model has a cooperative rule (cfg.coop_thr, pcg_seulex.hpp)
   bool queue_default;                // route adaptive plans to it unless told otherwise (models with a cost key)
@@ -1814,6 +1815,10 @@ Kernels make_kernels() {
   k.step[PCG_INT_RODAS4][0][0][0] = k.step[PCG_INT_RODAS4][0][0][1] = step_kernel<M, PCG_INT_RODAS4, false, false, true>;
   k.step[PCG_INT_RODAS4][1][0][0] = k.step[PCG_INT_RODAS4][1][0][1] = step_kernel<M, PCG_INT_RODAS4, true, false, true>;
   k.integ[PCG_INT_RODAS4][0] = integrate_kernel<M, PCG_INT_RODAS4, false>;
+  // fifth-order Rosenbrock pair: the same set
+  k.step[PCG_INT_RODAS5][0][0][0] = k.step[PCG_INT_RODAS5][0][0][1] = step_kernel<M, PCG_INT_RODAS5, false, false, true>;
+  k.step[PCG_INT_RODAS5][1][0][0] = k.step[PCG_INT_RODAS5][1][0][1] = step_kernel<M, PCG_INT_RODAS5, true, false, true>;
+  k.integ[PCG_INT_RODAS5][0] = integrate_kernel<M, PCG_INT_RODAS5, false>;
   k.ros_structured = ros_structured<M>::value;
   k.coop = ros_structured<M>::value && has_coop<M>::value;
   // guarded RK4 (models with a guard hook): general kernel, integration hook, fused rollout
@@ -1845,6 +1850,11 @@ Kernels make_kernels() {
     k.queue_r4w1[1] = step_kernel_queue<M, true, true, PCG_INT_RODAS4, 1>;
     // registers only: the fused rollout works as for the explicit pair (64-thread workgroups, no LDS)
     k.rollout[PCG_INT_RODAS4][0] = k.rollout[PCG_INT_RODAS4][1] = rollout_kernel<M, PCG_INT_RODAS4, false>;
+    k.queue_r5[0] = step_kernel_queue<M, false, true, PCG_INT_RODAS5>;
+    k.queue_r5[1] = step_kernel_queue<M, true, true, PCG_INT_RODAS5>;
+    k.queue_r5w1[0] = step_kernel_queue<M, false, true, PCG_INT_RODAS5, 1>;
+    k.queue_r5w1[1] = step_kernel_queue<M, true, true, PCG_INT_RODAS5, 1>;
+    k.rollout[PCG_INT_RODAS5][0] = k.rollout[PCG_INT_RODAS5][1] = rollout_kernel<M, PCG_INT_RODAS5, false>;
   }
   k.rhs = rhs_kernel<M>;
   if constexpr (!M::DYNAMIC) {
@@ -1915,6 +1925,7 @@ Kernels make_kernels() {
       k.step[PCG_INT_RK4][pe][1][ex] = k.step[PCG_INT_RK4][pe][0][ex];
       k.step[PCG_INT_RODAS3][pe][1][ex] = k.step[PCG_INT_RODAS3][pe][0][ex];
       k.step[PCG_INT_RODAS4][pe][1][ex] = k.step[PCG_INT_RODAS4][pe][0][ex];
+      k.step[PCG_INT_RODAS5][pe][1][ex] = k.step[PCG_INT_RODAS5][pe][0][ex];
       k.step[PCG_INT_TSIT5][pe][1][ex] = k.step[PCG_INT_TSIT5][pe][0][ex];
       k.step[PCG_INT_RK4G][pe][1][ex] = k.step[PCG_INT_RK4G][pe][0][ex];
       k.step[PCG_INT_T5G][pe][1][ex] = k.step[PCG_INT_T5G][pe][0][ex];
@@ -1926,6 +1937,7 @@ Kernels make_kernels() {
   k.integ[PCG_INT_RK4][1] = k.integ[PCG_INT_RK4][0];
   k.integ[PCG_INT_RODAS3][1] = k.integ[PCG_INT_RODAS3][0];
   k.integ[PCG_INT_RODAS4][1] = k.integ[PCG_INT_RODAS4][0];
+  k.integ[PCG_INT_RODAS5][1] = k.integ[PCG_INT_RODAS5][0];
   if (!k.integ[PCG_INT_DOPRI5][1]) k.integ[PCG_INT_DOPRI5][1] = k.integ[PCG_INT_DOPRI5][0];
   k.nfeat = feat_fill<ID>(k.feat, MAX_FEAT);
   k.has_lds_stages = M::FULL;

@@ -254,9 +254,12 @@ template <int NX, int INTEG>
 struct QLaneSel { using type = DpLane<NX>; };
 template <int NX>
 struct QLaneSel<NX, PCG_INT_RODAS4> { using type = R4Lane<NX>; };
+template <int NX>
+struct QLaneSel<NX, PCG_INT_RODAS5> { using type = R4Lane<NX>; };
 
-// one attempted step: the body of rodas4()'s loop.  Returns -1 to continue, else the final PCG_ST_* status.
-template <class M, class K, class F, class EP>
+// one attempted step: the body of ros_pair()'s loop (INTEG: PCG_INT_RODAS4 or PCG_INT_RODAS5).  Returns -1 to continue, else
+// the final PCG_ST_* status.
+template <class M, int INTEG, class K, class F, class EP>
 PCG_DEV int rodas4_attempt(const K& kp, const typename M::Hold& hold, const F& f, const EP& ep, R4Lane<M::NX>& L, int n,
                            double dt, double dt_edge, double h_floor, double rtol, double atol, int max_steps) {
 #pragma clang fp contract(off)
@@ -271,11 +274,11 @@ PCG_DEV int rodas4_attempt(const K& kp, const typename M::Hold& hold, const F& f
   double f0[NX], xn[NX], err[NX];
   f(L.x, f0);
   const RosStructured<M, K> ls{kp, hold, {}};
-  const bool lu_ok = rodas4_try<NX>(f, ls, L.x, f0, h, xn, err);
-  double E2 = ms_scaled_ep<NX>(ep, dt - (L.t + h), err, L.x, xn, n, rtol, atol);
+  const bool lu_ok = ros_pair_try<INTEG, NX>(f, ls, L.x, f0, h, xn, err);
+  double E2 = ms_scaled_ep<NX>(ep, dt - (L.t + h), err, L.x, xn, n, rtol, atol, ros_ep_cap<INTEG>(dt - (L.t + h), h));
   if (!lu_ok) E2 = __builtin_nan("");
   const bool ok = E2 < 1.0;
-  const double fac = rodas4_factor(E2, ok, L.rejected_last);
+  const double fac = ros_pair_factor<INTEG>(E2, ok, L.rejected_last);
   L.t = ok ? L.t + h : L.t;
   L.h = h * fac;
 #pragma unroll
@@ -360,7 +363,7 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
         if (Q.lean) {
           double f0[NX], d1;
           f(L.x, f0);
-          L.h = rodas4_h_init<NX>(L.x, f0, NX, dt, rtol, atol, d1);
+          L.h = rodas4_h_init<NX, INTEG>(L.x, f0, NX, dt, rtol, atol, d1);
         } else {
           L.h = Q.hs[slot];
         }
@@ -420,9 +423,9 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
       const typename M::Hold hold = M::hold(kp, u);
       const RhsFn<M> f{kp, hold};
       int st;
-      if constexpr (INTEG == PCG_INT_RODAS4) {
+      if constexpr (is_ros_pair(INTEG)) {
         const EpWeights<M, typename M::CKP> ep{kp, u, ep_c, ep_kmax};
-        st = rodas4_attempt<M>(kp, hold, f, ep, L, NX, dt, dt_edge, h_floor, rtol, atol, max_steps);
+        st = rodas4_attempt<M, INTEG>(kp, hold, f, ep, L, NX, dt, dt_edge, h_floor, rtol, atol, max_steps);
       } else {
         st = dopri5_attempt<NX>(f, L, NX, dt, dt_edge, h_floor, rtol, atol, max_steps);
       }
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
   int32_t* nq = next + 1;     // fix-up launch: number of marked envs parked in this round
   int32_t* nheavy = next + 2; // cooperative rule (Rodas4): heavy envs of the tile = its first sorted slots ...
   int32_t* cnext = next + 3;  // ... and the head of their queue
-  constexpr bool COOP = INTEG == PCG_INT_RODAS4 && has_coop<M>::value && !FIX;
+  constexpr bool COOP = is_ros_pair(INTEG) && has_coop<M>::value && !FIX;
   const bool coop = COOP && c.coop_thr > 0.0;
   const bool xlds = (A.q_tile & 0x20000) != 0;  // the tile's state lives in LDS (host: it fits)
   double* xs = reinterpret_cast<double*>(next + 4);  // [NX][T] when xlds (8-byte aligned: every array before it is)
@@ -706,10 +709,10 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
       double k1[NX];
       double d1, h;
       bool heavy = false;
-      if constexpr (INTEG == PCG_INT_RODAS4) {
+      if constexpr (is_ros_pair(INTEG)) {
         f(x, k1);
         double d0;
-        h = rodas4_h_init<NX>(x, k1, NX, dt, rtol, atol, d1, &d0);
+        h = rodas4_h_init<NX, INTEG>(x, k1, NX, dt, rtol, atol, d1, &d0);
         if constexpr (COOP) {  // the cooperative rule (the statements of seulex8_if_heavy): SEULEX-8's first big step instead
           if (coop && M::coop_key(kp, pre.u, d1) >= c.coop_thr) {
             heavy = true;
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(QB, WAVES > 0 ? WAVES : wpe(M::NX, PCG_INT_DOPRI5, 
       // already computed for the initial step size).  A least-squares fit on BASELINE configs[2] puts the weight at
       // 33 (correlation with the measured step counts 0.84 -> 0.96, list-scheduling efficiency of independent lanes
       // 0.836 -> 0.862); lock-stepped waves prefer less: measured optimum ~20 (pcg_abi.hip, profiles/r2/queue_w_sweep.txt)
-      if constexpr (INTEG == PCG_INT_RODAS4)  // fitted attempts per env step of the Rosenbrock pair (pcg_models.hpp)
+      if constexpr (is_ros_pair(INTEG))  // fitted attempts per env step of the (fourth-order) Rosenbrock pair (pcg_models.hpp)
         key = M::cost_key_ros(kp, pre.u) + A.q_w * __builtin_logf(__builtin_fmaxf((float)d1, 1.0f));
       else if constexpr (has_cost_key<M>::value)
         key = (float)(M::cost_key(kp, pre.u) * dt) + A.q_w * __builtin_logf(__builtin_fmaxf((float)d1, 1.0f));

@@ -81,11 +81,11 @@ def collect_rollouts(env, policy=None, actions=None):
     # the fused rollout records observations and rewards, not the constraint rows; per-env parameters roll through the
     # general rollout kernel's UNC form (RK4 / explicit pair, round 4); the 20-state DOPRI5 rollout kernel is slower than stepping (tools/rollout_probe.py)
     # (user models: the run-time compiled module carries its own rollout kernel for the register-only integrators)
-    fused_ok = (not s.ncon and (not s.nunc or s.integrator in ("rk4", "dopri5")) and (s.integrator not in ("rodas3", "rodas4", "tsit5") or (s.integrator == "rodas4" and s.model.name == "multistage_extraction"))
+    fused_ok = (not s.ncon and (not s.nunc or s.integrator in ("rk4", "dopri5")) and (s.integrator not in ("rodas3", "rodas4", "rodas5", "tsit5") or (s.integrator in ("rodas4", "rodas5") and s.model.name == "multistage_extraction"))
                 and (s.user_rhs_src is None or s.integrator in ("rk4", "cv8", "dopri5"))
                 # a plan with user expressions runs from its run-time compiled module, which carries a rollout kernel only
                 # for the register-only explicit schemes (pcg_abi.hip: jit_kernels): the Rosenbrock pairs step instead
-                and not ((s.user_reward_src or s.user_cons_src) and s.integrator in ("rodas3", "rodas4"))
+                and not ((s.user_reward_src or s.user_cons_src) and s.integrator in ("rodas3", "rodas4", "rodas5"))
                 and (s.integrator in ("rk4", "cv8") or s.nx <= 10))
     if actions is not None:
         actions = actions.to(device=dev, dtype=f64)
