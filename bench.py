@@ -17,9 +17,10 @@ launch, pcg_step_autoreset).  value = total env-steps / wall time (max over rank
              --integrator rk4 gives the RK4 x5 plan it replaced)
   me10       configs[2]: multistage_extraction (10 states) B = 262,144, adaptive DOPRI5 rtol = atol = 1e-8, dt = 1,
              (L, G) per env over the FULL action box [5,10]..[500,1000], x0 = doc ICs x (1 + 0.05 U(-1,1))
-  me10_ros4  the same envs, actions and starts through the stiff pair the engine now defaults to for this model (Rodas4 with
-             the cascade's structured linear algebra and end-point error control, rtol = atol = 3e-8): beside the named
-             RK45 line, not instead of it
+  me10_ros5  the same envs, actions and starts under the model's DEFAULT plan: the fifth-order Rosenbrock pair (Rodas5) with
+             the cascade's structured linear algebra and end-point error control, rtol = atol = 8e-8 (the accuracy class of
+             the named pair at 1e-8: <= 1e-6 of a 1e-13 solve) -- beside the named RK45 line, not instead of it
+  me10_ros4  ... under the fourth-order pair (Rodas4, 3e-8, cooperative rule on): the default plan of rounds 3-4
   me20       the 20-state reactive variant, same protocol
   cryst      configs[3]: crystallization B = 262,144, RK4 x32 per dt = 1, a_delta on
   mixed      configs[4], one shard: 1,048,572 envs = 349,524 each of cstr + Ti ~ N(350, 2) / four_tank /
@@ -103,7 +104,8 @@ def mixed_segments(B_shard):
       four_tank (set-point step changes h3 0.5 -> 0.1, h4 0.2 -> 0.3, 4tank_train.py:54-57), undisturbed: the model has
         no disturbance input (model_classes.py:926 lists ["None"]),
       multistage_extraction with X0 ~ N(0.6, 0.02) clipped to [0.5, 0.8] (X5 0.3 -> 0.4 -> 0.3; the model's default
-        integrator: Rodas4, rtol = atol = 3e-8 -- configs[4] names none; --integrator dopri5 gives round 2's line).
+        integrator: Rodas5, rtol = atol = 8e-8 -- configs[4] names none; --integrator rodas4 / dopri5 give the lines of
+        rounds 3-4 / round 2).
     Returns [(env_params, n_envs)] in the global layout [cstr | four_tank | ME]."""
     import numpy as np
 
@@ -145,11 +147,11 @@ def single_workload(name):
         return "cstr_b2^20_default-plan(tsit5g)_full-x0-box_fp64", p, 1 << 20, (1180, 118), 64
     if name == "four_tank":
         return "four_tank_b2^20_cv8x1_fp64", copy.deepcopy(S["four_tank_canonical"]["env_params"]), 1 << 20, (1180, 118), 16
-    if name == "me10_ros4":
+    if name in ("me10_ros4", "me10_ros5"):
         wl, p, B, kw, na = single_workload("me10")
-        p.update(integrator="rodas4")
-        p.pop("rtol"), p.pop("atol")  # the integrator's own default for this model (config.ROS4_TOL: 3e-8)
-        return wl.replace("dopri5_1e-8", "rodas4_3e-8_endpoint"), p, B, kw, na
+        p.update(integrator="rodas" + name[-1])
+        p.pop("rtol"), p.pop("atol")  # the integrator's own default for this model (config.ROS4_TOL: 3e-8, ROS5_TOL: 8e-8)
+        return wl.replace("dopri5_1e-8", "rodas4_3e-8_endpoint" if name == "me10_ros4" else "rodas5_8e-8_endpoint"), p, B, kw, na
     if name in ("me10", "me20"):
         p = copy.deepcopy(S["me_canonical" if name == "me10" else "me_reactive"]["env_params"])
         nx = 10 if name == "me10" else 20
@@ -463,7 +465,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cstr", choices=["cstr", "cstr_safe", "four_tank", "me10", "me10_ros4", "me20", "cryst", "cryst_cv8", "mixed"])
+    ap.add_argument("--workload", default="cstr", choices=["cstr", "cstr_safe", "four_tank", "me10", "me10_ros4", "me10_ros5", "me20", "cryst", "cryst_cv8", "mixed"])
     ap.add_argument("--batch", type=int, default=None, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=None, help="fixed OpenMP team of the cpu_baseline leg (default min(16, avail))")
@@ -613,7 +615,7 @@ def main():
         if args.coop_thr is not None and params.get("integrator") in ("rodas4", "rodas5"):
             params["cooperative"] = {"thr": args.coop_thr} if args.coop_thr > 0 else False
             wl_name += f"+coop{args.coop_thr:g}"
-        if os.environ.get("PCG_BENCH_ME_TOL") and args.workload in ("me10", "me10_ros4", "me20"):  # measurement switch
+        if os.environ.get("PCG_BENCH_ME_TOL") and args.workload in ("me10", "me10_ros4", "me10_ros5", "me20"):  # measurement switch
             params.update(rtol=float(os.environ["PCG_BENCH_ME_TOL"]), atol=float(os.environ["PCG_BENCH_ME_TOL"]))
             wl_name += "+tol" + os.environ["PCG_BENCH_ME_TOL"]
         B = args.batch or Bd

@@ -31,7 +31,7 @@ def test_enums_match_header():
     assert int(ids["PCG_MODEL_CRYST"]) == M.CRYST and int(ids["PCG_MODEL_AFFINE"]) == M.AFFINE
     ints = dict(re.findall(r"(PCG_INT_[A-Z0-9]+) = (\d+)", HDR))
     assert int(ints["PCG_INT_RK4"]) == abi.PCG_INT_RK4 and int(ints["PCG_INT_DOPRI5"]) == abi.PCG_INT_DOPRI5
-    assert int(ints.pop("PCG_INT_COUNT")) == len(ints) == 8
+    assert int(ints.pop("PCG_INT_COUNT")) == len(ints) == 9 and int(ints["PCG_INT_RODAS5"]) == abi.PCG_INT_RODAS5 == 8
     for name, v in ints.items():
         assert getattr(abi, name) == int(v), name
 
@@ -93,7 +93,7 @@ def test_cfg_validate_rejects_bad_input():
     base = SC.scenarios()["cstr_canonical"]["env_params"]
     cfg, keep = EnvSpec(base).to_cfg()
     assert lib.pcg_cfg_validate(None) == abi.PCG_E_NULL
-    for field, val, code in [("model_id", 77, abi.PCG_E_MODEL), ("integrator_id", 8, abi.PCG_E_MODEL),
+    for field, val, code in [("model_id", 77, abi.PCG_E_MODEL), ("integrator_id", abi.PCG_INT_RODAS5 + 1, abi.PCG_E_MODEL),
                              ("nx", 3, abi.PCG_E_DIM), ("N", 1, abi.PCG_E_DIM), ("dt", -1.0, abi.PCG_E_VALUE),
                              ("nsp", 9, abi.PCG_E_DIM), ("n_params", 3, abi.PCG_E_DIM)]:
         c2, k2 = EnvSpec(base).to_cfg()

@@ -37,7 +37,7 @@ def test_single_rank_line():
     assert d["config"]["ranks_seen"] == 1
 
 
-@pytest.mark.parametrize("wl,batch,steps", [("mixed", 30000, 8), ("mixed", 30000, 59), ("me10", 8192, 6), ("me10_ros4", 8192, 6), ("cryst", 8192, 6), ("cryst_cv8", 8192, 6), ("cstr_safe", 65536, 20), ("four_tank", 65536, 20)])
+@pytest.mark.parametrize("wl,batch,steps", [("mixed", 30000, 8), ("mixed", 30000, 59), ("me10", 8192, 6), ("me10_ros4", 8192, 6), ("me10_ros5", 8192, 6), ("cryst", 8192, 6), ("cryst_cv8", 8192, 6), ("cstr_safe", 65536, 20), ("four_tank", 65536, 20)])
 def test_other_workloads_line(wl, batch, steps):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--batch", str(batch), "--steps",
                         str(steps), "--warmup", "2", "--preheat-ms", "10", "--no-cpu-baseline"], capture_output=True,
@@ -124,7 +124,7 @@ def test_gpus_n_as_typed_starts_its_own_ranks():
 
 
 @pytest.mark.parametrize("wl,batch,steps", [("cstr", 65536, 70), ("mixed", 30000, 8), ("cstr_safe", 65536, 20),
-                                            ("four_tank", 65536, 20), ("me10_ros4", 16384, 6), ("me20", 16384, 4),
+                                            ("four_tank", 65536, 20), ("me10_ros4", 16384, 6), ("me10_ros5", 16384, 6), ("me20", 16384, 4),
                                             ("cryst_cv8", 16384, 10)])
 def test_eight_rank_launch_path_on_one_device(wl, batch, steps):
     """No 8-GPU node is available to the builder: the EIGHT-rank code path of the command the driver types

@@ -211,7 +211,12 @@ def test_integrator_selection():
     sf = EnvSpec(P("four_tank_canonical"))  # one order-8 step per canonical dt
     assert sf.integrator == "cv8" and sf.substeps == 1 and sf.to_cfg()[0].integrator_id == abi.PCG_INT_CV8
     sm = EnvSpec(P("me_canonical"))                            # stiff: the Rosenbrock pair with end-point control
-    assert sm.integrator == "rodas4" and sm.rtol == 3e-8 and sm.atol == 3e-8 and (sm.ep_frac, sm.ep_kmax) == (0.5, 10)
+    assert sm.integrator == "rodas5" and sm.rtol == 8e-8 and sm.atol == 8e-8 and (sm.ep_frac, sm.ep_kmax) == (0.5, 12)
+    assert sm.coop_thr == 0.0 and sm.to_cfg()[0].integrator_id == abi.PCG_INT_RODAS5
+    p4 = P("me_canonical")
+    p4["integrator"] = "rodas4"                                # round 3's plan stays available, cooperative rule on
+    s4 = EnvSpec(p4)
+    assert s4.rtol == 3e-8 and s4.atol == 3e-8 and (s4.ep_frac, s4.ep_kmax) == (0.5, 10) and s4.coop_thr == 60.0
     pj = P("me_canonical")
     pj["integration_method"] = "jax"                           # the reference's explicit 5(4) path keeps its semantic
     assert EnvSpec(pj).integrator == "tsit5" and EnvSpec(pj).rtol == 1e-8 and EnvSpec(pj).ep_kmax == 0
@@ -578,7 +583,7 @@ def test_integrators_without_a_per_env_parameter_kernel_are_refused_by_name():
     p.update(uncertainty_percentages={"q": 0.1}, uncertainty_bounds={"low": np.array([80.0]), "high": np.array([120.0])},
              distribution="uniform")
     assert EnvSpec(copy.deepcopy(p)).integrator == "dopri5"  # the default moves to a pair that has the kernel
-    for integ in ("rodas4", "rodas3", "tsit5g", "rk4g", "cv8", "tsit5"):
+    for integ in ("rodas4", "rodas5", "rodas3", "tsit5g", "rk4g", "cv8", "tsit5"):
         with pytest.raises(ValueError, match="use 'rk4' or 'dopri5'"):
             EnvSpec(dict(copy.deepcopy(p), integrator=integ))
     assert EnvSpec(dict(copy.deepcopy(p), integrator="rk4")).nunc == 1

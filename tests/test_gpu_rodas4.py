@@ -228,6 +228,7 @@ def test_fused_rollout_equals_stepping_and_dense_path_is_refused():
     from pcgym_amd import VecEnv
 
     p = copy.deepcopy(SC.scenarios()["me_canonical"]["env_params"])
+    p.update(integrator="rodas4")
     B, T = 700, 6
     e1, e2 = VecEnv(p, n_envs=B, seed=3), VecEnv(p, n_envs=B, seed=3)
     assert e1.spec.integrator == "rodas4"

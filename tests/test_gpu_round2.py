@@ -59,7 +59,7 @@ def test_mixed_batch_with_gaussian_disturbances_vs_oracle():
     mixed = MixedVecEnv(segs, seed=21, env_offset=5 * 10**9, auto_reset=True)
     orcs = [O.OracleEnv(e.spec, e.B, seed=21, env_offset=off) for e, off in zip(mixed.envs, mixed.offsets)]
     assert [e.spec.model.name for e in mixed.envs] == ["cstr", "four_tank", "multistage_extraction"]
-    assert mixed.envs[0].spec.gauss and mixed.envs[2].spec.gauss and mixed.envs[2].spec.integrator == "rodas4"
+    assert mixed.envs[0].spec.gauss and mixed.envs[2].spec.gauss and mixed.envs[2].spec.integrator == "rodas5"
     mixed.reset()
     for o in orcs:
         o.reset()
@@ -772,7 +772,7 @@ def test_step_graph_with_adaptive_kernels(name, B):
 
 
 def test_collector_steps_a_rosenbrock_plan_that_carries_a_reward_expression():
-    """multistage_extraction defaults to Rodas4; with a reward expression (or a traced custom_reward callable)
+    """multistage_extraction defaults to a Rosenbrock pair; with a reward expression (or a traced custom_reward callable)
     the plan runs from its run-time compiled module, which has no fused rollout kernel for the Rosenbrock pairs --
     collect_rollouts(env, actions=...) used to raise PCG_E_UNSUPPORTED there instead of stepping."""
     torch = _torch()
@@ -781,7 +781,7 @@ def test_collector_steps_a_rosenbrock_plan_that_carries_a_reward_expression():
     p = copy.deepcopy(SC.scenarios()["me_canonical"]["env_params"])
     p["custom_reward"] = {"expr": "-1e2*(X5 - SP_X5)*(X5 - SP_X5)"}
     env = VecEnv(copy.deepcopy(p), n_envs=192, seed=4)
-    assert env.spec.integrator == "rodas4" and env.spec.user_reward_src
+    assert env.spec.integrator == "rodas5" and env.spec.user_reward_src
     ref = VecEnv(copy.deepcopy(p), n_envs=192, seed=4)
     gen = torch.Generator(device="cuda").manual_seed(8)
     acts = 0.3 * (2 * torch.rand((env.spec.N, env.spec.na, 192), generator=gen, device="cuda", dtype=torch.float64) - 1) - 0.6

@@ -421,7 +421,7 @@ def test_python_model_object_is_traced_and_equals_the_declarative_model(with_dis
     ed.close(), eo.close()
 
 
-@pytest.mark.parametrize("integ", ["rodas3", "rodas4"])
+@pytest.mark.parametrize("integ", ["rodas3", "rodas4", "rodas5"])
 def test_user_model_with_the_stiff_pairs_past_48_kb_of_lds(integ):
     """a 12-state user model needs 12^2 x 64 x 8 B = 72 KB of LDS for the per-lane matrices of the Rosenbrock pairs:
     the run-time compiled kernels get the larger dynamic-LDS limit at plan creation (such plans used to be

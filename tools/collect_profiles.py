@@ -18,7 +18,7 @@ def last(f):
     return lines[-1] if lines else None
 
 
-for w in "cstr cstr_safe four_tank me10 me10_ros4 me20 cryst cryst_cv8 mixed".split():
+for w in "cstr cstr_safe four_tank me10 me10_ros4 me10_ros5 me20 cryst cryst_cv8 mixed".split():
     src = os.path.join(ROOT, "gpurun_out", "prof_" + w)
     if not os.path.exists(os.path.join(src, "summary.txt")):
         continue
@@ -48,7 +48,7 @@ if sess:
     put("bench_runs.jsonl", [os.path.join(s, f"bench_default_run{i}.json") for i in (1, 2, 3)])
     put("bench_driver_shape_runs.jsonl", [os.path.join(s, f"bench_driver_shape_run{i}.json") for i in (1, 2, 3)])
     put("bench_workloads.jsonl", [os.path.join(s, f"bench_{w}.json") for w in
-                                  "cstr_safe four_tank four_tank_rk4 me10 me10_ros4 me20 cryst cryst_cv8 mixed".split()])
+                                  "cstr_safe four_tank four_tank_rk4 me10 me10_ros4 me10_ros5 me20 cryst cryst_cv8 mixed".split()])
     put("bench_graph.json", [os.path.join(s, "bench_graph.json")])
     if os.path.exists(os.path.join(s, "bench_all.txt")):
         shutil.copy(os.path.join(s, "bench_all.txt"), os.path.join(dst, "bench_all.txt"))
