@@ -1112,7 +1112,11 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       // Rodas4, launches of at most ~one full tile per CU (measured: 1024 envs per CU 0.361 -> 0.337 ms; 1366 per CU no
       // difference; 4096 per CU 1.47 -> 1.71 ms): ONE workgroup per CU on the instantiation that keeps the whole loop in
       // registers, every wave alone on its SIMD
-      int w1_cap = 1200;  // envs per CU up to which the one-workgroup-per-CU shape is taken
+      // (the fifth-order pair spills more at two waves per SIMD -- 480 B of scratch per lane against 352 -- and takes the shape up to
+      // the 1366 envs per CU of BASELINE configs[4]'s segment, whose lean tile of 1408 slots still fits the CU's LDS with its
+      // state: 330 against 337 us per step, HBM traffic 1.06 x the algorithmic bytes against 1.9 x; under the fourth-order pair
+      // the same shape was 12 % SLOWER than two workgroups per CU, profiles/r5/mixed_lean_layout.txt, mixed_rodas5.txt)
+      int w1_cap = p->integrator_id == PCG_INT_RODAS5 ? 1500 : 1200;  // envs per CU up to which the one-workgroup-per-CU shape is taken
       if (const char* ev = std::getenv("PCG_Q_W1CAP")) w1_cap = std::atoi(ev);  // measurement switch
       bool w1 = r4q && q_w1[pe] && p->q_tile1[pe] >= QBLOCK && io->B <= (int64_t)p->num_cus * w1_cap &&
                 io->B > (int64_t)p->num_cus * QBLOCK;
