@@ -318,25 +318,28 @@ typedef struct pcg_env_cfg {
   /* PCG_MODEL_USER: the model's right-hand side (the reference's custom_model.__call__(x, u), pcgym.py:150-153) as C
    * statements that fill dx[0 .. nx-1] (double) from x[] (nx states), u[] (na inputs, then ndm disturbance inputs) and
    * p[] (n_params parameters = cfg.params).  Compiled with hipRTC into this plan's general step kernel (both time
-   * modes), pcg_integrate, pcg_rhs and pcg_rollout (the last not for PCG_INT_RODAS3 / PCG_INT_RODAS4); any integrator;
+   * modes), pcg_integrate, pcg_rhs and pcg_rollout (the last not for PCG_INT_RODAS3 / PCG_INT_RODAS4 / PCG_INT_RODAS5); any integrator;
    * composes with user_cons_src / user_reward_src.  Not available: per-env uncertain parameters. */
   const char* user_rhs_src;
-  /* PCG_INT_RODAS4, end-point error control (see enum pcg_integrator): 0 / 0 = classical local error control */
+  /* PCG_INT_RODAS4 / PCG_INT_RODAS5, end-point error control (see enum pcg_integrator): 0 / 0 = classical local error control */
   double ep_frac;         /* fraction of the model's contraction rate credited to the damping (0.5 by default: the cascade
                              is non-normal -- a perturbation travels down the stages before it decays)                 */
-  int32_t ep_kmax;        /* largest exponent: tolerances are relaxed by at most 2^ep_kmax (10 by default, 0 = off)    */
+  int32_t ep_kmax;        /* largest exponent: tolerances are relaxed by at most 2^ep_kmax (0 = off; the Python side's defaults:
+                             10 under PCG_INT_RODAS4, 12 under PCG_INT_RODAS5, whose attempts additionally cap the exponent
+                             at 2 bits per remaining step of their size, trunc(2 (dt - t') / h): a Rosenbrock step damps a
+                             stiff component by |R(h lambda)| ~ 0.1-0.16 only, whatever exp(h lambda) says)              */
   /* Disturbances TOGETHER with per-env uncertain parameters (pcgym.py:291-316, 386-412; quirk Q11).  The state /
    * observation layout is the reference's reset() order [x | SP | d | unc] in reset AND step (its step() writes the
    * disturbance slots at another offset -- the one place where this engine deliberately does not follow it); a model
    * disturbance input that is NOT configured takes the env's own (possibly uncertain) parameter value, as the
    * reference's `self.model.info()["parameters"][k]` does (pcgym.py:400-404).  d_param_index names that parameter. */
   const int32_t* d_param_index; /* [ndm] or NULL: index in `params` of each model disturbance input                  */
-  /* PCG_INT_RODAS4 on a model with a cooperative rule (multistage_extraction with eq_exponent == 2): env steps whose
+  /* PCG_INT_RODAS4 / PCG_INT_RODAS5 on a model with a cooperative rule (multistage_extraction with eq_exponent == 2): env steps whose
    * predicted cost -- the model's fit of the pair's attempts per env step from the held input and the scaled size of
    * f(x0), in exact arithmetic -- reaches coop_thr are integrated by SEULEX-8 (extrapolated linearly implicit Euler, fixed
    * column of eight, same accuracy class: pcg_seulex.hpp) instead of the pair.  In the work-queue kernel eight lanes share
    * such an env (one row of the extrapolation tableau each), elsewhere one lane runs the eight rows: the same bits either
-   * way.  A launch is as long as its heaviest env; this is what shortens it (the reference's CVODES integrates a stiff
+   * way (the threshold counts attempts of the FOURTH-order pair under either).  A launch is as long as its heaviest env; this is what shortens it (the reference's CVODES integrates a stiff
    * column at a cost that does not depend on its batch-mates, integrator.py:163-182).  0 = off (every env takes the pair);
    * nsteps then counts big steps for the heavy envs.  PCG_E_UNSUPPORTED for other models / integrators when > 0. */
   double coop_thr;

@@ -151,13 +151,13 @@ PCG_DEV int dopri5_attempt(const F& f, DpLane<NX>& L, int n, double dt, double d
     h = dt - L.t;
     last = true;
   }
+  using namespace dp5;
   // ACCUMULATOR FORM.  The stage sums are left-to-right fused multiply-add chains (dp5_row(): for NX > 4 starting at x with the step
   // size folded into the coefficients): once k4 is there, the partial sums of the rows still to come (stage 6, the 5th-order
   // solution, the error estimate) are formed and k2..k4 are dead; k5 and k6 are folded in as they arrive.  The same
   // operations on the same operands in the same order as dopri5()'s rows -- bit for bit -- with at most six NX-vectors
   // alive instead of eight: the 20-state cascade's attempt carried 216 8-byte moves to and from the accumulation
   // registers (256 + 166 registers: one wave per SIMD) for 1390 fp64 operations; the 10-state one fits either way.
-  using namespace dp5;
   constexpr bool FOLD = dp5_fold(NX);
   double y[NX], kk[NX], k2[NX], k3[NX], s6[NX], s7[NX], se[NX];
   const double (&x)[NX] = L.x;
@@ -290,6 +290,11 @@ PCG_DEV int rodas4_attempt(const K& kp, const typename M::Hold& hold, const F& f
   return !(L.h > h_floor) ? PCG_ST_UNDERFLOW : -1;
 }
 
+#ifndef PCG_Q_TAIL
+#define PCG_Q_TAIL 2
+#endif
+constexpr bool q_tail(bool fixup) { return PCG_Q_TAIL >= 2 || (PCG_Q_TAIL == 1 && fixup); }
+
 // ---- phase 2: the work queue of one tile.  (Tried as a real, non-inlined function so that the loop would own the
 // whole register file: the call ABI's save / restore made it worse -- 772 B of scratch against 140.)
 template <class M, int INTEG = PCG_INT_DOPRI5, int QB = QBLOCK, bool COMPACT = false>
@@ -403,6 +408,41 @@ PCG_DEV void queue_integrate(typename M::CKP* kpp, double* xg, int64_t xstride, 
       if (got < n) continue;
     }
     if (bm == 0ull) break;  // nothing in flight in this wave and the queue is empty
+    // ---- TAIL: the queue holds nothing more for this wave, every busy lane finishes the env it has ----
+    // Once `drained` no lane of this wave will be handed another env: what is left is the classic one-env-per-lane loop, and
+    // it is run as such -- the held input and the model's per-step constants in registers, no ballot, no queue head, no
+    // priority bookkeeping per attempt.  The attempt is the same function on the same lane state: the same bits.  A wave
+    // that has its SIMD to itself issues ONE instruction every four cycles whatever its kind, so the ~100 instructions of
+    // bookkeeping per iteration cost it as much as 100 fused multiply-adds.  Measured (profiles/r5/queue_tail.txt): the
+    // default cstr plan on the full x0 box 175 -> 167 us per step (its fix-up launch is one lane's chain across an ignition
+    // front), me10 610 -> 581, me20 334 -> 320, me10_ros5 223.5 -> 217.5, configs[4]'s shard 332 -> 329.
+    // PCG_Q_TAIL (A/B builds): 0 = off, 1 = the fix-up launch only, 2 = every work-queue kernel (the default).
+    if constexpr (q_tail(COMPACT)) {
+      if (drained) {  // (wave-uniform; no lane is `fresh` here: a fresh lane was refilled at the top of this iteration)
+        if (prio_h > 0 && !wave_hi) __builtin_amdgcn_s_setprio(0);
+        if (busy) {
+          double u[NU];
+          Q.load_u(slot, u);
+          const typename M::Hold hold = M::hold(kp, u);
+          const RhsFn<M> f{kp, hold};
+          int st;
+          if constexpr (is_ros_pair(INTEG)) {
+            const EpWeights<M, typename M::CKP> ep{kp, u, ep_c, ep_kmax};
+            do st = rodas4_attempt<M, INTEG>(kp, hold, f, ep, L, NX, dt, dt_edge, h_floor, rtol, atol, max_steps);
+            while (st < 0);
+          } else {
+            do st = dopri5_attempt<NX>(f, L, NX, dt, dt_edge, h_floor, rtol, atol, max_steps);
+            while (st < 0);
+          }
+          poison_if_failed<NX>(st, L.x);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xg[(size_t)i * xstride + xpos(slot)] = L.x[i];
+          Q.finish(slot, L.acc, L.rej, st);
+          slot = -1;
+        }
+        break;
+      }
+    }
 #ifdef PCG_QSTATS
     ++qs_att;
     qs_busy += __popcll(bm);
