@@ -96,7 +96,7 @@ def _random_params(rng):
     return p
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PCG_LIVE_SEEDS", "48"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PCG_LIVE_SEEDS", "128"))))
 def test_random_config_oracle_matches_reference(ref, seed):
     from oracle import oracle as O
     from pcgym_amd.config import EnvSpec
