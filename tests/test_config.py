@@ -211,7 +211,7 @@ def test_integrator_selection():
     sf = EnvSpec(P("four_tank_canonical"))  # one order-8 step per canonical dt
     assert sf.integrator == "cv8" and sf.substeps == 1 and sf.to_cfg()[0].integrator_id == abi.PCG_INT_CV8
     sm = EnvSpec(P("me_canonical"))                            # stiff: the Rosenbrock pair with end-point control
-    assert sm.integrator == "rodas5" and sm.rtol == 8e-8 and sm.atol == 8e-8 and (sm.ep_frac, sm.ep_kmax) == (0.5, 12)
+    assert sm.integrator == "rodas5" and sm.rtol == 8e-8 and sm.atol == 8e-8 and (sm.ep_frac, sm.ep_kmax) == (0.5, 16)
     assert sm.coop_thr == 0.0 and sm.to_cfg()[0].integrator_id == abi.PCG_INT_RODAS5
     p4 = P("me_canonical")
     p4["integrator"] = "rodas4"                                # round 3's plan stays available, cooperative rule on

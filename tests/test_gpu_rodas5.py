@@ -155,7 +155,7 @@ def test_full_size_configs2_rodas5():
     p = copy.deepcopy(SC.scenarios()["me_canonical"]["env_params"])
     p.update(integrator="rodas5", N=200, tsim=200.0, SP={"X5": [0.3] * 200})
     env = VecEnv(p, n_envs=B)
-    assert env.spec.rtol == 8e-8 and env.spec.ep_kmax == 12 and env.spec.coop_thr == 0.0
+    assert env.spec.rtol == 8e-8 and env.spec.ep_kmax == 16 and env.spec.coop_thr == 0.0
     env.reset()
     x0 = env.x * (1 + 0.05 * (2 * torch.rand(env.x.shape, generator=gen, device="cuda", dtype=torch.float64) - 1))
     env.x.copy_(x0)
