@@ -325,7 +325,7 @@ typedef struct pcg_env_cfg {
   double ep_frac;         /* fraction of the model's contraction rate credited to the damping (0.5 by default: the cascade
                              is non-normal -- a perturbation travels down the stages before it decays)                 */
   int32_t ep_kmax;        /* largest exponent: tolerances are relaxed by at most 2^ep_kmax (0 = off; the Python side's defaults:
-                             10 under PCG_INT_RODAS4, 12 under PCG_INT_RODAS5, whose attempts additionally cap the exponent
+                             10 under PCG_INT_RODAS4, 16 under PCG_INT_RODAS5, whose attempts additionally cap the exponent
                              at 2 bits per remaining step of their size, trunc(2 (dt - t') / h): a Rosenbrock step damps a
                              stiff component by |R(h lambda)| ~ 0.1-0.16 only, whatever exp(h lambda) says)              */
   /* Disturbances TOGETHER with per-env uncertain parameters (pcgym.py:291-316, 386-412; quirk Q11).  The state /

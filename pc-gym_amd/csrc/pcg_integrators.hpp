@@ -1310,9 +1310,77 @@ PCG_DEV double rodas4_h_init(const double (&x)[NX], const double (&f0)[NX], int 
 }
 // the two Rosenbrock pairs behind one name: attempt and controller verdict of PCG_INT_RODAS4 / PCG_INT_RODAS5
 constexpr bool is_ros_pair(int integ) { return integ == PCG_INT_RODAS4 || integ == PCG_INT_RODAS5; }
+// LARGE MODELS (NX > 16: the dense-W path of the 20- and 24-state models and of user models that size).  The attempt with
+// its component loops fully unrolled gives the step kernels of such a model ~1400 spilled scalar registers on top of all 512
+// vector registers, and in that regime the compiler's spill code is not reliable: the 24-state registry model's lock-stepped
+// PCG_INT_RODAS4 / PCG_INT_RODAS5 step kernels returned a garbage x[2] (scalar spills in vector-register lanes) or x[0]
+// (scalar spills in memory) for some or most envs, correct only at -O1 -- found by the round-5 fuzz once it covered all three
+// Rosenbrock integrators (tests/test_gpu_rodas4.py::test_step_kernels_of_the_large_models_dense_path,
+// tools/ros_dense_sweep.py).  Here the SAME arithmetic (the rows' fused multiply-adds innermost-first, as rodas4_try /
+// rodas5_try write them) is written as loops that stay loops: the tableau read from tables, the stage vectors indexed at run
+// time (private memory).  The per-lane LU of these models dominates their attempt anyway.
+namespace r4 {
+constexpr double A[5][4] = {{0, 0, 0, 0}, {A21, 0, 0, 0}, {A31, A32, 0, 0}, {A41, A42, A43, 0}, {A51, A52, A53, A54}};
+constexpr double C[6][5] = {{0, 0, 0, 0, 0},         {C21, 0, 0, 0, 0},       {C31, C32, 0, 0, 0},
+                            {C41, C42, C43, 0, 0},   {C51, C52, C53, C54, 0}, {C61, C62, C63, C64, C65}};
+}  // namespace r4
+template <int INTEG>
+PCG_DEV double ros_tab_a(int s, int j) {
+  if constexpr (INTEG == PCG_INT_RODAS5) return r5::A[s][j];
+  else return r4::A[s][j];
+}
+template <int INTEG>
+PCG_DEV double ros_tab_c(int s, int j) {
+  if constexpr (INTEG == PCG_INT_RODAS5) return r5::C[s][j];
+  else return r4::C[s][j];
+}
+template <int INTEG, int NX, class F, class LS>
+PCG_DEV bool ros_try_rolled(const F& f, const LS& ls, const double (&x)[NX], const double (&f0)[NX], double h,
+                            double (&xn)[NX], double (&err)[NX]) {
+#pragma clang fp contract(off)
+  // stages, and how many of them have a row of a-coefficients (the remaining two / one start from the previous stage's point)
+  constexpr int S = INTEG == PCG_INT_RODAS5 ? 8 : 6, SA = INTEG == PCG_INT_RODAS5 ? 6 : 5;
+  const double ih = rcp_ieee(h), igh = INTEG == PCG_INT_RODAS5 ? ih * r5::IGAM : 4.0 * ih;
+  const bool lu_ok = ls.factor(x, f0, igh);
+  double U[S][NX], y[NX], fy[NX];
+#pragma unroll 1
+  for (int i = 0; i < NX; ++i) U[0][i] = f0[i];
+  ls.solve(U[0]);
+#pragma unroll 1
+  for (int s = 1; s < S; ++s) {
+    if (s < SA) {
+#pragma unroll 1
+      for (int i = 0; i < NX; ++i) {
+        double v = x[i];
+#pragma unroll 1
+        for (int j = 0; j < s; ++j) v = __builtin_fma(ros_tab_a<INTEG>(s, j), U[j][i], v);
+        y[i] = v;
+      }
+    } else {
+#pragma unroll 1
+      for (int i = 0; i < NX; ++i) y[i] = y[i] + U[s - 1][i];
+    }
+    f(y, fy);
+#pragma unroll 1
+    for (int i = 0; i < NX; ++i) {
+      double v = fy[i];
+#pragma unroll 1
+      for (int j = 0; j < s; ++j) v = __builtin_fma(ros_tab_c<INTEG>(s, j) * ih, U[j][i], v);
+      U[s][i] = v;
+    }
+    ls.solve(U[s]);
+  }
+#pragma unroll 1
+  for (int i = 0; i < NX; ++i) {
+    xn[i] = y[i] + U[S - 1][i];
+    err[i] = U[S - 1][i];
+  }
+  return lu_ok;
+}
 template <int INTEG, int NX, class F, class LS>
 PCG_DEV bool ros_pair_try(const F& f, const LS& ls, const double (&x)[NX], const double (&f0)[NX], double h,
                           double (&xn)[NX], double (&err)[NX]) {
+  if constexpr (NX > 16) return ros_try_rolled<INTEG, NX>(f, ls, x, f0, h, xn, err);
   // (instantiated, and dead, for every INTEG at the kernels' run-time-free `if (INTEG == ...)` chains: anything but
   // PCG_INT_RODAS5 is the fourth-order pair)
   if constexpr (INTEG == PCG_INT_RODAS5) return rodas5_try<NX>(f, ls, x, f0, h, xn, err);
@@ -1325,7 +1393,7 @@ PCG_DEV bool ros_pair_try(const F& f, const LS& ls, const double (&x)[NX], const
 // relaxed by 2^10 they left single envs of the action box at 1.0e-6 - 1.8e-6 (profiles/r5/rodas5_calib.txt).  So the
 // exponent of an attempt of size h is capped at r5::EP_KB bits per remaining step of that size:
 //     k <= trunc(EP_KB tau / h),   EP_KB = 2
-// (scanned: 3 and 4 leave outliers again, 1 and 0.5 cost attempts; with the cap the largest exponent can grow to 12: 11.3
+// (scanned: 3 and 4 leave outliers again, 1 and 0.5 cost attempts; with the cap the largest exponent can grow to 16: 10.8
 // attempts per env step against 13.3 at exponents up to 8 without it, same worst case).  Exact arithmetic: tau (1/h), a
 // scaling by two, a truncation -- the kernels and the oracle cap alike.  The fourth-order pair keeps its calibration.
 template <int INTEG>

@@ -1475,7 +1475,7 @@ def test_random_configurations_rosenbrock_vs_oracle(seed):
 
     rng = np.random.default_rng(9000 + seed)
     p = _random_params(rng)
-    p.update(integrator="rodas3", rtol=1e-6, atol=1e-8)
+    p.update(integrator=("rodas3", "rodas4", "rodas5")[seed % 3], rtol=1e-6, atol=1e-8)  # (all three pairs: round 5)
     per_env_t = bool(rng.integers(0, 2))
     B = int(rng.choice([130, 257]))
     try:
@@ -1506,7 +1506,8 @@ def test_random_configurations_rosenbrock_vs_oracle(seed):
         # single env can differ by the integrator's own tolerance (8e-7, 1.6e-6 seen) with identical step counts -- both
         # answers are in the 1e-6 accuracy class of the truth (1.1e-5 once in 1000 configurations, on the biofilm model's
         # growing modes).  Hence: 99 % of the envs to round-off, all to 1e-4.
-        assert same.mean() >= 0.97, (seed, i, spec.model.name, same.mean())
+        # (the six- and eight-stage pairs take a few more decisions near a threshold on that model: 96.9 % seen once in 150)
+        assert same.mean() >= (0.97 if seed % 3 == 0 else 0.95), (seed, i, spec.model.name, same.mean())
         assert np.quantile(ex, 0.99) <= ROS_TOL * 10 and ex.max() <= 1e-4, (seed, i, spec.model.name, np.quantile(ex, 0.99), ex.max())
         assert np.mean(dg.cpu().numpy().astype(np.uint8)[ok] == dc[ok]) >= 0.99, (seed, i)
         env.x.copy_(torch.tensor(orc.x, device=env.device))

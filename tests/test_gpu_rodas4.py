@@ -289,3 +289,44 @@ def test_guarded_rk4_vs_oracle_on_the_ignition_box():
             env.x.copy_(torch.tensor(orc.x, device=env.device))  # one-step comparisons
         assert seen_esc > B // 10
         env.close()
+
+
+@pytest.mark.parametrize("scenario", ["heat_exchanger_sp", "biofilm_sp", "me_reactive"])
+@pytest.mark.parametrize("integ", ["rodas3", "rodas4", "rodas5"])
+def test_step_kernels_of_the_large_models_dense_path(scenario, integ):
+    """the GENERAL STEP KERNEL (not pcg_integrate) of the 16- / 20- / 24-state models under the three Rosenbrock integrators,
+    both counter modes, one-step comparisons with the oracle from a common state.  Round 5: the 24-state model's lock-stepped
+    PCG_INT_RODAS4 / PCG_INT_RODAS5 kernels (all 512 vector registers in use, ~1400 spilled scalar registers) came back with a
+    garbage x[2] for most envs under the compiler's scalar-spills-into-vector-lanes -- the fuzz had only covered
+    PCG_INT_RODAS3, and the integration hook is another kernel.  Models with more than 16 states now run the attempt with
+    loops that stay loops (pcg_integrators.hpp: ros_try_rolled: the same arithmetic, a third of the vector spills);
+    tools/ros_dense_sweep.py runs this check over every registry model."""
+    torch = _torch()
+    from oracle import oracle as O
+    from pcgym_amd import VecEnv
+
+    S = SC.scenarios()
+    name = scenario if scenario in S else [k for k in S if k.startswith(scenario.split("_")[0])][0]
+    for per_env_t in (False, True):
+        p = copy.deepcopy(S[name]["env_params"])
+        p.update(integrator=integ, rtol=1e-6, atol=1e-8)
+        B = 130
+        env = VecEnv(copy.deepcopy(p), n_envs=B, seed=3, per_env_t=per_env_t)
+        spec = env.spec
+        orc = O.OracleEnv(spec, B, seed=3, per_env_t=per_env_t)
+        env.reset(), orc.reset()
+        rng = np.random.default_rng(1)
+        for i in range(3):
+            a = rng.uniform(-1, 1, (spec.na, B))
+            if not spec.normalise_a:
+                a = (a + 1) * (spec.a_high - spec.a_low)[:, None] / 2 + spec.a_low[:, None]
+            env.step(torch.tensor(a, device=env.device))
+            orc.step(a)
+            xg = env.x.cpu().numpy()
+            xs = np.maximum(np.abs(orc.x), 1e-6 * np.max(np.abs(orc.x), axis=1, keepdims=True))
+            ex = np.max(np.abs(xg - orc.x) / xs, axis=0)
+            same = np.all(env.nsteps.cpu().numpy() == orc.nsteps, axis=0)
+            assert same.mean() >= 0.95 and ex.max() <= 1e-4 and np.quantile(ex, 0.99) <= 5e-7, (name, integ, per_env_t, i, same.mean(), ex.max())
+            assert not env.status.any()
+            env.x.copy_(torch.tensor(orc.x, device=env.device))
+        env.close()
