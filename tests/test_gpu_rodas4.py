@@ -300,7 +300,7 @@ def test_step_kernels_of_the_large_models_dense_path(scenario, integ):
     garbage x[2] for most envs under the compiler's scalar-spills-into-vector-lanes -- the fuzz had only covered
     PCG_INT_RODAS3, and the integration hook is another kernel.  Models with more than 16 states now run the attempt with
     loops that stay loops (pcg_integrators.hpp: ros_try_rolled: the same arithmetic, a third of the vector spills);
-    tools/ros_dense_sweep.py runs this check over every registry model."""
+    tools/integrator_sweep.py runs this check over every registry model."""
     torch = _torch()
     from oracle import oracle as O
     from pcgym_amd import VecEnv
