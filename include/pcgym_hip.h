@@ -49,7 +49,7 @@ typedef unsigned long uintptr_t;
 extern "C" {
 #endif
 
-#define PCG_ABI_VERSION 13
+#define PCG_ABI_VERSION 14
 
 #ifndef PCG_API
 #define PCG_API __attribute__((visibility("default")))
@@ -505,6 +505,13 @@ PCG_API const char* pcg_last_jit_log(void);
  * use them: S in {512, 1024, 2048}, threads in {256, 512}; anything else PCG_E_UNSUPPORTED.  The step results do not depend
  * on the order of a tile -- this is the only way to see that the sort sorts. */
 PCG_API int pcg_test_sort_tile(uint32_t* words, int32_t S, int32_t threads, int64_t ntiles, void* stream);
+
+/* Kernel-instantiation coverage (TEST HOOK; active only when PCG_COVERAGE is set in the environment at load time, otherwise
+ * returns -1 and records nothing).  Every kernel launch of this library notes the instantiation it launches; this call
+ * writes their MANGLED names, newline-separated and NUL-terminated, into buf (at most cap bytes; run-time compiled kernels
+ * carry the prefix "jit:"), and returns the size the full list needs.  reset != 0 empties the record afterwards.
+ * tests/conftest.py asks after every GPU test; tools/kernel_inventory.py lists what the library carries. (host) */
+PCG_API int64_t pcg_coverage_names(char* buf, int64_t cap, int reset);
 
 /* Raw Philox4x32-10 block for KAT tests: ctr[4], key[2] -> out[4]. (host) */
 PCG_API void pcg_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -15,6 +15,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libpcg_oracle.so")
 _lib = None
+CALLS = [0]  # how often the oracle library was reached for (tests/conftest.py: which GPU tests check against the oracle)
 
 
 def build(force=False):
@@ -26,6 +27,7 @@ def build(force=False):
 
 def lib():
     global _lib
+    CALLS[0] += 1
     if _lib is None:
         if not os.path.exists(LIB):
             build()

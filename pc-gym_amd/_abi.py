@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-PCG_ABI_VERSION = 13
+PCG_ABI_VERSION = 14
 PCG_MAX_NX = 24
 PCG_MAX_NA = 5
 PCG_MAX_NDM = 4
@@ -185,6 +185,7 @@ EXPORTS = [
     "pcg_last_jit_log",
     "pcg_philox4x32_10",
     "pcg_test_sort_tile",
+    "pcg_coverage_names",
 ]
 
 
@@ -242,6 +243,8 @@ def declare(lib):
     lib.pcg_last_jit_log.argtypes = []
     lib.pcg_test_sort_tile.restype = C.c_int
     lib.pcg_test_sort_tile.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, vp]
+    lib.pcg_coverage_names.restype = C.c_int64
+    lib.pcg_coverage_names.argtypes = [C.c_char_p, C.c_int64, C.c_int]
     lib.pcg_philox4x32_10.restype = None
     lib.pcg_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]

@@ -12,10 +12,12 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <cstdlib>
 
 #include <fstream>
 #include <map>
 #include <mutex>
+#include <set>
 #include <sstream>
 #include <string>
 
@@ -119,6 +121,34 @@ static constexpr uint32_t PLAN_MAGIC = 0x50434731u;  // 'PCG1'
     if (_e != hipSuccess) return (int)_e;      \
   } while (0)
 
+// Kernel-instantiation coverage (test infrastructure; off unless PCG_COVERAGE is set in the environment when the library is
+// loaded).  Every launch site passes its kernel through cov(): with coverage on, the host function pointer (or, for a
+// run-time compiled module, the hipFunction_t) is noted in a process-wide set.  pcg_coverage_names() turns the set into
+// the kernels' mangled names -- the names tools/kernel_inventory.py reads out of this library's code objects -- so that
+// the GPU suite can say which of the shipped instantiations it launched, test by test (tests/conftest.py).
+static bool cov_on() {
+  static const bool on = std::getenv("PCG_COVERAGE") != nullptr;
+  return on;
+}
+static std::mutex g_cov_mu;
+static std::set<const void*> g_cov_fn;        // ahead-of-time kernels: host function pointers
+static std::set<hipFunction_t> g_cov_jit;     // run-time compiled kernels
+template <class F>
+static inline F cov(F fn) {
+  if (cov_on()) {
+    std::lock_guard<std::mutex> g(g_cov_mu);
+    g_cov_fn.insert((const void*)fn);
+  }
+  return fn;
+}
+static inline hipFunction_t cov_jit(hipFunction_t fn) {
+  if (cov_on()) {
+    std::lock_guard<std::mutex> g(g_cov_mu);
+    g_cov_jit.insert(fn);
+  }
+  return fn;
+}
+
 // Test hook: the work-queue kernel's tile sort on its own (the step results do not depend on the order, so no parity test
 // can see a sort that does not sort -- only a slower launch would).
 template <int E, int QB>
@@ -133,6 +163,35 @@ __global__ __launch_bounds__(QB) void sort_tile_test_kernel(uint32_t* w) {
 extern "C" {
 
 int pcg_version(void) { return PCG_ABI_VERSION; }
+
+int64_t pcg_coverage_names(char* buf, int64_t cap, int reset) {
+  std::string out;
+  {
+    std::lock_guard<std::mutex> g(g_cov_mu);
+    for (const void* f : g_cov_fn) {
+      const char* n = hipKernelNameRefByPtr(f, nullptr);
+      out += n ? n : "?";
+      out += '\n';
+    }
+    for (hipFunction_t f : g_cov_jit) {
+      const char* n = hipKernelNameRef(f);
+      out += "jit:";
+      out += n ? n : "?";
+      out += '\n';
+    }
+    if (reset) {
+      g_cov_fn.clear();
+      g_cov_jit.clear();
+    }
+  }
+  if (buf && cap > 0) {
+    const size_t n = std::min((size_t)cap - 1, out.size());
+    std::memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return cov_on() ? (int64_t)out.size() + 1 : -1;
+}
+
 #ifndef PCG_SRC_HASH
 #define PCG_SRC_HASH "unknown-build"  // the Makefile passes a digest of csrc/*.hpp, csrc/*.hip and include/pcgym_hip.h
 #endif
@@ -179,12 +238,12 @@ int pcg_test_sort_tile(uint32_t* words, int32_t S, int32_t threads, int64_t ntil
   if (!words || ntiles <= 0 || ntiles > 0x7fffffff) return PCG_E_VALUE;
   const dim3 g((unsigned)ntiles);
   hipStream_t st = (hipStream_t)stream;
-  if (threads == QBLOCK && S == QSORT / 4) hipLaunchKernelGGL((sort_tile_test_kernel<QSORT / 4 / QBLOCK, QBLOCK>), g, dim3(QBLOCK), 0, st, words);
-  else if (threads == QBLOCK && S == QSORT / 2) hipLaunchKernelGGL((sort_tile_test_kernel<QSORT / 2 / QBLOCK, QBLOCK>), g, dim3(QBLOCK), 0, st, words);
-  else if (threads == QBLOCK && S == QSORT) hipLaunchKernelGGL((sort_tile_test_kernel<QSORT / QBLOCK, QBLOCK>), g, dim3(QBLOCK), 0, st, words);
-  else if (threads == 2 * QBLOCK && S == QSORT / 4) hipLaunchKernelGGL((sort_tile_test_kernel<QSORT / 8 / QBLOCK, 2 * QBLOCK>), g, dim3(2 * QBLOCK), 0, st, words);
-  else if (threads == 2 * QBLOCK && S == QSORT / 2) hipLaunchKernelGGL((sort_tile_test_kernel<QSORT / 4 / QBLOCK, 2 * QBLOCK>), g, dim3(2 * QBLOCK), 0, st, words);
-  else if (threads == 2 * QBLOCK && S == QSORT) hipLaunchKernelGGL((sort_tile_test_kernel<QSORT / 2 / QBLOCK, 2 * QBLOCK>), g, dim3(2 * QBLOCK), 0, st, words);
+  if (threads == QBLOCK && S == QSORT / 4) hipLaunchKernelGGL(cov((sort_tile_test_kernel<QSORT / 4 / QBLOCK, QBLOCK>)), g, dim3(QBLOCK), 0, st, words);
+  else if (threads == QBLOCK && S == QSORT / 2) hipLaunchKernelGGL(cov((sort_tile_test_kernel<QSORT / 2 / QBLOCK, QBLOCK>)), g, dim3(QBLOCK), 0, st, words);
+  else if (threads == QBLOCK && S == QSORT) hipLaunchKernelGGL(cov((sort_tile_test_kernel<QSORT / QBLOCK, QBLOCK>)), g, dim3(QBLOCK), 0, st, words);
+  else if (threads == 2 * QBLOCK && S == QSORT / 4) hipLaunchKernelGGL(cov((sort_tile_test_kernel<QSORT / 8 / QBLOCK, 2 * QBLOCK>)), g, dim3(2 * QBLOCK), 0, st, words);
+  else if (threads == 2 * QBLOCK && S == QSORT / 2) hipLaunchKernelGGL(cov((sort_tile_test_kernel<QSORT / 4 / QBLOCK, 2 * QBLOCK>)), g, dim3(2 * QBLOCK), 0, st, words);
+  else if (threads == 2 * QBLOCK && S == QSORT) hipLaunchKernelGGL(cov((sort_tile_test_kernel<QSORT / 2 / QBLOCK, 2 * QBLOCK>)), g, dim3(2 * QBLOCK), 0, st, words);
   else return PCG_E_UNSUPPORTED;
   return (int)hipGetLastError();
 }
@@ -1057,7 +1116,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
     if (lds_st) return PCG_E_UNSUPPORTED;
     void* argv[1] = {&a};
     const size_t sh = (per_env_t && a.sched_in_lds) ? shmem : integ_shmem;
-    return (int)hipModuleLaunchKernel(p->jit_fn[per_env_t ? 1 : 0], grid_for(io->B, block), 1, 1, block, 1, 1, (unsigned)sh,
+    return (int)hipModuleLaunchKernel(cov_jit(p->jit_fn[per_env_t ? 1 : 0]), grid_for(io->B, block), 1, 1, block, 1, 1, (unsigned)sh,
                                       (hipStream_t)stream, argv, nullptr);
   }
   if (c.nunc > 0) {  // per-env uncertain parameters: dedicated general kernel
@@ -1073,7 +1132,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       }
     }
     const int ub = tb(false, p->integrator_id);
-    hipLaunchKernelGGL(ufn, dim3(grid_for(io->B, ub)), dim3(ub), sh, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(cov(ufn), dim3(grid_for(io->B, ub)), dim3(ub), sh, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
   // Adaptive plans: the work-queue kernel (lanes that finish early pull the next env from an LDS tile).
@@ -1210,7 +1269,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
         a.q_tile = (a.q_tile & ~(0xFFFF | 0x20000)) | Tq;
         qsh = k.queue_lds(Tq) + 4 * (size_t)Tq + 8 + sb;
       }
-      hipLaunchKernelGGL(w1 ? q_w1[pe] : wide ? k.queue_w[pe] : qtab[pe], dim3((unsigned)nwg), dim3(qb), qsh, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(cov(w1 ? q_w1[pe] : wide ? k.queue_w[pe] : qtab[pe]), dim3((unsigned)nwg), dim3(qb), qsh, (hipStream_t)stream, a);
       rc_out = (int)hipGetLastError();
       return true;
       }
@@ -1292,7 +1351,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       a.q_prio = prio_env >= 0 ? prio_env : 0;
       a.q_tile = p->num_cus;
     }
-    hipLaunchKernelGGL(sfn, dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(cov(sfn), dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
   // Feature-masked pipelined kernel (pcg_step_feat.hpp): RK4 plans of the small models with anything beyond the
@@ -1330,7 +1389,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
       int64_t grid = (int64_t)p->num_cus * bpc;
       if (grid > ntile) grid = ntile;
       a.nt_stores = p->nt_stores;
-      hipLaunchKernelGGL(k.feat[best].fn, dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(cov(k.feat[best].fn), dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
       return (int)hipGetLastError();
     }
   }
@@ -1338,7 +1397,7 @@ static int step_impl(pcg_plan* p, const pcg_buffers* io, int32_t t, uint64_t see
   if (!fn) return PCG_E_UNSUPPORTED;
   if (shmem > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(fn, dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(cov(fn), dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
   rc = (int)hipGetLastError();
   if (rc != PCG_OK || !fixup) return rc;
   int qrc = PCG_OK;
@@ -1386,7 +1445,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
     a.r_ss = rew_step_stride;
     if (a.a_cs < io->B || (obs_seq && a.o_cs < io->B)) return PCG_E_DIM;
     const int ub = tb(false, p->integrator_id);
-    hipLaunchKernelGGL(ufn, dim3(grid_for(io->B, ub)), dim3(ub), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(cov(ufn), dim3(grid_for(io->B, ub)), dim3(ub), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
   a.t_scalar = t0;
@@ -1402,7 +1461,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   if (p->jit_fn[0]) {  // run-time compiled rollout kernel with the plan's user expressions (general step, one env per lane)
     void* argv[1] = {&a};
     const int jb = tb(false, p->integrator_id);
-    return (int)hipModuleLaunchKernel(p->jit_roll, grid_for(io->B, jb), 1, 1, jb, 1, 1, 0, (hipStream_t)stream, argv, nullptr);
+    return (int)hipModuleLaunchKernel(cov_jit(p->jit_roll), grid_for(io->B, jb), 1, 1, jb, 1, 1, 0, (hipStream_t)stream, argv, nullptr);
   }
   const Kernels& k = kernels(p->kid);
   const bool lds_st = p->lds_stages && p->integrator_id == PCG_INT_DOPRI5 && k.has_lds_stages;
@@ -1415,7 +1474,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
                     al16(io->rew) && (!obs_seq || al16(obs_seq)) && (!rew_seq || al16(rew_seq)) &&
                     (reinterpret_cast<uintptr_t>(io->done) & 1u) == 0;
     const int epl = e2 ? 2 : 1;
-    hipLaunchKernelGGL(k.roll_lean[epl - 1], dim3(grid_for(io->B, BLOCK * epl)), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(cov(k.roll_lean[epl - 1]), dim3(grid_for(io->B, BLOCK * epl)), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
   const int block = tb(lds_st, p->integrator_id);
@@ -1424,7 +1483,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   if (!fn) return PCG_E_UNSUPPORTED;  // the Rosenbrock integrator steps through pcg_step only
   if (shmem > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(fn, dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(cov(fn), dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1446,7 +1505,7 @@ int pcg_reset(pcg_plan* p, const pcg_buffers* io, const uint8_t* mask, uint64_t 
   if (p->hc.nunc > 0 && !io->p_unc) return PCG_E_NULL;
   a.mask = mask;
   a.seed = seed;
-  hipLaunchKernelGGL(reset_kernel, dim3(grid_for(io->B)), dim3(BLOCK), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(cov(reset_kernel), dim3(grid_for(io->B)), dim3(BLOCK), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1567,11 +1626,11 @@ int pcg_rhs(pcg_plan* p, int64_t B, const double* x, const double* u, double* dx
     const PCG_CONSTANT DevConst* dc = (CDevConst*)p->dC;
     int nu = p->cfg_nu;
     void* argv[6] = {&dc, &B, &nu, &x, &u, &dx};
-    return (int)hipModuleLaunchKernel(p->jit_rhs, grid_for(B), 1, 1, BLOCK, 1, 1, 0, (hipStream_t)stream, argv, nullptr);
+    return (int)hipModuleLaunchKernel(cov_jit(p->jit_rhs), grid_for(B), 1, 1, BLOCK, 1, 1, 0, (hipStream_t)stream, argv, nullptr);
   }
   if (p->model_id == PCG_MODEL_USER) return PCG_E_PLAN;
   const Kernels& k = kernels(p->kid);
-  hipLaunchKernelGGL(k.rhs, dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, (CDevConst*)p->dC, B, p->cfg_nu, x, u, dx);
+  hipLaunchKernelGGL(cov(k.rhs), dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, (CDevConst*)p->dC, B, p->cfg_nu, x, u, dx);
   return (int)hipGetLastError();
 }
 
@@ -1585,7 +1644,7 @@ int pcg_integrate(pcg_plan* p, int64_t B, double* x, const double* u, int32_t* n
     const PCG_CONSTANT DevConst* dc = (CDevConst*)p->dC;
     int nu = p->cfg_nu;
     void* argv[6] = {&dc, &B, &nu, &x, &u, &nsteps};
-    return (int)hipModuleLaunchKernel(p->jit_integ, grid_for(B, ub), 1, 1, ub, 1, 1, (unsigned)ush, (hipStream_t)stream, argv,
+    return (int)hipModuleLaunchKernel(cov_jit(p->jit_integ), grid_for(B, ub), 1, 1, ub, 1, 1, (unsigned)ush, (hipStream_t)stream, argv,
                                       nullptr);
   }
   if (p->model_id == PCG_MODEL_USER) return PCG_E_PLAN;
@@ -1597,7 +1656,7 @@ int pcg_integrate(pcg_plan* p, int64_t B, double* x, const double* u, int32_t* n
   if (!fn) return PCG_E_UNSUPPORTED;
   if (shmem > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(fn, dim3(grid_for(B, block)), dim3(block), shmem, (hipStream_t)stream, (CDevConst*)p->dC, B, p->cfg_nu, x,
+  hipLaunchKernelGGL(cov(fn), dim3(grid_for(B, block)), dim3(block), shmem, (hipStream_t)stream, (CDevConst*)p->dC, B, p->cfg_nu, x,
                      u, nsteps);
   return (int)hipGetLastError();
 }

@@ -10,7 +10,11 @@ from pcgym_amd.config import EnvSpec
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+GOLD_LOADS = [0]  # tests/conftest.py: which GPU tests check against a committed reference fixture
+
+
 def gold(name):
+    GOLD_LOADS[0] += 1
     return np.load(os.path.join(GOLD, name + ".npz"))
 
 
