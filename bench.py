@@ -13,6 +13,10 @@ launch, pcg_step_autoreset).  value = total env-steps / wall time (max over rank
 --workload selects the other BASELINE configurations (parity-test cases made measurable; not the headline):
   cstr_safe  the headline's envs / dt / actions under the model's DEFAULT plan (guarded RK4 with adaptive fallback) on the
              full x0 box U(0.7,1.0) x U(310,350) K of SURVEY.md section 8(d) -- reported beside the headline, not as it
+  cstr_rollout  section 8(f-1), the rollout collector: each 59-step episode of the headline's envs as ONE fused launch
+             (pcg_rollout_strided) writing x (Nx, N, B) / r (1, N, B) in the reference's axis order; a "step" is still one
+             env step of the whole batch (--steps must be a multiple of 59)
+  cstr_unc   section 8(f-3): the headline's envs with per-env model parameters (UA, Caf ~ U(+-5 %)) sampled at reset
   four_tank  four_tank B = 2^20, one Cooper-Verner order-8 step per dt = 1000/60 (the model's default: 11 right-hand sides;
              --integrator rk4 gives the RK4 x5 plan it replaced)
   me10       configs[2]: multistage_extraction (10 states) B = 262,144, adaptive DOPRI5 rtol = atol = 1e-8, dt = 1,
@@ -145,6 +149,19 @@ def single_workload(name):
         del p["integrator"], p["substeps"]
         p.update(x0=np.array([0.85, 330.0, 0.85]), uncertainty_percentages={"x0": [0.15 / 0.85, 20.0 / 330.0]})
         return "cstr_b2^20_default-plan(tsit5g)_full-x0-box_fp64", p, 1 << 20, (1180, 118), 64
+    if name == "cstr_rollout":
+        # the rollout collector (policy_evaluation.py:71-130) -- every episode of the headline's
+        # envs as ONE fused launch (pcg_rollout_strided: T = N - 1 = 59 steps, state in registers) that writes the
+        # trajectories in the reference's axis order x (Nx, N, B), r (1, N, B) from pre-generated actions u (N, Nu, B)
+        return "cstr_b2^20_rk4_fused-rollout_T59_reference-axis-order_fp64", workload_params(), 1 << 20, (590, 59), 60
+    if name == "cstr_unc":
+        # reset-time parameter uncertainty (pcgym.py:212-316) -- the headline's envs with
+        # per-env model parameters UA and Caf ~ U(+-5 %) sampled by the reset, read per lane by the step kernel and
+        # appended to the observation
+        p = workload_params()
+        p["uncertainty_percentages"] = dict(p["uncertainty_percentages"], UA=0.05, Caf=0.05)
+        p["uncertainty_bounds"] = {"low": np.array([4e4, 0.9]), "high": np.array([6e4, 1.1])}
+        return "cstr_b2^20_rk4_per-env-parameters(UA,Caf)_fp64", p, 1 << 20, (1180, 118), 64
     if name == "four_tank":
         return "four_tank_b2^20_cv8x1_fp64", copy.deepcopy(S["four_tank_canonical"]["env_params"]), 1 << 20, (1180, 118), 16
     if name in ("me10_ros4", "me10_ros5"):
@@ -201,7 +218,7 @@ def _physical_cores(avail):
         return avail
 
 
-def cpu_baseline(spec, seconds_target=10.0, threads=None):
+def cpu_baseline(spec, seconds_target=8.0, threads=None, all_legs=False):
     """The CPU oracle (oracle/pcg_oracle.c: same algorithm, plain C + OpenMP) on the host cores, on a bounded sample of
     the same workload, with a FIXED thread count; beside it the reference-shaped leg: one env at a time through a
     Python loop with an adaptive integrator at the reference's CVODES-default tolerance class (pcgym.py:350-500 +
@@ -233,17 +250,19 @@ def cpu_baseline(spec, seconds_target=10.0, threads=None):
             env = O.OracleEnv(spec, Bs, seed=1, n_threads=nthreads)
             env.reset()
             env.step(acts[0])  # warm-up (thread pool, page faults)
-            t0 = time.perf_counter()
-            env.step(acts[1])
-            per = max(time.perf_counter() - t0, 1e-6)
-            reps = int(max(2, min(4000, budget_s / per)))
             env.reset()
-            t0 = time.perf_counter()
-            for i in range(reps):
+            # stop on ELAPSED time, never on a step count sized from one un-throttled step: under a cgroup CPU quota a team
+            # larger than the quota runs its first step at full speed and everything after it throttled (round 5: a 4-s leg
+            # of 256 threads took 350 s of the driver's 379)
+            reps, t0 = 0, time.perf_counter()
+            while True:
                 if env.t == spec.N - 1:
                     env.reset()
-                env.step(acts[i % T])
-            dt = time.perf_counter() - t0
+                env.step(acts[reps % T])
+                reps += 1
+                dt = time.perf_counter() - t0
+                if (dt >= budget_s and reps >= 2) or reps >= 4000:
+                    break
         finally:
             O.lib().orc_unpin_threads()
         return reps * Bs / dt, reps, dt, pinned
@@ -256,14 +275,22 @@ def cpu_baseline(spec, seconds_target=10.0, threads=None):
     # on "256 logical CPUs" against 1.5e8 on 16 threads) -- the quota is on the line, and a leg above it says so.
     legs = {}
     for name, n in (("physical_cores", phys), ("all_logical_cpus", avail)):
+        above = quota is not None and n > quota + 0.5
+        if above and not all_legs:
+            # a team above the quota is throttled, not parallel: the leg says nothing about the host (round 5 measured it:
+            # 2.0e6 env-steps/s on 256 threads against 1.5e8 on 16) -- skipped unless --cpu-all-legs
+            legs[name] = {"value": None, "unit": "env-steps/s", "cores": n, "above_cgroup_cpu_quota": True,
+                          "sample": f"not run: a team of {n} is above the container's CPU quota of {quota:g} CPUs "
+                                    "(--cpu-all-legs runs it anyway)"}
+            continue
         if n == cores:
             v, r, d = value, reps, dt
         else:
-            v, r, d, _ = rate(n, 4.0)
+            v, r, d, _ = rate(n, 3.0)
         legs[name] = {"value": v, "unit": "env-steps/s", "cores": n,
                       "sample": f"{r} steps x {Bs} envs, pinned OpenMP team of {n} ({d:.1f} s)",
-                      **({"above_cgroup_cpu_quota": True} if quota is not None and n > quota + 0.5 else {})}
-    all_value, all_reps, all_dt = legs["all_logical_cpus"]["value"], 0, 0.0
+                      **({"above_cgroup_cpu_quota": True} if above else {})}
+    all_value = legs["all_logical_cpus"]["value"] or 0.0
     # accuracy of the workload's integrator setting vs a tight adaptive solve, same starts
     p2 = dict(spec.env_params)
     p2.update(integrator="dopri5", rtol=1e-12, atol=1e-14)
@@ -312,7 +339,7 @@ def cpu_baseline(spec, seconds_target=10.0, threads=None):
         "one_thread_env_steps_per_s": one,
         "all_host_cpus": legs["all_logical_cpus"],
         "physical_cores": legs["physical_cores"],
-        "best_of_legs_env_steps_per_s": max(one, value, legs["physical_cores"]["value"], all_value),
+        "best_of_legs_env_steps_per_s": max(one, value, legs["physical_cores"]["value"] or 0.0, all_value),
         "threads_pinned_first_touch_parallel": bool(pinned),
         "cgroup_cpu_quota_cpus": quota,
         "host_cpu": cpu_model,
@@ -465,9 +492,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cstr", choices=["cstr", "cstr_safe", "four_tank", "me10", "me10_ros4", "me10_ros5", "me20", "cryst", "cryst_cv8", "mixed"])
+    ap.add_argument("--workload", default="cstr", choices=["cstr", "cstr_safe", "cstr_rollout", "cstr_unc", "four_tank", "me10", "me10_ros4", "me10_ros5", "me20", "cryst", "cryst_cv8", "mixed"])
     ap.add_argument("--batch", type=int, default=None, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-legs", action="store_true",
+                    help="cpu_baseline: also run the legs whose thread count is above the container's cgroup CPU quota")
     ap.add_argument("--cpu-threads", type=int, default=None, help="fixed OpenMP team of the cpu_baseline leg (default min(16, avail))")
     ap.add_argument("--preheat-ms", type=float, default=100.0,
                     help="untimed GPU clock pre-heat (generic matmul loop) before the warm-up steps (0 = off)")
@@ -654,7 +683,37 @@ def main():
         n_pairs = 2 + (max(Kd, K) + last_t - 1) // last_t
         ev_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_pairs)]
 
+        roll = args.workload == "cstr_rollout"
+        if roll:
+            if K % last_t or W % last_t:
+                raise SystemExit(f"--workload cstr_rollout: --steps and --warmup must be multiples of the episode length {last_t}")
+            Nn = env.N
+            # the collector's storage (rollout.collect_rollouts): x (Nobs, N, B), r (1, N, B), actions (N, na, B)
+            traj_x = torch.empty((spec.nobs, Nn, B), dtype=torch.float64, device=dev)
+            traj_r = torch.zeros((1, Nn, B), dtype=torch.float64, device=dev)
+            a_seq = acts[:Nn].contiguous()
+            roll_fn = lib.pcg_rollout_strided
+            x1_ptr, r1_ptr, a_ptr = traj_x[:, 1:].data_ptr(), traj_r[:, 1:].data_ptr(), a_seq.data_ptr()
+
+        def run_rollout(n, timed):
+            for _ in range(n // last_t):
+                env.reset()  # inside the timed region, like the headline's episode-end resets
+                traj_x[:, 0].copy_(env.obs_soa)
+                if timed:
+                    eb, ee = ev_pool[len(brackets)]
+                    eb.record(stream)
+                rc = roll_fn(plan, bufp, 0, last_t, a_ptr, spec.na * B, B, x1_ptr, B, Nn * B, r1_ptr, B,
+                             env._episode_seed(), sptr)
+                if rc:
+                    _lib.check(rc, "pcg_rollout_strided")
+                if timed:
+                    ee.record(stream)
+                    brackets.append((eb, ee, last_t))
+                env.t = last_t
+
         def run(n, timed):
+            if roll:
+                return run_rollout(n, timed)
             # hipEvent pairs on the launch stream, one pair around each run of consecutive step launches of an episode
             i = 0
             while i < n:
@@ -844,6 +903,13 @@ def main():
             kern_avg_s = sum(eb.elapsed_time(ee) for eb, ee, _ in brackets) * 1e-3 / sum(m for _, _, m in brackets)
             bpe = env.bytes_per_env_step  # SURVEY.md section 8d formula for this plan and buffer set
             alg_bytes = float(bpe) * B
+            if roll:
+                # the fused rollout keeps the state in registers: per env step it reads the action and writes the
+                # observation row and the reward, 8 (na + Nobs + 1) B; the state is read and the last step's outputs written
+                # once per episode.  `kern_avg_s` is the launch's duration / 59 (one bracket per launch), so `achieved` is per
+                # env-step batch, like every other workload's
+                bpe = 8 * (spec.na + spec.nobs + 1)
+                alg_bytes = float(bpe) * B + float(8 * (2 * spec.nx + spec.nobs + 1) + 2) * B / last_t
             achieved = alg_bytes / kern_avg_s / 1e9
             adaptive = spec.integrator not in ("rk4", "cv8")
             fp64 = spec.model.name in FLOP_PER_RHS
@@ -919,10 +985,15 @@ def main():
                           4 * spec.substeps * (f_survey + 12 * spec.nx))
                     rl["frac_at_survey_flop_count"] = rl["frac"] * (fs * B) / fl
             out["roofline"] = rl
-            out["config"]["launch"] = ("eager pcg_step launches" if graph is None else
+            if roll:
+                rl["kernel_launch_us"] = kern_avg_s * 1e6 * last_t
+                rl["env_steps_per_launch"] = last_t
+                rl["algorithmic_bytes_per_launch"] = alg_bytes * last_t
+            out["config"]["launch"] = (f"one pcg_rollout_strided launch per {last_t}-step episode (+ reset kernel, + copy of the "
+                                       "first observation row)" if roll else "eager pcg_step launches" if graph is None else
                                        f"HIP graph of one {last_t}-step episode (pcg_graph_*)")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, threads=args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(spec, threads=args.cpu_threads, all_legs=args.cpu_all_legs)
         print(json.dumps(out), flush=True)
     for e in all_envs:
         e.close()

@@ -2020,11 +2020,12 @@ ORC_EXPORT int orc_step(const pcg_env_cfg* c, const pcg_buffers* io, double* slo
  * runs on the SAME static partition of the envs as orc_step -- each thread's slice of every row is first touched, hence
  * placed, on that thread's NUMA node; (2) the team is pinned, thread i on the (i n_cpu / n)-th CPU of the process's mask
  * (spread over the sockets; OMP_PROC_BIND cannot be relied on: another OpenMP runtime is already initialised in the process);
- * orc_unpin_threads() gives the calling thread its mask back. */
+ * orc_unpin_threads() gives every pinned worker (and the calling thread) the process's mask back. */
 static int g_reset_threads = 1;
 ORC_EXPORT void orc_set_reset_threads(int n) { g_reset_threads = n > 0 ? n : 1; }
 static cpu_set_t g_mask0;
 static int g_mask0_valid = 0;
+static int g_pinned_team = 0; /* the largest team orc_pin_threads has pinned */
 ORC_EXPORT int orc_pin_threads(int n) {
   if (n < 1) return -1;
   if (!g_mask0_valid) {
@@ -2037,6 +2038,7 @@ ORC_EXPORT int orc_pin_threads(int n) {
   if (nc == 0) return -3;
   int bad = 0;
   (void)cpus;
+  if (n > g_pinned_team) g_pinned_team = n;
 #ifdef _OPENMP
 #pragma omp parallel num_threads(n) reduction(+ : bad)
   {
@@ -2049,8 +2051,20 @@ ORC_EXPORT int orc_pin_threads(int n) {
 #endif
   return bad;
 }
+/* every worker of the largest team pinned so far gets the process's mask back, not only the calling thread: a later,
+ * smaller team must not inherit the stale pinning of a larger one (the OpenMP runtime keeps its workers) */
 ORC_EXPORT int orc_unpin_threads(void) {
-  return g_mask0_valid ? sched_setaffinity(0, sizeof g_mask0, &g_mask0) : 0;
+  if (!g_mask0_valid) return 0;
+  int bad = 0;
+#ifdef _OPENMP
+  const int n = g_pinned_team > 0 ? g_pinned_team : 1;
+#pragma omp parallel num_threads(n) reduction(+ : bad)
+  {
+    if (sched_setaffinity(0, sizeof g_mask0, &g_mask0) != 0) ++bad;
+  }
+#endif
+  if (sched_setaffinity(0, sizeof g_mask0, &g_mask0) != 0) ++bad;
+  return bad;
 }
 
 ORC_EXPORT int orc_reset(const pcg_env_cfg* c, const pcg_buffers* io, double* slots, const uint8_t* mask,

@@ -90,8 +90,11 @@ def pytest_runtest_call(item):
     names = _coverage_drain()
     COVERAGE_STATE["gpu_ran"] += 1
     if outcome.excinfo is not None:
-        COVERAGE_STATE["gpu_failed"] += 1
-        return  # a failing test checks nothing
+        if outcome.excinfo[0] is pytest.skip.Exception:
+            COVERAGE_STATE["gpu_skipped_in_call"] = COVERAGE_STATE.get("gpu_skipped_in_call", 0) + 1
+        else:
+            COVERAGE_STATE["gpu_failed"] += 1
+        return  # a failing (or skipping) test checks nothing
     for n in names:
         COVERAGE.setdefault(n, {"oracle": [], "golden": [], "other": []})[kind].append(item.nodeid)
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/rN/kernel_coverage.txt: which of the kernels libpcgym_hip.so carries the GPU suite launched, and against what.
 
-    python tools/kernel_coverage.py [gpurun_out/kernel_coverage.json] > profiles/r6/kernel_coverage.txt
+    python tools/kernel_coverage.py [gpurun_out/kernel_coverage.json ...] > profiles/r6/kernel_coverage.txt
 
 Input: the record tests/conftest.py writes at the end of a `pytest -m gpu` session (PCG_COVERAGE: the library notes every
 launch, the conftest attributes it to the running test and classes the test as oracle / golden fixture / other);
@@ -17,9 +17,17 @@ import kernel_inventory as KI  # noqa: E402
 
 
 def main():
-    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "kernel_coverage.json")
-    rec = json.load(open(path))
-    cov, state = rec["kernels"], rec["state"]
+    paths = sys.argv[1:] or [os.path.join(ROOT, "gpurun_out", "kernel_coverage.json")]
+    cov, state = {}, {}
+    for path in paths:  # several records (sessions that ran parts of the suite) are merged
+        rec = json.load(open(path))
+        for k, v in rec["state"].items():
+            state[k] = state.get(k, 0) + v
+        for name, d in rec["kernels"].items():
+            c = cov.setdefault(name, {kind: {"n": 0, "tests": []} for kind in ("oracle", "golden", "other")})
+            for kind in c:
+                c[kind]["n"] += d[kind]["n"]
+                c[kind]["tests"] = (c[kind]["tests"] + d[kind]["tests"])[:4]
     ks = KI.inventory()
     allow = []
     with open(os.path.join(ROOT, "tests", "kernel_coverage_allow.txt")) as f:
