@@ -7,13 +7,17 @@ Mirrors the parsing done by the reference ``make_env.__init__`` and its
 C ABI.  Nothing numeric about the hot path happens here.
 
 New optional keys (do not exist in the reference):
-  integrator   'rk4' | 'cv8' (fixed-step order 8) | 'rk4g' / 'tsit5g' (guarded fixed step with adaptive fallback, cstr) | 'dopri5' | 'tsit5' | 'rodas3' | 'rodas4' (stiff-capable Rosenbrock pairs)   (default per model,
-               see DEFAULT_INTEGRATOR; integration_method='jax' -> 'tsit5', the reference's own method, integrator.py:56-61)
-  endpoint_control  rodas4 only: {'frac': 0.5, 'kmax': 10} | False -- end-point error control (pcgym_hip.h,
-               PCG_INT_RODAS4); on by default, acts only on models with a contraction-rate hook (extraction cascades)
-  cooperative  rodas4 on multistage_extraction with eq_exponent == 2 only: {'thr': 60} | False -- env steps whose predicted
-               cost (attempts of the pair, a per-env rule) reaches thr take SEULEX-8, eight lanes per env in the work-queue
-               kernel (pcgym_hip.h: coop_thr; pcg_seulex.hpp); on by default where it applies
+  integrator   'rk4' | 'cv8' (fixed-step order 8) | 'rk4g' / 'tsit5g' (guarded fixed step with adaptive fallback, cstr) |
+               'dopri5' | 'tsit5' | 'rodas3' | 'rodas4' | 'rodas5' (stiff-capable Rosenbrock pairs; 'rodas5' is the
+               multistage_extraction default: rtol = atol = 8e-8 / max(1, dt), halved for eq_exponent != 2)
+               (default per model, see DEFAULT_INTEGRATOR; integration_method='jax' -> 'tsit5', the reference's own
+               method, integrator.py:56-61)
+  endpoint_control  rodas4 / rodas5: {'frac': 0.5, 'kmax': 10 | 16} | False -- end-point error control (pcgym_hip.h,
+               PCG_INT_RODAS4 / PCG_INT_RODAS5); on by default (kmax 10 under rodas4, 16 under rodas5, whose attempts also
+               cap the exponent per remaining step), acts only on models with a contraction-rate hook (extraction cascades)
+  cooperative  rodas4 / rodas5 on multistage_extraction with eq_exponent == 2 only: {'thr': 60} | False -- env steps whose
+               predicted cost (attempts of the pair, a per-env rule) reaches thr take SEULEX-8, eight lanes per env in the
+               work-queue kernel (pcgym_hip.h: coop_thr; pcg_seulex.hpp); on by default under rodas4, OPT-IN under rodas5
   substeps     RK4 sub-steps per env step
   rtol, atol   DOPRI5 tolerances (default 1e-8, integrator.py:61)
   max_steps    DOPRI5 step budget per env step
@@ -112,6 +116,7 @@ ROS4_TOL = {M.ME: 3e-8}
 # integrator = 'rodas5' (fifth-order pair, same hooks): worst 6.0e-7 over the action box at 8e-8 with end-point exponents up
 # to 16 under the step cap, at 0.53 x the attempts of the fourth-order pair (tests/test_rodas5.py, profiles/r5/rodas5_calib.txt)
 ROS5_TOL = {M.ME: 8e-8}
+ROS5_NONDEFAULT_CURVE = 0.5  # factor on ROS5_TOL for eq_exponent != 2 (EnvSpec: the round-6 contract, profiles/r6/rodas5_contract.txt)
 DEFAULT_COOP_THR = 60.0  # cooperative rule of rodas4 plans: predicted attempts from which an env step takes SEULEX-8 (pcg_seulex.hpp)
 ROS4_DT_CAL = 1.0  # the env step (model time units) ROS4_TOL was calibrated at; larger steps tighten it (EnvSpec)
 
@@ -958,6 +963,15 @@ class EnvSpec:
                 # at dt = 2 and 3.9e-6 at dt = 5.  Scaled by the calibrated dt it stays at 7.0-7.4e-7 for dt =
                 # 2, 5, 10 (tests/test_rodas4.py).
                 d_tol = d_tol / max(1.0, self.dt / ROS4_DT_CAL)
+                # Round 6, the contract beyond the sample the tolerance was calibrated on (tools/rodas5_contract.py: 1e6 env
+                # steps of 200-step random-action episodes, X0 / Y6 disturbed, eq_exponent 1.5 / 2 / 3, dt 0.2 ... 5, against
+                # a 1e-13 solve): the reference's default curve stays within 1.4 x its tolerances everywhere; with
+                # eq_exponent = 3 at dt = 5 two steps in 84,000 reached 3.5 x (slow liquid AND slow gas: the end-point
+                # weights' coupling bound is the slope of the eq_exponent == 2 curve).  Not re-tuned on that sample: a
+                # non-default curve simply runs the fifth-order pair at HALF the tolerance (1.6 x there, ~15 % more attempts)
+                if self.integrator == "rodas5" and self.model.model_id == M.ME and \
+                        float(self.model.parameters.get("eq_exponent", 2.0)) != 2.0:
+                    d_tol *= ROS5_NONDEFAULT_CURVE
         self.rtol = float(p.get("rtol", d_tol))
         self.atol = float(p.get("atol", d_tol))
         self.max_steps = int(p.get("max_steps", 100000))

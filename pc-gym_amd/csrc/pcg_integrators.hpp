@@ -1377,10 +1377,14 @@ PCG_DEV bool ros_try_rolled(const F& f, const LS& ls, const double (&x)[NX], con
   }
   return lu_ok;
 }
+// state count above which the attempt takes the rolled form (tools/hostcheck builds the unrolled one at any size)
+#ifndef PCG_ROS_ROLLED_ABOVE
+#define PCG_ROS_ROLLED_ABOVE 16
+#endif
 template <int INTEG, int NX, class F, class LS>
 PCG_DEV bool ros_pair_try(const F& f, const LS& ls, const double (&x)[NX], const double (&f0)[NX], double h,
                           double (&xn)[NX], double (&err)[NX]) {
-  if constexpr (NX > 16) return ros_try_rolled<INTEG, NX>(f, ls, x, f0, h, xn, err);
+  if constexpr (NX > PCG_ROS_ROLLED_ABOVE) return ros_try_rolled<INTEG, NX>(f, ls, x, f0, h, xn, err);
   // (instantiated, and dead, for every INTEG at the kernels' run-time-free `if (INTEG == ...)` chains: anything but
   // PCG_INT_RODAS5 is the fourth-order pair)
   if constexpr (INTEG == PCG_INT_RODAS5) return rodas5_try<NX>(f, ls, x, f0, h, xn, err);
@@ -1466,4 +1470,6 @@ PCG_DEV int rodas4(const F& f, const LS& ls, const EP& ep, double (&x)[NX], int 
 
 }  // namespace pcg
 
+#ifndef PCG_HOST_CHECK  // (tools/hostcheck: the attempt templates on the host, without the wave-level cooperative phase)
 #include "pcg_seulex.hpp"
+#endif

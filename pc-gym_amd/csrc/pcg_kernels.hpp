@@ -1897,7 +1897,9 @@ Kernels make_kernels() {
     // streaming / pipelined lean kernels
     k.roll_lean[0] = rollout_kernel_lean<M, 1>;
     k.stream[PCG_INT_RK4][0] = step_kernel_stream<M, PCG_INT_RK4, 1, 1>;
-    k.stream[PCG_INT_DOPRI5][0] = step_kernel_stream<M, PCG_INT_DOPRI5, 1, 1>;
+    // (rounds 1-5 also shipped step_kernel_stream<M, PCG_INT_DOPRI5>: reachable only through the measurement switch
+    // PCG_OPT_VARIANT 2, never a default -- adaptive plans take the work queue or the classic kernel -- and launched by no
+    // test: removed in round 6 with the kernel-coverage gate, tests/test_zz_kernel_coverage.py)
     // several envs per lane only where the per-env register footprint is
     // small (the HBM-bound models)
     if constexpr (M::NX <= 4) {

@@ -23,6 +23,16 @@ N = 201
 NT = min(8, os.cpu_count() or 1)
 
 
+def registry_object(model, **over):
+    """an object the way the reference's registry classes look to make_env (pcgym.py:150-153): class name + info()"""
+    from pcgym_amd.models import get_model
+
+    mi = get_model(model)
+    info = {"parameters": {**mi.parameters, **over}, "states": list(mi.states), "inputs": list(mi.inputs),
+            "disturbances": list(mi.disturbances)}
+    return type(model, (), {"info": lambda self: info, "int_method": "hip"})()
+
+
 def params(dt, **kw):
     p = copy.deepcopy(SC.scenarios()["me_dist_cons"]["env_params"])
     for k in ("constraints", "done_on_cons_vio", "r_penalty"):
@@ -42,11 +52,11 @@ print(f"{'eq_exponent':>11s} {'dt':>5s} {'rtol':>9s} {'env steps':>10s} {'attemp
 allu, t0 = [], time.time()
 for expo in (1.5, 2.0, 3.0):
     for dt in (0.2, 1.0, 2.0, 5.0):
-        s1 = EnvSpec(params(dt))  # the default plan: integrator and tolerance are the model's own
-        s2 = EnvSpec(params(dt, integrator="dopri5", rtol=1e-13, atol=1e-13))
+        cm = {} if expo == 2.0 else {"custom_model": registry_object("multistage_extraction", eq_exponent=expo)}
+        s1 = EnvSpec(params(dt, **cm))  # the default plan: integrator and tolerance are the model's own
+        s2 = EnvSpec(params(dt, integrator="dopri5", rtol=1e-13, atol=1e-13, **cm))
         assert s1.integrator == "rodas5", s1.integrator
-        for s in (s1, s2):
-            s.model.parameters["eq_exponent"] = expo
+        assert s1.model.parameters["eq_exponent"] == expo and s2.model.parameters["eq_exponent"] == expo
         e1 = O.OracleEnv(s1, B, seed=77, n_threads=NT)
         e2 = O.OracleEnv(s2, B, seed=77, n_threads=NT)
         e1.reset(), e2.reset()
