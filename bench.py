@@ -388,14 +388,14 @@ _PMC = None
 
 
 def committed_pmc(workload, build_id):
-    """per-launch counters of this workload's dominant kernel from the committed rocprofv3 PMC passes (profiles/r5/pmc.json,
+    """per-launch counters of this workload's dominant kernel from the committed rocprofv3 PMC passes (profiles/r6/pmc.json,
     made by tools/prof_all.sh + tools/pmc_json.py on the GPU box; FETCH_SIZE x 2 per MI355X_MICROARCH.md's gfx950 note).
     NOT measured in this run: hardware counters cannot be read from inside the process.  An entry is quoted only when it was
     taken on THIS build of the library (pcg_build_id(): a digest of the kernel headers and the .hip units): -> (entry or None, reason)."""
     global _PMC
     if _PMC is None:
         _PMC = {}
-        for tp in ("profiles/r5/pmc.json", "profiles/r4/pmc.json", "profiles/r3/pmc.json"):
+        for tp in ("profiles/r6/pmc.json", "profiles/r5/pmc.json", "profiles/r4/pmc.json", "profiles/r3/pmc.json"):
             tpath = os.path.join(ROOT, tp)
             if os.path.exists(tpath):
                 with open(tpath) as fh:
@@ -959,7 +959,7 @@ def main():
                 rl["traffic_reason"] = pm_why
             if pm:
                 rl["traffic"] = pm["traffic_bytes_per_launch"]
-                rl["traffic_over_algorithmic"] = pm["traffic_bytes_per_launch"] / alg_bytes
+                rl["traffic_over_algorithmic"] = pm["traffic_bytes_per_launch"] / (alg_bytes * (last_t if roll else 1))
                 rl["traffic_source"] = pm["source"]
                 if "valu_issue_frac" in pm:
                     # instruction-issue view of the same kernel: 4 cycles per wave64 VALU instruction on a 16-lane SIMD,

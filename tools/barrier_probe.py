@@ -44,3 +44,17 @@ for w in (64, 256, 1024):
     bal = g.sum(axis=(0, 2)) / w              # perfectly balanced within the group
     print(f"groups of {w:5d}: lock-stepped group cost mean {lock.mean():7.1f} max {lock.max():5d} | heaviest member mean {free.mean():7.1f} max {free.max():5d}"
           f" | balanced mean {bal.mean():7.1f} max {bal.max():7.1f}")
+
+# --- would SORTING the envs by how hot they are rescue a wave that steps its 64 lanes together? --------------------------------
+# (the fused rollout as it exists: one env per lane for the whole episode, the wave pays the per-step maximum of its lanes)
+tot = att.sum(axis=0)
+for name_, order in (("as drawn", np.arange(B)), ("sorted by the episode's total (hindsight)", np.argsort(tot)),
+                     ("sorted by the first 5 steps' attempts", np.argsort(att[:5].sum(axis=0), kind="stable"))):
+    g = att[:, order][:, : B // 64 * 64].reshape(T, -1, 64)
+    lock = g.max(axis=2).sum(axis=0)
+    print(f"waves of 64, envs {name_:45s}: wave cost mean {lock.mean():7.1f} (balanced {att.mean() * T:6.1f}), "
+          f"sum over waves / balanced = {lock.sum() * 64 / max(att.sum(), 1):.2f}")
+# persistence: does an env that needed the adaptive pair at step t need it at t + 1?
+hot = att > 0
+print(f"P(hot at t+1 | hot at t) = {(hot[1:] & hot[:-1]).sum() / max(hot[:-1].sum(), 1):.3f},  P(hot at t+1 | calm at t) = "
+      f"{(hot[1:] & ~hot[:-1]).sum() / max((~hot[:-1]).sum(), 1):.3f},  share of hot env steps {hot.mean():.3f}")

@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 root, wls = sys.argv[1], sys.argv[2:]
-RND = os.environ.get("PMC_ROUND", "r5")
+RND = os.environ.get("PMC_ROUND", "r6")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 try:
     from pcgym_amd import _lib
@@ -31,7 +31,7 @@ def counters(d):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 k = row["Kernel_Name"]
-                if "step_kernel" in k:
+                if "step_kernel" in k or "rollout_kernel" in k:
                     agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"_n": len(next(iter(cs.values())))} for k, cs in agg.items()}
 
