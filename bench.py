@@ -15,7 +15,7 @@ launch, pcg_step_autoreset).  value = total env-steps / wall time (max over rank
              full x0 box U(0.7,1.0) x U(310,350) K of SURVEY.md section 8(d) -- reported beside the headline, not as it
   cstr_rollout  section 8(f-1), the rollout collector: each 59-step episode of the headline's envs as ONE fused launch
              (pcg_rollout_strided) writing x (Nx, N, B) / r (1, N, B) in the reference's axis order; a "step" is still one
-             env step of the whole batch (--steps must be a multiple of 59)
+             env step of the whole batch (--steps is rounded up to whole episodes of 59)
   cstr_unc   section 8(f-3): the headline's envs with per-env model parameters (UA, Caf ~ U(+-5 %)) sampled at reset
   four_tank  four_tank B = 2^20, one Cooper-Verner order-8 step per dt = 1000/60 (the model's default: 11 right-hand sides;
              --integrator rk4 gives the RK4 x5 plan it replaced)
@@ -685,8 +685,9 @@ def main():
 
         roll = args.workload == "cstr_rollout"
         if roll:
-            if K % last_t or W % last_t:
-                raise SystemExit(f"--workload cstr_rollout: --steps and --warmup must be multiples of the episode length {last_t}")
+            # a launch is a whole episode: steps and warm-up are rounded UP to whole episodes (the line reports what ran)
+            K = max(1, -(-K // last_t)) * last_t
+            W = -(-W // last_t) * last_t
             Nn = env.N
             # the collector's storage (rollout.collect_rollouts): x (Nobs, N, B), r (1, N, B), actions (N, na, B)
             traj_x = torch.empty((spec.nobs, Nn, B), dtype=torch.float64, device=dev)

@@ -771,6 +771,10 @@ PCG_DEV int tsit5(const F& f, double (&x)[NX], int n, double dt, double rtol, do
 // ---------------------------------------------------------------------------------------------------------------
 // one wave per workgroup; past 16 states only half of its lanes carry an env, so that the matrices (nx^2 x lanes x 8 B)
 // still fit the 160 KB of LDS (nx = 24: 147 KB + pivots)
+// state count above which the Rosenbrock attempt (ros_pair_try) and the pivot exchanges of the dense solve (ros_solve) take their rolled forms (tools/hostcheck builds the unrolled one at any size)
+#ifndef PCG_ROS_ROLLED_ABOVE
+#define PCG_ROS_ROLLED_ABOVE 12
+#endif
 constexpr int ros_threads(int nx) { return nx <= 16 ? 64 : 32; }
 constexpr size_t ros_lds_doubles(int nx) { return (size_t)(nx * nx + (nx + 1) / 2) * ros_threads(nx); }
 
@@ -840,6 +844,21 @@ PCG_DEV bool ros_lu(const RosLds<NX>& L, int n) {
 // solve W z = b in place (b in registers; the row swaps by select chains: no dynamic register indexing)
 template <int NX>
 PCG_DEV void ros_solve(const RosLds<NX>& L, int n, double (&b)[NX]) {
+  if constexpr (NX > PCG_ROS_ROLLED_ABOVE) {
+    // LARGE MODELS: the row swaps through run-time indexing of the right-hand side (private memory), one rolled loop.
+    // As select chains, the NX x NX comparisons (i == pk) of the fully unrolled form are NX^2 / 2 lane masks in scalar
+    // register pairs -- 576 at NX = 24 -- and they were what pushed these kernels into the regime of ~1400 spilled scalar
+    // registers multiplexed through whole-wave-mode vector registers (profiles/r6/kernel_resources.txt, DESIGN.md
+    // "Root cause").  The same exchanges, exact: no arithmetic here.
+#pragma unroll 1
+    for (int k = 0; k < NX; ++k) {
+      if (k >= n) break;
+      const int pk = L.p(k);
+      const double bk = b[k], bp = b[pk];
+      b[pk] = bk;
+      b[k] = bp;
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < NX; ++k) {
     if (k < n) {
@@ -852,6 +871,7 @@ PCG_DEV void ros_solve(const RosLds<NX>& L, int n, double (&b)[NX]) {
       for (int i = 0; i < NX; ++i) b[i] = (i == pk) ? bk : b[i];
       b[k] = bp;
     }
+  }
   }
 #pragma unroll
   for (int i = 1; i < NX; ++i) {
@@ -1377,10 +1397,6 @@ PCG_DEV bool ros_try_rolled(const F& f, const LS& ls, const double (&x)[NX], con
   }
   return lu_ok;
 }
-// state count above which the attempt takes the rolled form (tools/hostcheck builds the unrolled one at any size)
-#ifndef PCG_ROS_ROLLED_ABOVE
-#define PCG_ROS_ROLLED_ABOVE 16
-#endif
 template <int INTEG, int NX, class F, class LS>
 PCG_DEV bool ros_pair_try(const F& f, const LS& ls, const double (&x)[NX], const double (&f0)[NX], double h,
                           double (&xn)[NX], double (&err)[NX]) {

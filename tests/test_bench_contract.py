@@ -37,14 +37,20 @@ def test_single_rank_line():
     assert d["config"]["ranks_seen"] == 1
 
 
-@pytest.mark.parametrize("wl,batch,steps", [("mixed", 30000, 8), ("mixed", 30000, 59), ("me10", 8192, 6), ("me10_ros4", 8192, 6), ("me10_ros5", 8192, 6), ("cryst", 8192, 6), ("cryst_cv8", 8192, 6), ("cstr_safe", 65536, 20), ("four_tank", 65536, 20)])
+@pytest.mark.parametrize("wl,batch,steps", [("mixed", 30000, 8), ("mixed", 30000, 59), ("me10", 8192, 6), ("me10_ros4", 8192, 6), ("me10_ros5", 8192, 6), ("cryst", 8192, 6), ("cryst_cv8", 8192, 6), ("cstr_safe", 65536, 20), ("four_tank", 65536, 20),
+                                            ("cstr_rollout", 65536, 59), ("cstr_rollout", 65536, 100), ("cstr_unc", 65536, 20)])
 def test_other_workloads_line(wl, batch, steps):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--batch", str(batch), "--steps",
                         str(steps), "--warmup", "2", "--preheat-ms", "10", "--no-cpu-baseline"], capture_output=True,
                        text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
-    assert KEYS <= set(d) and d["config"]["sane"] and d["steps"] == steps and d["warmup"] == 2
+    if wl == "cstr_rollout":  # a launch is a whole 59-step episode: steps and warm-up are rounded up to whole episodes
+        assert d["steps"] == -(-steps // 59) * 59 and d["warmup"] == 59 and d["roofline"]["env_steps_per_launch"] == 59
+        assert d["roofline"]["algorithmic_bytes_per_env_step"] == 8 * (1 + 3 + 1)
+    else:
+        assert d["steps"] == steps and d["warmup"] == 2
+    assert KEYS <= set(d) and d["config"]["sane"]
     assert abs(d["value"] - d["config"]["global_envs"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "fp64_valu", "chain") and 0 < rf["frac"] < 1.0

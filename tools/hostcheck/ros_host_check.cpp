@@ -40,7 +40,9 @@ static inline int host_frexp_exp(double x) { int e; (void)std::frexp(x, &e); ret
 using std::ldexp;
 
 #define PCG_HOST_CHECK 1
-#define PCG_ROS_ROLLED_ABOVE 9999  // ros_pair_try takes the UNROLLED attempt whatever NX (the form that broke on the device)
+#ifndef PCG_ROS_ROLLED_ABOVE
+#define PCG_ROS_ROLLED_ABOVE 9999  // ros_pair_try takes the UNROLLED attempt whatever NX (the form that broke on the device),
+#endif                             // ros_solve its select-chain pivot exchanges; -DPCG_ROS_ROLLED_ABOVE=12: the product's forms
 #include "../../pc-gym_amd/csrc/pcg_integrators.hpp"
 
 using namespace pcg;

@@ -66,6 +66,12 @@ def main():
             if cls == "other":
                 tests = "   <- " + ", ".join(cov[k["name"]]["other"]["tests"][:2])
             print(f"  {k['demangled']}{tests}" + (f"   [allowed: {why}]" if why else "   [NOT ALLOWED]"))
+    # the compact map build() and tools/kernel_inventory.py --scratch print beside each spilling kernel
+    tests_out = os.environ.get("KERNEL_TESTS_JSON")
+    if tests_out:
+        with open(tests_out, "w") as f:
+            json.dump({k["name"]: (cov[k["name"]]["oracle"]["tests"] or cov[k["name"]]["golden"]["tests"])[0]
+                       for k in ks if k["cls"] in ("oracle", "golden")}, f, indent=0, sort_keys=True)
     print("\n# every checked kernel, with the number of passing tests that launched it (oracle / fixture / other) and one of them")
     for k in ks:
         if k["cls"] in ("oracle", "golden"):

@@ -133,6 +133,17 @@ def inventory(path=LIB):
     return ks
 
 
+def covering_tests():
+    """mangled kernel name -> one passing test of the GPU suite that launched it against the oracle / a fixture (the record
+    tools/kernel_coverage.py condensed from the last full GPU run, committed under profiles/)"""
+    for rnd in ("r6",):
+        p = os.path.join(ROOT, "profiles", rnd, "kernel_tests.json")
+        if os.path.exists(p):
+            with open(p) as f:
+                return json.load(f)
+    return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=LIB)
@@ -147,14 +158,18 @@ def main():
     for k in ks:
         fams.setdefault(k["family"], []).append(k)
     print(f"{len(ks)} kernels in {os.path.relpath(a.lib, ROOT)}")
-    print(f"{'family':42s} {'n':>5s} {'max vgpr+agpr':>14s} {'n scratch>0':>12s} {'max scratch B':>14s} {'max LDS B':>10s}")
+    # (.vgpr_count of the metadata is the unified register file's allocation, accumulation registers included: <= 512)
+    print(f"{'family':42s} {'n':>5s} {'max vgprs':>10s} {'n scratch>0':>12s} {'max scratch B':>14s} {'max LDS B':>10s}")
     for fam, v in sorted(fams.items(), key=lambda kv: -len(kv[1])):
-        print(f"{fam:42s} {len(v):5d} {max(k['vgpr'] + k['agpr'] for k in v):14d} "
+        print(f"{fam:42s} {len(v):5d} {max(k['vgpr'] for k in v):10d} "
               f"{sum(1 for k in v if k['scratch'] > 0):12d} {max(k['scratch'] for k in v):14d} {max(k['lds'] for k in v):10d}")
     if a.scratch:
-        print("\nkernels with scratch > 0 (bytes per lane; vgpr+agpr; sgpr spills / vgpr spills):")
+        tests = covering_tests()
+        print("\nkernels with scratch > 0: bytes per lane; registers (of them accumulation); scalar / vector spills; the kernel; "
+              "a passing oracle test that launches it (profiles/r6/kernel_tests.json)")
         for k in sorted((k for k in ks if k["scratch"] > 0), key=lambda k: -k["scratch"]):
-            print(f"{k['scratch']:7d} {k['vgpr'] + k['agpr']:4d} {k['sgpr_spill']:5d}/{k['vgpr_spill']:<5d} {k['demangled']}")
+            print(f"{k['scratch']:7d} {k['vgpr']:4d} ({k['agpr']:3d}) {k['sgpr_spill']:5d}/{k['vgpr_spill']:<5d} {k['demangled']}   <- "
+                  f"{tests.get(k['name'], 'NO COVERING TEST RECORDED')}")
 
 
 if __name__ == "__main__":
