@@ -16,6 +16,7 @@ launch, pcg_step_autoreset).  value = total env-steps / wall time (max over rank
   cstr_rollout  section 8(f-1), the rollout collector: each 59-step episode of the headline's envs as ONE fused launch
              (pcg_rollout_strided) writing x (Nx, N, B) / r (1, N, B) in the reference's axis order; a "step" is still one
              env step of the whole batch (--steps is rounded up to whole episodes of 59)
+  cstr_safe_rollout  the same collector on cstr_safe's envs (default plan, full x0 box): the barrier-free two-pass rollout
   cstr_unc   section 8(f-3): the headline's envs with per-env model parameters (UA, Caf ~ U(+-5 %)) sampled at reset
   four_tank  four_tank B = 2^20, one Cooper-Verner order-8 step per dt = 1000/60 (the model's default: 11 right-hand sides;
              --integrator rk4 gives the RK4 x5 plan it replaced)
@@ -154,6 +155,11 @@ def single_workload(name):
         # envs as ONE fused launch (pcg_rollout_strided: T = N - 1 = 59 steps, state in registers) that writes the
         # trajectories in the reference's axis order x (Nx, N, B), r (1, N, B) from pre-generated actions u (N, Nu, B)
         return "cstr_b2^20_rk4_fused-rollout_T59_reference-axis-order_fp64", workload_params(), 1 << 20, (590, 59), 60
+    if name == "cstr_safe_rollout":
+        # the same collector under the model's DEFAULT plan on the full x0 box (cstr_safe): the barrier-free rollout in two
+        # passes (pcg_rollout_flat.hpp) -- PCG_NO_FLAT=1 gives the single-kernel rollout it replaced
+        wl, p, B, kw, _ = single_workload("cstr_safe")
+        return wl.replace("default-plan(tsit5g)", "default-plan(tsit5g)_fused-rollout_T59"), p, B, (590, 59), 60
     if name == "cstr_unc":
         # reset-time parameter uncertainty (pcgym.py:212-316) -- the headline's envs with
         # per-env model parameters UA and Caf ~ U(+-5 %) sampled by the reset, read per lane by the step kernel and
@@ -492,7 +498,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cstr", choices=["cstr", "cstr_safe", "cstr_rollout", "cstr_unc", "four_tank", "me10", "me10_ros4", "me10_ros5", "me20", "cryst", "cryst_cv8", "mixed"])
+    ap.add_argument("--workload", default="cstr", choices=["cstr", "cstr_safe", "cstr_rollout", "cstr_safe_rollout", "cstr_unc", "four_tank", "me10", "me10_ros4", "me10_ros5", "me20", "cryst", "cryst_cv8", "mixed"])
     ap.add_argument("--batch", type=int, default=None, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-legs", action="store_true",
@@ -683,7 +689,7 @@ def main():
         n_pairs = 2 + (max(Kd, K) + last_t - 1) // last_t
         ev_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_pairs)]
 
-        roll = args.workload == "cstr_rollout"
+        roll = args.workload in ("cstr_rollout", "cstr_safe_rollout")
         if roll:
             # a launch is a whole episode: steps and warm-up are rounded UP to whole episodes (the line reports what ran)
             K = max(1, -(-K // last_t)) * last_t
@@ -929,7 +935,7 @@ def main():
                 "copy_ceiling_GBps": COPY_CEILING["GBps"],
                 "frac_of_copy_ceiling": (achieved / COPY_CEILING["GBps"]) if COPY_CEILING["GBps"] else None,
             }
-            if adaptive and not fp64 and env.nsteps is not None:
+            if adaptive and not fp64 and env.nsteps is not None and not roll:
                 # adaptive plans of the cheap models (the cstr's guarded default on the full x0 box): neither HBM nor issue
                 # bound -- the launch waits for its heaviest env, one lane crossing an ignition front attempt by attempt
                 att_max = int(env.nsteps.sum(dim=0).max().item())
@@ -986,6 +992,10 @@ def main():
                           4 * spec.substeps * (f_survey + 12 * spec.nx))
                     rl["frac_at_survey_flop_count"] = rl["frac"] * (fs * B) / fl
             out["roofline"] = rl
+            if roll and adaptive:
+                rl["note"] = ("barrier-free rollout of a guarded plan (pcg_rollout_flat.hpp): two launches per episode; neither "
+                              "HBM- nor issue-bound end to end -- the second pass carries one env per lane through the adaptive "
+                              "pair; the hbm figures are the algorithmic bytes over the episode's time")
             if roll:
                 rl["kernel_launch_us"] = kern_avg_s * 1e6 * last_t
                 rl["env_steps_per_launch"] = last_t

@@ -112,6 +112,8 @@ struct pcg_plan {
   hipFunction_t jit_integ, jit_rhs;  // PCG_MODEL_USER: the run-time compiled test hooks (pcg_integrate / pcg_rhs)
   hipFunction_t jit_roll;            // run-time compiled fused rollout of a plan with user expressions (or null)
   int nx;                   // states (the kernel table's for built-in models, the cfg's for PCG_MODEL_USER)
+  int32_t* flat_ws;         // work space of the barrier-free rollout (pcg_rollout_flat.hpp): 4 counters + 2 x flat_cap indices,
+  int64_t flat_cap;         // allocated at the first rollout that takes that path (and again if a later batch is larger)
 };
 static constexpr uint32_t PLAN_MAGIC = 0x50434731u;  // 'PCG1'
 
@@ -917,6 +919,7 @@ int pcg_plan_destroy(pcg_plan* p) {
   if (!plan_ok(p)) return PCG_E_PLAN;
   p->magic = 0;
   hipError_t e1 = hipFree(p->dC), e2 = hipFree(p->dsched);
+  if (p->flat_ws) (void)hipFree(p->flat_ws);
   delete p;
   if (e1 != hipSuccess) return (int)e1;
   if (e2 != hipSuccess) return (int)e2;
@@ -1481,6 +1484,33 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
   const size_t shmem = lds_st ? sizeof(double) * 6 * (size_t)k.nx * BLOCK_LDS : 0;
   StepFn fn = k.rollout[p->integrator_id][lds_st ? 1 : 0];
   if (!fn) return PCG_E_UNSUPPORTED;  // the Rosenbrock integrator steps through pcg_step only
+  // The guarded default plan of a model with a guard (PCG_INT_T5G), batches of at least one wave per SIMD: the barrier-free
+  // rollout in two passes (pcg_rollout_flat.hpp).  The first pass is this plan's ordinary fused rollout kernel, told to hand
+  // an env over at the first step its guard does not trust; the second carries each handed-over env to the end of the rollout
+  // on a lane of its own.  Same bits as T pcg_step launches.  Not with a_delta (env_pre accumulates), not while the stream is
+  // being captured into a graph before the work space exists (hipMalloc); PCG_NO_FLAT=1 keeps the single-kernel rollout (A/B).
+  if (p->integrator_id == PCG_INT_T5G && k.roll_hot && !lds_st && p->variant == 0 && !(c.flags & PCG_F_A_DELTA) && T >= 2 &&
+      io->B >= (int64_t)p->num_cus * 4 * 64 && io->B < ((int64_t)1 << 31) && !std::getenv("PCG_NO_FLAT")) {
+    if (p->flat_cap < io->B) {
+      if (p->flat_ws) HIP_TRY(hipFree(p->flat_ws));
+      p->flat_ws = nullptr;
+      p->flat_cap = 0;
+      HIP_TRY(hipMalloc((void**)&p->flat_ws, sizeof(int32_t) * (4 + 2 * (size_t)io->B)));
+      p->flat_cap = io->B;
+    }
+    HIP_TRY(hipMemsetAsync(p->flat_ws, 0, sizeof(int32_t) * 4, (hipStream_t)stream));
+    a.flat_q = p->flat_ws;
+    a.flat_hot = p->flat_ws + 4;
+    a.flat_tstar = p->flat_ws + 4 + p->flat_cap;
+    a.fixup = 1;
+    hipLaunchKernelGGL(cov(fn), dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);
+    rc = (int)hipGetLastError();
+    if (rc != PCG_OK) return rc;
+    int wps = 2;  // persistent waves per SIMD of the second pass (measured: profiles/r6/flat_rollout.txt)
+    if (const char* ev = std::getenv("PCG_FLAT_WPS")) wps = std::max(1, std::min(8, std::atoi(ev)));  // measurement switch
+    hipLaunchKernelGGL(cov(k.roll_hot), dim3((unsigned)(p->num_cus * wps)), dim3(FLAT_BLOCK), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
   if (shmem > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(cov(fn), dim3(grid_for(io->B, block)), dim3(block), shmem, (hipStream_t)stream, a);

@@ -182,6 +182,10 @@ struct StepArgs {
   int32_t fixup;         // guarded plans in two launches (pcg_abi.hip): 1 = the general kernel leaves an env the guard does not
                          // trust untouched and marks it (done[e] = PCG_DONE_PENDING), the work-queue kernel then integrates
                          // exactly the marked envs with the adaptive pair and finishes their step
+  // barrier-free rollout of a guarded plan in two passes (pcg_rollout_flat.hpp): plan-owned work space
+  int32_t* flat_q;       // [4] counters: [1] length of the hand-over list, [2] head of the second pass's queue
+  int32_t* flat_hot;     // [B] the envs the first pass handed over (in the order they tripped)
+  int32_t* flat_tstar;   // [B] the step at which an env left the first pass
 };
 
 // ---------------------------------------------------------------------------
@@ -1608,6 +1612,15 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG)) void rollout_kernel(const St
     const bool last = (s == A.T - 1);
     EnvOut<M> out;
     env_step<M, INTEG, false, LDS_STAGES, true, UNC>(A, c, lds, lds, e, A.t_scalar + s, a, x, out);
+    if constexpr (INTEG == PCG_INT_RK4G || INTEG == PCG_INT_T5G) {
+      // first pass of the barrier-free rollout (A.fixup: pcg_rollout_flat.hpp): the guard did not trust this step -- nothing
+      // of it has been stored and x is the step's start state again; the env leaves this pass here, with the step it stopped at
+      if (out.status == PCG_ST_PENDING) {
+        A.flat_tstar[e] = s;
+        A.flat_hot[atomicAdd(A.flat_q + 1, 1)] = (int32_t)e;
+        break;
+      }
+    }
     if (A.rew_seq) A.rew_seq[(size_t)s * A.r_ss + e] = out.rew;
     if (A.obs_seq) store_obs<M, UNC>(A, c, out, A.obs_seq + (size_t)s * A.o_ss + e, A.o_cs);
     if (last || !A.obs_seq) store_out<M, UNC>(A, c, e, out, A.obs + e);  // io->obs/rew/done hold the last step
@@ -1730,6 +1743,7 @@ __global__ __launch_bounds__(tb(LDS_STAGES, INTEG, M::NX, ros_structured<M>::val
 
 }  // namespace pcg
 #include "pcg_step_queue.hpp"
+#include "pcg_rollout_flat.hpp"
 namespace pcg {
 
 using StepFn = void (*)(const StepArgs);
@@ -1781,6 +1795,7 @@ struct Kernels {
   StepFn roll_lean[2];               // RK4 lean fused rollout [EPL-1] (may be null)
   StepFn rollout[PCG_INT_COUNT][2];  // [integrator][lds_stages]
   StepFn rollout_unc[PCG_INT_COUNT]; // fused rollout with per-env parameters (RK4, DOPRI5; null for affine)
+  StepFn roll_hot;                   // second pass of the barrier-free rollout of a PCG_INT_T5G plan (models with a guard)
   RhsKFn rhs;
   IntKFn integ[PCG_INT_COUNT][2];
   int nx, na, ndm, nraw;
@@ -1828,6 +1843,7 @@ Kernels make_kernels() {
     k.integ[PCG_INT_RK4G][0] = k.integ[PCG_INT_RK4G][1] = integrate_kernel<M, PCG_INT_RK4G, false>;
     k.rollout[PCG_INT_RK4G][0] = k.rollout[PCG_INT_RK4G][1] = rollout_kernel<M, PCG_INT_RK4G, false>;
   }
+  if constexpr (has_guard<M>::value && !M::DYNAMIC) k.roll_hot = rollout_kernel_hot<M>;
   if constexpr (has_guard<M>::value) {  // guarded fixed-step Tsit5: the same set
     k.step[PCG_INT_T5G][0][0][0] = k.step[PCG_INT_T5G][0][0][1] = step_kernel<M, PCG_INT_T5G, false, false, true>;
     k.step[PCG_INT_T5G][1][0][0] = k.step[PCG_INT_T5G][1][0][1] = step_kernel<M, PCG_INT_T5G, true, false, true>;
