@@ -48,6 +48,7 @@ __global__ __launch_bounds__(FLAT_BLOCK) void rollout_kernel_hot(const StepArgs 
   EnvPre<M> pre;
   DpLane<NX> L;
   bool drained = n_items <= 0;  // wave-uniform
+  const int every = A.q_tile > 0 ? A.q_tile : 1;  // the step boundaries run every that many iterations (host: FLAT_EVERY)
   // every spin is bounded (max_steps bounds each env step): a logic error becomes a flagged result, not a hung GPU
   const long long cap64 = ((long long)c.max_steps + 8) * (long long)T * 4 + 64;
   for (long long iter = 0; iter < cap64 * 64; ++iter) {
@@ -73,31 +74,7 @@ __global__ __launch_bounds__(FLAT_BLOCK) void rollout_kernel_hot(const StepArgs 
       }
     }
     if (__ballot(e >= 0) == 0ull) break;
-    if (phase == START) {  // the step's action, the pre-step half, and what the guard says about the start state
-      double a[NA];
-      const double* as = A.a_seq + (size_t)s * A.a_ss;
-#pragma unroll
-      for (int i = 0; i < NA; ++i) a[i] = as[(size_t)i * A.a_cs + e];
-      env_pre<M, false, true>(A, c, nullptr, e, A.t_scalar + s, a, x, pre);
-      const typename M::Hold hold = M::hold(kp, pre.u);
-      double k1[NX], g, rho;
-      M::rhs_guard(kp, hold, x, k1, g, rho);
-      bool calm[1] = {true}, slow[1] = {true};
-      guard_acc<double, 1>(g, rho, c.h, T5G_SLOW_LIMIT, calm, slow);
-      if (calm[0] && slow[0]) {
-        phase = FIX;
-      } else {  // not trusted whatever the fixed step would give: the adaptive pair from the start state
-        const RhsFn<M> f{kp, hold};
-#pragma unroll
-        for (int i = 0; i < NX; ++i) L.x[i] = x[i];
-        L.t = 0.0;
-        L.acc = L.rej = 0;
-        L.rejected_last = false;
-        double d1;
-        L.h = dopri5_h_init<NX>(f, L.x, L.k1, NX, c.dt, c.rtol, c.atol, d1);
-        phase = ADAPT;
-      }
-    } else if (phase == ADAPT) {  // one attempted step of the adaptive pair
+    if (phase == ADAPT) {  // one attempted step of the adaptive pair
       const typename M::Hold hold = M::hold(kp, pre.u);
       const RhsFn<M> f{kp, hold};
       const int st = dopri5_attempt<NX>(f, L, NX, c.dt, c.dt_edge, c.h_floor, c.rtol, c.atol, c.max_steps);
@@ -107,6 +84,55 @@ __global__ __launch_bounds__(FLAT_BLOCK) void rollout_kernel_hot(const StepArgs 
         for (int i = 0; i < NX; ++i) x[i] = L.x[i];
         nacc = L.acc, nrej = L.rej, status = st;
         phase = POST;
+      }
+    }
+    // The step boundaries (POST of the finished step, START of the next one) cost the wave more instructions than an attempt
+    // of this two-state model (~650 against ~550), whichever lanes need them: they run every `every`-th iteration -- a lane that
+    // finishes in between waits -- or at once when no lane of the wave is mid-step (measured: profiles/r6/flat_rollout.txt).
+    const bool boundary = (iter % every) == 0 || __ballot(phase == ADAPT) == 0ull;
+    if (!boundary) continue;
+    if (phase == POST) {  // the post-step half and the outputs of step s, each at its own place in the trajectories
+      if (A.nsteps) {
+        A.nsteps[e] = nacc;
+        A.nsteps[B + e] = nrej;
+      }
+      EnvOut<M> out;
+      env_post<M, false, true, false>(A, c, nullptr, e, A.t_scalar + s, pre, x, finite_status<NX>(status, x, NX), out);
+      if (A.rew_seq) A.rew_seq[(size_t)s * A.r_ss + e] = out.rew;
+      if (A.obs_seq) store_obs<M, false>(A, c, out, A.obs_seq + (size_t)s * A.o_ss + e, A.o_cs);
+      if (s == T - 1 || !A.obs_seq) store_out<M, false>(A, c, e, out, A.obs + e);
+      ++s;
+      if (s == T) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) A.x[(size_t)i * B + e] = x[i];
+        e = -1;
+        phase = IDLE;
+      } else {
+        phase = START;
+      }
+    }
+    if (phase == START) {  // the step's action, the pre-step half, and what the guard says about the start state
+      double a[NA];
+      const double* as = A.a_seq + (size_t)s * A.a_ss;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a[i] = as[(size_t)i * A.a_cs + e];
+      env_pre<M, false, true>(A, c, nullptr, e, A.t_scalar + s, a, x, pre);
+      const typename M::Hold hold = M::hold(kp, pre.u);
+      double g, rho;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) L.x[i] = x[i];
+      M::rhs_guard(kp, hold, L.x, L.k1, g, rho);  // k1 = f(x): the same bits as rhs() (pcg_models.hpp)
+      bool calm[1] = {true}, slow[1] = {true};
+      guard_acc<double, 1>(g, rho, c.h, T5G_SLOW_LIMIT, calm, slow);
+      if (calm[0] && slow[0]) {
+        phase = FIX;
+      } else {  // not trusted whatever the fixed step would give: the adaptive pair from the start state
+        const RhsFn<M> f{kp, hold};
+        L.t = 0.0;
+        L.acc = L.rej = 0;
+        L.rejected_last = false;
+        L.h = dopri5_h_init_k1<NX>(f, L.x, L.k1, NX, c.dt, c.rtol, c.atol);
+        phase = ADAPT;
       }
     }
     if (phase == FIX) {  // (rare in this pass: an env that was handed over and whose start guard holds again)
@@ -129,26 +155,6 @@ __global__ __launch_bounds__(FLAT_BLOCK) void rollout_kernel_hot(const StepArgs 
         double d1;
         L.h = dopri5_h_init<NX>(f, L.x, L.k1, NX, c.dt, c.rtol, c.atol, d1);
         phase = ADAPT;
-      }
-    }
-    if (phase == POST) {  // the post-step half and the outputs of step s, each at its own place in the trajectories
-      if (A.nsteps) {
-        A.nsteps[e] = nacc;
-        A.nsteps[B + e] = nrej;
-      }
-      EnvOut<M> out;
-      env_post<M, false, true, false>(A, c, nullptr, e, A.t_scalar + s, pre, x, finite_status<NX>(status, x, NX), out);
-      if (A.rew_seq) A.rew_seq[(size_t)s * A.r_ss + e] = out.rew;
-      if (A.obs_seq) store_obs<M, false>(A, c, out, A.obs_seq + (size_t)s * A.o_ss + e, A.o_cs);
-      if (s == T - 1 || !A.obs_seq) store_out<M, false>(A, c, e, out, A.obs + e);
-      ++s;
-      if (s == T) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) A.x[(size_t)i * B + e] = x[i];
-        e = -1;
-        phase = IDLE;
-      } else {
-        phase = START;
       }
     }
   }

@@ -138,6 +138,28 @@ PCG_DEV double dopri5_h_init(const F& f, const double (&x)[NX], double (&k1)[NX]
   return fmin(qtrunc6(fmin(100.0 * h0, h1)), dt);
 }
 
+// ... with k1 = f(x) already there (the barrier-free rollout has it from the guard's evaluation at the start state: the same
+// bits): the statements of dopri5_h_init() after the first right-hand side
+template <int NX, class F>
+PCG_DEV double dopri5_h_init_k1(const F& f, const double (&x)[NX], const double (&k1)[NX], int n, double dt, double rtol,
+                                double atol) {
+#pragma clang fp contract(off)
+  double y[NX], w[NX];
+  const double d0 = rms_scaled<NX>(x, x, x, n, rtol, atol);
+  const double d1 = rms_scaled<NX>(k1, x, x, n, rtol, atol);
+  double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+  h0 = fmin(h0, dt);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) y[i] = axpy(h0, k1[i], x[i]);
+  f(y, w);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) w[i] -= k1[i];
+  const double d2 = rms_scaled<NX>(w, x, x, n, rtol, atol) / h0;
+  const double dm = fmax(d1, d2);
+  const double h1 = (dm <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : ctrl_pow(dm * dm * 1e4, 1.0);
+  return fmin(qtrunc6(fmin(100.0 * h0, h1)), dt);
+}
+
 // one attempted step (the body of dopri5()'s loop).  Returns -1 to continue, else the final PCG_ST_* status
 // (PCG_ST_OK: reached dt; on failure the caller poisons the state).
 template <int NX, class F>
