@@ -1508,7 +1508,7 @@ int pcg_rollout_strided(pcg_plan* p, const pcg_buffers* io, int32_t t0, int32_t 
     if (rc != PCG_OK) return rc;
     int wps = 3;  // persistent waves per SIMD of the second pass (measured: profiles/r6/flat_rollout.txt)
     if (const char* ev = std::getenv("PCG_FLAT_WPS")) wps = std::max(1, std::min(8, std::atoi(ev)));  // measurement switch
-    a.q_tile = 3;  // ... and the cadence of its step boundaries (rollout_kernel_hot: `every`)
+    a.q_tile = 2;  // ... and the cadence of its step boundaries (rollout_kernel_hot: `every`)
     if (const char* ev = std::getenv("PCG_FLAT_EVERY")) a.q_tile = std::max(1, std::min(64, std::atoi(ev)));  // measurement switch
     hipLaunchKernelGGL(cov(k.roll_hot), dim3((unsigned)(p->num_cus * wps)), dim3(FLAT_BLOCK), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();

@@ -32,8 +32,14 @@ namespace pcg {
 constexpr int FLAT_BLOCK = 256;
 constexpr int FLAT_REFILL = 8;  // idle lanes that trigger a pull from the hand-over list (or: no busy lane left)
 
+#ifndef PCG_FLAT_WPE
+#define PCG_FLAT_WPE 1  // min waves per SIMD asked of the register allocator (A/B builds)
+#endif
+#ifndef PCG_FLAT_ATT
+#define PCG_FLAT_ATT 2  // attempts of the adaptive pair per loop iteration (A/B builds)
+#endif
 template <class M>
-__global__ __launch_bounds__(FLAT_BLOCK) void rollout_kernel_hot(const StepArgs A) {
+__global__ __launch_bounds__(FLAT_BLOCK, PCG_FLAT_WPE) void rollout_kernel_hot(const StepArgs A) {
   CDevConst& c = *A.C;
   constexpr int NX = M::NX, NA = M::NA;
   const int64_t B = A.B;
@@ -44,7 +50,7 @@ __global__ __launch_bounds__(FLAT_BLOCK) void rollout_kernel_hot(const StepArgs 
   enum { IDLE = 0, START = 1, FIX = 2, ADAPT = 3, POST = 4 };
   int64_t e = -1;
   int s = 0, phase = IDLE, nacc = 0, nrej = 0, status = PCG_ST_OK;
-  double x[NX];
+  double x[NX], a_nxt[NA];  // a_nxt: the action of step s, in flight since the previous step's START
   EnvPre<M> pre;
   DpLane<NX> L;
   bool drained = n_items <= 0;  // wave-uniform
@@ -69,6 +75,8 @@ __global__ __launch_bounds__(FLAT_BLOCK) void rollout_kernel_hot(const StepArgs 
           s = A.flat_tstar[e];
 #pragma unroll
           for (int i = 0; i < NX; ++i) x[i] = A.x[(size_t)i * B + e];
+#pragma unroll
+          for (int i = 0; i < NA; ++i) a_nxt[i] = A.a_seq[(size_t)s * A.a_ss + (size_t)i * A.a_cs + e];
           phase = START;
         }
       }
@@ -77,7 +85,10 @@ __global__ __launch_bounds__(FLAT_BLOCK) void rollout_kernel_hot(const StepArgs 
     if (phase == ADAPT) {  // one attempted step of the adaptive pair
       const typename M::Hold hold = M::hold(kp, pre.u);
       const RhsFn<M> f{kp, hold};
-      const int st = dopri5_attempt<NX>(f, L, NX, c.dt, c.dt_edge, c.h_floor, c.rtol, c.atol, c.max_steps);
+      int st = dopri5_attempt<NX>(f, L, NX, c.dt, c.dt_edge, c.h_floor, c.rtol, c.atol, c.max_steps);
+#pragma unroll
+      for (int r = 1; r < PCG_FLAT_ATT; ++r)
+        if (st < 0) st = dopri5_attempt<NX>(f, L, NX, c.dt, c.dt_edge, c.h_floor, c.rtol, c.atol, c.max_steps);
       if (st >= 0) {
         poison_if_failed<NX>(st, L.x);
 #pragma unroll
@@ -113,9 +124,13 @@ __global__ __launch_bounds__(FLAT_BLOCK) void rollout_kernel_hot(const StepArgs 
     }
     if (phase == START) {  // the step's action, the pre-step half, and what the guard says about the start state
       double a[NA];
-      const double* as = A.a_seq + (size_t)s * A.a_ss;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) a[i] = as[(size_t)i * A.a_cs + e];
+      for (int i = 0; i < NA; ++i) a[i] = a_nxt[i];
+      if (s + 1 < T) {  // the next step's action travels while this step is integrated (a scattered 8-byte load per lane)
+        const double* as = A.a_seq + (size_t)(s + 1) * A.a_ss;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a_nxt[i] = as[(size_t)i * A.a_cs + e];
+      }
       env_pre<M, false, true>(A, c, nullptr, e, A.t_scalar + s, a, x, pre);
       const typename M::Hold hold = M::hold(kp, pre.u);
       double g, rho;

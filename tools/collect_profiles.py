@@ -18,7 +18,7 @@ def last(f):
     return lines[-1] if lines else None
 
 
-for w in "cstr cstr_safe cstr_rollout cstr_unc four_tank me10 me10_ros4 me10_ros5 me20 cryst cryst_cv8 mixed".split():
+for w in "cstr cstr_safe cstr_rollout cstr_safe_rollout cstr_unc four_tank me10 me10_ros4 me10_ros5 me20 cryst cryst_cv8 mixed".split():
     src = os.path.join(ROOT, "gpurun_out", "prof_" + w)
     if not os.path.exists(os.path.join(src, "summary.txt")):
         continue

@@ -4,7 +4,7 @@
 # the TCC block has 4 counter slots, FETCH_SIZE takes 3 and WRITE_SIZE 2), then tools/pmc_json.py condenses them.
 #   usage: tools/prof_all.sh [workload ...]      output: gpurun_out/prof_<workload>/summary.txt, gpurun_out/pmc.json
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-WLS=${@:-cstr cstr_safe cstr_rollout cstr_unc four_tank me10 me10_ros4 me10_ros5 me20 cryst cryst_cv8 mixed}
+WLS=${@:-cstr cstr_safe cstr_rollout cstr_safe_rollout cstr_unc four_tank me10 me10_ros4 me10_ros5 me20 cryst cryst_cv8 mixed}
 for w in $WLS; do
   extra="--workload $w"
   PROF_PMC_STEPS=${PROF_PMC_STEPS:-118} PROF_PMC_WARMUP=${PROF_PMC_WARMUP:-12} bash $ROOT/tools/prof.sh $w $extra > /dev/null 2>&1
