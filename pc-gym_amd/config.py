@@ -17,7 +17,9 @@ New optional keys (do not exist in the reference):
                cap the exponent per remaining step), acts only on models with a contraction-rate hook (extraction cascades)
   cooperative  rodas4 / rodas5 on multistage_extraction with eq_exponent == 2 only: {'thr': 60} | False -- env steps whose
                predicted cost (attempts of the pair, a per-env rule) reaches thr take SEULEX-8, eight lanes per env in the
-               work-queue kernel (pcgym_hip.h: coop_thr; pcg_seulex.hpp); on by default under rodas4, OPT-IN under rodas5
+               work-queue kernel (pcgym_hip.h: coop_thr; pcg_seulex.hpp); on by default under rodas4, OPT-IN under rodas5 (there
+               SEULEX-8 runs at 4 x 8e-8: worst 1.4e-6 of a 1e-13 solve over the action box against 8e-7 for the pair alone,
+               tests/test_rodas5.py)
   substeps     RK4 sub-steps per env step
   rtol, atol   DOPRI5 tolerances (default 1e-8, integrator.py:61)
   max_steps    DOPRI5 step budget per env step
