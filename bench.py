@@ -9,6 +9,8 @@ Default workload (config.workload = "cstr_b2^20_rk4_fp64", BASELINE configs[1], 
 A "step" = ONE pass of the hot path over the whole batch (pcg_step launches: one per model segment); episodes are
 N-1 steps long and the reset that ends each episode is inside the timed region (fused into the episode's last step
 launch, pcg_step_autoreset).  value = total env-steps / wall time (max over ranks), whole job.
+Launch form (round 6): the consecutive plain steps of an episode are recorded as ONE HIP graph (pcg_graph_*: the same step
+kernels with the same arguments) before the timed region and replayed inside it; --eager issues them one by one.
 
 --workload selects the other BASELINE configurations (parity-test cases made measurable; not the headline):
   cstr_safe  the headline's envs / dt / actions under the model's DEFAULT plan (guarded RK4 with adaptive fallback) on the
@@ -509,12 +511,15 @@ def main():
     ap.add_argument("--separate-reset", action="store_true",
                     help="end each episode with a separate pcg_reset launch instead of the fused pcg_step_autoreset (A/B)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay whole episodes as HIP graphs (pcg_graph_*) instead of eager launches (the mixed workload "
-                         "does by default: one graph per segment and episode)")
+                    help="replay the consecutive plain steps of every episode as one HIP graph (pcg_graph_*) instead of eager "
+                         "launches -- also partial episodes, e.g. --steps 20 (the mixed workload does by default: one graph per "
+                         "segment and episode)")
     ap.add_argument("--work-queue", action="store_true",
                     help="single-model adaptive workloads: route the plan through the in-workgroup work queue whatever the "
                          "model (PCG_OPT_VARIANT 5), e.g. --workload cstr_safe --integrator dopri5 --work-queue")
-    ap.add_argument("--eager", action="store_true", help="mixed workload: eager pcg_step launches instead of the graphs")
+    ap.add_argument("--eager", action="store_true",
+                    help="plain pcg_step launches instead of the HIP graphs (the default since round 6 for every workload: the "
+                         "consecutive plain steps of an episode are one graph launch, recorded before the timed region)")
     ap.add_argument("--substeps", type=int, default=None,
                     help="cstr workload: RK4 sub-steps per env step (1 = the headline; other values are probes)")
     ap.add_argument("--status", type=int, default=1, help="write the per-env status byte (0 = off, A/B)")
@@ -524,6 +529,11 @@ def main():
     ap.add_argument("--coop-thr", type=float, default=None,
                     help="me10_ros4 / mixed: threshold of the cooperative rule of the Rodas4 plan (0 = off; default: the plan's)")
     args = ap.parse_args()
+    # Round 6: HIP graphs are the default launch form of the single-model workloads too (the mixed shard's since round 4):
+    # same kernels, same arguments, no launch-to-launch gaps -- measured on the headline 13.58 -> 12.50 us per step in the default
+    # shape and 15.2 -> 14.5 in a 20-step region (profiles/r6/graph_default.txt).  --eager gives the plain launches.
+    if not args.eager and args.workload != "mixed":
+        args.graph = True
 
     import numpy as np
     import torch
@@ -677,7 +687,31 @@ def main():
         torch.cuda.synchronize()
         plan, bufp, buf, sptr = env._plan, env._bufp, env._buf, stream.cuda_stream
         last_t = env.N - 1
-        graph = env.capture_steps([acts[j % n_act] for j in range(last_t)]) if args.graph else None
+        graph = None
+        graphs = {}  # --graph: (first step, steps) -> the recorded launches (pcg_graph_*), created before the timed region
+
+        def graph_for(t0, m):
+            if (t0, m) not in graphs:
+                t_now, env.t = env.t, t0
+                try:
+                    graphs[(t0, m)] = env.capture_steps([acts[(t0 + j) % n_act] for j in range(m)])
+                finally:
+                    env.t = t_now
+            return graphs[(t0, m)]
+
+        def chunks(t, n):
+            """the runs of consecutive steps of one episode that n steps from step t fall into: (first step, steps)"""
+            out, i = [], 0
+            while i < n:
+                m = min(last_t - t, n - i)
+                out.append((t, m))
+                i += m
+                t = (t + m) % last_t
+            return out
+
+        def graph_len(t, m):
+            """steps of the chunk (t, m) replayed as a graph: all but the episode's last one, whose launch carries the reset"""
+            return (m - 1 if t + m == last_t and not args.separate_reset else m) if args.graph else 0
         brackets = []
         stepsum = [0.0, 0.0, 0]  # accepted, rejected, samples (adaptive workloads)
 
@@ -729,11 +763,15 @@ def main():
                 if timed:
                     eb, ee = ev_pool[len(brackets)]
                     eb.record(stream)
-                if graph is not None and t == 0 and m == last_t:
-                    graph.replay()
+                mg = graph_len(t, m)
+                if mg >= 2:  # the chunk's plain steps as ONE graph launch (same kernels, no launch-to-launch gaps)
+                    graph_for(t, mg).replay()
+                    t += mg
                 else:
+                    mg = 0
+                if mg < m:
                     seed = env._episode_seed()
-                    for j in range(m):
+                    for j in range(m - mg):
                         buf.a = a_ptrs[t % n_act]
                         if t == last_t - 1 and not args.separate_reset:
                             # last step of the episode: the reset of the (lock-stepped) batch happens inside the same
@@ -763,6 +801,11 @@ def main():
         offs[rank] = float(first)
         dist.all_reduce(offs)
         rank_offsets = [int(v) for v in offs.tolist()]
+    if not mixed and args.graph and not roll:
+        # every graph the warm-up and the timed region will replay is recorded and instantiated here, outside both
+        for t0, m in chunks(env.t, W) + chunks((env.t + W) % last_t, K):
+            if graph_len(t0, m) >= 2:
+                graph_for(t0, graph_len(t0, m))
     preheat_ms = clock_preheat(torch, dev, args.preheat_ms)
     run(W, False)
     # the timed region: K steps between (synchronize, barrier, synchronize) brackets.  With ONE rank there is no barrier and
@@ -1001,8 +1044,9 @@ def main():
                 rl["env_steps_per_launch"] = last_t
                 rl["algorithmic_bytes_per_launch"] = alg_bytes * last_t
             out["config"]["launch"] = (f"one pcg_rollout_strided launch per {last_t}-step episode (+ reset kernel, + copy of the "
-                                       "first observation row)" if roll else "eager pcg_step launches" if graph is None else
-                                       f"HIP graph of one {last_t}-step episode (pcg_graph_*)")
+                                       "first observation row)" if roll else "eager pcg_step launches" if not graphs else
+                                       f"HIP graphs (pcg_graph_*) of the consecutive plain steps of an episode: {len(graphs)} recorded before "
+                                       "the timed region; an episode's last step (same-launch reset) is a plain launch")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, threads=args.cpu_threads, all_legs=args.cpu_all_legs)
         print(json.dumps(out), flush=True)
