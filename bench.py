@@ -931,6 +931,8 @@ def main():
                         d["traffic_over_algorithmic"] = q["traffic_bytes_per_launch"] / (float(d["algorithmic_bytes_per_env_step"]) * d["envs"])
                         if "valu_issue_frac" in q:
                             d["valu_issue_frac"] = q["valu_issue_frac"]
+                        if "valu_issue_time_frac_by_class" in q:  # the segment's launch priced by instruction class (tools/pmc_json.py)
+                            d["valu_issue_time_frac_by_class"] = q["valu_issue_time_frac_by_class"]
             dom = max(segs_out, key=lambda d: d["kernel_avg_us"])
             out["roofline"] = {
                 "bound": "fp64_valu" if "fp64_frac" in dom else "hbm",
@@ -940,6 +942,7 @@ def main():
                 "frac": dom.get("fp64_frac", dom["hbm_frac"]),
                 "traffic": dom.get("traffic"),
                 "traffic_over_algorithmic": dom.get("traffic_over_algorithmic"),
+                "valu_issue_time_frac_by_class": dom.get("valu_issue_time_frac_by_class"),
                 "traffic_measured_in_run": False,
                 "copy_ceiling_GBps": COPY_CEILING["GBps"],
                 **({} if pmx else {"traffic_reason": pm_why}),
