@@ -35,7 +35,7 @@ def _params(extras):
     return p
 
 
-@pytest.mark.parametrize("B,extras", [(1 << 17, False), (70_001, True)])
+@pytest.mark.parametrize("B,extras", [(1 << 17, False), (70_001, True), (1 << 20, False)])  # the last: BASELINE configs[1]'s batch
 def test_flat_rollout_equals_stepping_and_the_oracle(B, extras):
     import torch
     from oracle import oracle as O
