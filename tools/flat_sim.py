@@ -107,3 +107,71 @@ for name, cA, cB, every, natt in (("first build: boundaries every iteration", 55
     print(f"{name:64s}: slowest wave {mx / 1e6:7.3f} M slots ({mx / base:5.2f} of the first build), mean {mean / 1e6:7.3f} M, {it} iterations")
 ideal = (att.sum() * 550 + hot.sum() * 650) / lanes
 print(f"ideal (every lane always busy with useful work): {ideal / 1e6:.3f} M slots per wave")
+
+
+def simulate_sorted(cA, cB, waves_per_wg, lanes_total, natt=1, overhead=80):
+    """contexts of a WORKGROUP sorted by phase every round (LDS), its waves taking slices of 64 of a kind; a round ends with a
+    barrier (its slowest wave); `overhead` slots per round for the sort, the context traffic and the barrier"""
+    per_wg = waves_per_wg * 64
+    nwg = max(1, lanes_total // per_wg)
+    n = len(order)
+    head = 0
+    e = -np.ones((nwg, per_wg), dtype=np.int64)
+    s = np.zeros((nwg, per_wg), dtype=np.int64)
+    rem = np.zeros((nwg, per_wg), dtype=np.int64)
+    cost = np.zeros(nwg)
+    while True:
+        idle = e < 0
+        need = int(idle.sum())
+        if need and head < n:
+            take = min(need, n - head)
+            idx = np.argwhere(idle)[:take]
+            ids = order[head:head + take]
+            head += take
+            e[idx[:, 0], idx[:, 1]] = ids
+            s[idx[:, 0], idx[:, 1]] = first[ids]
+            rem[idx[:, 0], idx[:, 1]] = -1
+        busy = e >= 0
+        act = busy.any(axis=1)
+        if not act.any():
+            break
+        nA = (busy & (rem > 0)).sum(axis=1)
+        nB = (busy & (rem <= 0)).sum(axis=1)
+        # slices of 64 of a kind; a remainder of fewer than 32 contexts of a kind WAITS for the next round (no mixed wave, no
+        # second turn): the round costs its dearest kind
+        rc = np.zeros(nwg)
+        run_a = np.zeros_like(busy)
+        run_b = np.zeros_like(busy)
+        for g in np.where(act)[0]:
+            ia = np.where(busy[g] & (rem[g] > 0))[0]
+            ib = np.where(busy[g] & (rem[g] <= 0))[0]
+            sa_, sb_ = len(ia) // 64 + (1 if len(ia) % 64 >= 32 else 0), len(ib) // 64 + (1 if len(ib) % 64 >= 32 else 0)
+            if sa_ + sb_ == 0:  # nothing fills half a wave: run what there is
+                sa_, sb_ = (1 if len(ia) else 0), (1 if len(ib) else 0)
+            while sa_ + sb_ > waves_per_wg:
+                if sa_ >= sb_:
+                    sa_ -= 1
+                else:
+                    sb_ -= 1
+            run_a[g, ia[: sa_ * 64]] = True
+            run_b[g, ib[: sb_ * 64]] = True
+            rc[g] = overhead + max(cA * natt if sa_ else 0, cB if sb_ else 0)
+        cost += rc
+        ad = run_a
+        rem = np.where(ad, np.maximum(rem - natt, 0), rem)
+        atb = run_b
+        fin = atb & (rem == 0)
+        s = np.where(fin, s + 1, s)
+        done = atb & (s >= T)
+        e = np.where(done, -1, e)
+        st = atb & ~done
+        rem[st] = att[s[st], e[st]]
+        rem = np.where(done, 0, rem)
+    return cost.max(), cost.mean()
+
+
+print("# contexts sorted by phase across the waves of a workgroup every round (not built):")
+for wpw in (4, 8, 12):
+    for natt in (1, 2):
+        mx, mean = simulate_sorted(550, 650, wpw, lanes, natt)
+        print(f"  {wpw:2d} waves per workgroup, {natt} attempt(s) per round: slowest workgroup {mx / 1e6:7.3f} M slots ({mx / base:5.2f} of the first build), mean {mean / 1e6:7.3f} M")
