@@ -106,7 +106,8 @@ for wl in wls:
             if name and (name not in segs or c["_n"] > segs[name]["launches_in_pmc_pass"]):
                 segs[name] = entry(k, c, dur, wl)
         res[wl] = {"segments": segs, "build_id": BUILD_ID}
-    elif wl == "cstr_safe":
+    elif wl in ("cstr_safe", "cstr_safe_rollout"):
+        # (cstr_safe_rollout: an EPISODE is two launches -- the barrier-free rollout's two passes, pcg_rollout_flat.hpp)
         # a guarded plan's step is TWO launches (the guarded step of every env + the work-queue fix-up of the envs it marked):
         # per-step counters = the sum over both kernels' per-launch means; the duration is the sum of the two averages
         ks = [q for q in cs if cs[q]["_n"] >= 0.5 * max(v["_n"] for v in cs.values())]
